@@ -1,0 +1,113 @@
+"""Generate the golden model fixtures under tests/golden/ (BUILD CONTAINER ONLY).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Imports the reference's own Python
+model files from /root/reference over `oracle.ocnn_ref` (see oracle/ref_import.py),
+fills them with the closed-form synthetic weights of `hotformerloc_amd.synthetic`
+(profile 'stress'), runs the REFERENCE forward on CPU and stores inputs + outputs:
+
+    tests/golden/model_<case>.npz
+        cfg            name of the model cfg (file committed under hotformerloc_amd/configs/)
+        octree_depth   int
+        n_points       (B,) points per cloud
+        points         (sum n, 3) float32 -- clouds *after* the coordinate transform,
+                       i.e. exactly what `Points(...)` receives (dataset_utils.py:85-90)
+        descriptors    (B, 256) float32  -- reference `model(batch)['global']`
+        patch_embed_head / octf_out_head / feat_final_<d>_head / rt_final_<d>_head
+                       first 32 rows of reference intermediates (forward hooks)
+        *_sum          float64 checksums (sum, sum of squares) of the full intermediates
+
+Usage:  python -m oracle.gen_golden            (writes all cases)
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import                                   # noqa: E402
+from oracle.ocnn_ref import Octree, Points, merge_octrees        # noqa: E402
+from hotformerloc_amd import synthetic as syn                    # noqa: E402
+
+# case -> (cfg, octree depth, config_id, list of (n_points, kind))
+CASES = {
+    'wild_places_b3':     ('wild-places', 7, 1, [(4096, 'ball')] * 3),
+    'wild_places_b1':     ('wild-places', 7, 1, [(4096, 'ball')]),
+    'wild_places_ragged': ('wild-places', 7, 11, [(4096, 'ball'), (60, 'ball'), (700, 'forest'),
+                                                  (9, 'ball'), (4096, 'forest')]),
+    'cs_wild_places_b2':  ('cs-wild-places', 7, 3, [(6000, 'forest'), (4096, 'ball')]),
+    'oxford_b2':          ('oxford', 9, 5, [(4096, 'ball')] * 2),
+}
+
+
+def build_case(case):
+    cfg, depth, cid, spec = CASES[case]
+    cfg_path = os.path.join(ref_import.REFERENCE_ROOT, 'models', 'hotformerloc_%s_cfg.txt' % cfg)
+    model, params = ref_import.reference_model(cfg_path)
+    syn.fill_synthetic_weights(model, 'stress')
+    clouds = []
+    for i, (n, kind) in enumerate(spec):
+        seed = 1000 * cid + i
+        pc = syn.unit_ball_cloud(seed, n) if kind == 'ball' else syn.forest_cloud(seed, n)
+        if params.coordinates == 'cylindrical':
+            pc = syn.cylindrical(pc)
+        clouds.append(pc)
+    octs = []
+    for pc in clouds:
+        o = Octree(depth, 2)
+        o.build_octree(Points(torch.from_numpy(pc)))
+        octs.append(o)
+    octree = merge_octrees(octs)
+    octree.construct_all_neigh()
+
+    cap = {}
+    base = model.backbone.backbone
+    hooks = [
+        base.patch_embed.register_forward_hook(lambda m, i, o: cap.__setitem__('patch_embed', o)),
+        base.downsample[0].register_forward_hook(lambda m, i, o: cap.__setitem__('octf_out', o)),
+        base.hotf_stage.register_forward_hook(lambda m, i, o: cap.__setitem__('hotf', o)),
+    ]
+    with torch.inference_mode():
+        y = model({'octree': octree})['global']
+    for h in hooks:
+        h.remove()
+    assert torch.isfinite(y).all()
+
+    out = dict(cfg=np.array(cfg), octree_depth=np.array(depth),
+               n_points=np.array([c.shape[0] for c in clouds], dtype=np.int64),
+               points=np.concatenate(clouds, 0).astype(np.float32),
+               descriptors=y.numpy().astype(np.float32),
+               nnum_nempty=octree.nnum_nempty.numpy())
+
+    def put(name, t):
+        t = t.detach().double()
+        out[name + '_head'] = t[:32].float().numpy()
+        out[name + '_sum'] = np.array([t.sum().item(), (t * t).sum().item()])
+    put('patch_embed', cap['patch_embed'])
+    put('octf_out', cap['octf_out'])
+    feats, rts = cap['hotf']
+    for d in feats:
+        put('feat_final_%d' % d, feats[d])
+        put('rt_final_%d' % d, rts[d])
+    return out
+
+
+def main():
+    dst = os.path.join(ROOT, 'tests', 'golden')
+    os.makedirs(dst, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    for case in (sys.argv[1:] or CASES):
+        out = build_case(case)
+        path = os.path.join(dst, 'model_%s.npz' % case)
+        np.savez_compressed(path, **out)
+        d = out['descriptors']
+        print(case, out['n_points'].tolist(), 'nne', out['nnum_nempty'].tolist(),
+              'desc[0,:3]', d[0, :3], 'pairwise', np.round(d @ d.T, 3).tolist(),
+              '%.0f KB' % (os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    main()
