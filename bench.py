@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- clouds/s of the HOTFormerLoc encoder forward on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per
+GPU over RCCL.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by a barrier +
+`torch.cuda.synchronize()`; max over ranks; rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): batch of 32 synthetic 4096-point clouds per GPU,
+Wild-Places cfg (octree depth 7, cylindrical, K=48), forward only, eval mode, fp32, random-init
+style closed-form weights; the batch octree is resident on the device with neighbour tables
+built when the timed region starts (the reference's model boundary: `misc/torch_utils.py:47-51`
+happens before `model(batch)`).  A step = `model(batch)['global']` on every rank followed, for
+N > 1, by the RCCL all-gather of the (B_local,256) descriptors.  Weak scaling: each rank
+encodes its own contiguous slice of the global batch.
+
+Extra objects on the JSON line: `roofline` for the dominant hand-written kernel (windowed
+attention) from HIP events recorded around every launch inside the timed region, and
+`cpu_baseline` = the CPU oracle (a port of the reference forward) timed on this box's host cores
+on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='wild-places')
+    ap.add_argument('--batch', type=int, default=32, help='clouds per GPU')
+    ap.add_argument('--points', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=4, help='clouds in the CPU baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(params, depth, args):
+    """Oracle forward (port of the reference, torch CPU fp32) on the first `cpu_sample` clouds
+    of the same workload; returns the dict for the JSON line."""
+    import torch
+    from hotformerloc_amd import synthetic as syn
+    from oracle import hotformer_ref
+    from oracle.testing import oracle_octree, synthetic_state_dict
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic_state_dict(params, 'init')
+    warm = syn.make_clouds(2, 1, args.points, params.coordinates)
+    hotformer_ref.forward(sd, params, oracle_octree(warm, depth))            # warm-up, B=1
+    clouds = syn.make_clouds(2, args.cpu_sample, args.points, params.coordinates)
+    octree = oracle_octree(clouds, depth)                                    # boundary: prebuilt
+    t0 = time.perf_counter()
+    hotformer_ref.forward(sd, params, octree)
+    dt = time.perf_counter() - t0
+    return {'value': round(args.cpu_sample / dt, 4), 'unit': 'clouds/s', 'cores': cores,
+            'kind': 'port',
+            'sample': 'oracle forward, 1 batch of %d clouds x %d pts, %s cfg, %.1f s, torch %d threads'
+                      % (args.cpu_sample, args.points, args.config, dt, torch.get_num_threads())}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from hotformerloc_amd import build_batch_octree, load_config, model_factory, ops
+    from hotformerloc_amd import synthetic as syn
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d'
+                         % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    params, depth = load_config(args.config)
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'init')
+    model = model.to(dev).eval()
+
+    # this rank's contiguous slice of the global batch (ordered)
+    clouds = syn.make_clouds(2, args.batch, args.points, params.coordinates,
+                             first_index=rank * args.batch)
+    octree = build_batch_octree(clouds, depth, 2, dev, construct_neigh=True)
+    batch = {'octree': octree}
+    gathered = [torch.empty((args.batch, params.output_dim), device=dev) for _ in range(world)] \
+        if world > 1 else None
+
+    def step():
+        y = model(batch)['global']
+        if world > 1:
+            dist.all_gather(gathered, y.contiguous())
+        return y
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        with ops.KernelTimer() as timer:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                y = step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+        kern = timer.summary()
+    assert torch.isfinite(y).all()
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_clouds = args.batch * world * args.steps
+        n, ms, nbytes, flops = kern.get('hfl_window_attention_fwd', (0, 0.0, 0, 0))
+        roof = None
+        if n:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            roof = {'kernel': 'hfl_window_attention_fwd', 'bound': 'hbm',
+                    'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+                    'algorithmic_bytes_per_launch': int(nbytes / n),
+                    'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 2),
+                    'mfma_frac': round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+        others = {}
+        for name, (kn, kms, kb, kf) in kern.items():
+            others[name] = {'launches_per_step': kn // args.steps,
+                            'ms_per_step': round(kms / args.steps, 4),
+                            'GBps': round(kb / (kms * 1e-3) / 1e9, 1) if kms > 0 else None}
+        line = {
+            'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)', 'value': round(total_clouds / elapsed, 2),
+            'unit': 'clouds/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s cfg, batch=%d clouds/GPU x %d pts, octree depth %d, forward-only, '
+                                   'octree+neighbours resident' % (args.config, args.batch, args.points, depth),
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'collective': 'rccl all_gather (B_local,256) f32' if world > 1 else 'none'},
+            'roofline': roof, 'kernels': others,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(params, depth, args)
+            line['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,99 @@
+"""ctypes binding of libhotformerloc_hip.so (the C-ABI in include/hotformerloc_hip.h).
+
+The product path has NO CPU fallback: if the library is missing or a call fails,
+this module raises.  Build it with `python -m hotformerloc_amd.build`
+(or `__graft_entry__.build()`); it is loaded from `hotformerloc_amd/lib/` in-tree.
+"""
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libhotformerloc_hip.so')
+
+HFL_OCTREE_MAX_POINTS = 1 << 20
+HFL_OCTREE_MAX_DEPTH = 10
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class WindowAttnDesc(ctypes.Structure):
+    """hfl_window_attn_desc"""
+    _fields_ = [('n_tokens', c_int64), ('rt_row0', c_int64), ('n_windows', c_int32),
+                ('patch_size', c_int32), ('dilation', c_int32), ('n_relay', c_int32),
+                ('n_heads', c_int32), ('pos_bnd', c_int32), ('batch_size', c_int32),
+                ('scale', c_float)]
+
+
+# name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
+SIGNATURES = {
+    'hfl_version': (c_int, []),
+    'hfl_arch': (c_char_p, []),
+    'hfl_dwconv_forward_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                            c_int64, c_int, c_void_p]),
+    'hfl_dwconv_weight_backward_workspace': (c_int64, [c_int64, c_int64, c_int]),
+    'hfl_dwconv_weight_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                           c_int64, c_int, c_void_p, c_void_p]),
+    'hfl_inverse_neigh': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    'hfl_cpe_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_int64, c_int, c_float, c_int, c_void_p]),
+    'hfl_octree_scratch_bytes': (c_int64, [c_int64, c_int, c_int, c_int]),
+    'hfl_octree_build_clouds': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hfl_octree_merge': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    'hfl_octree_neigh': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                 c_int, c_void_p]),
+    'hfl_token_meta': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'hfl_octree_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
+                                         ctypes.POINTER(WindowAttnDesc), c_void_p]),
+    'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_float, c_void_p]),
+    'hfl_relay_token_init': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                     c_int64, c_void_p]),
+    'hfl_window_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    'hfl_segment_softmax': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            'libhotformerloc_hip.so not found at %s -- the HIP extension is required '
+            '(no CPU fallback); run `python -m hotformerloc_amd.build`' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError('symbol %s missing from %s' % (name, LIB_PATH)) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: 'HFL_EINVAL (unsupported shape/argument)',
+                -2: 'HFL_ECAPACITY (input exceeds a kernel limit)'}.get(rc, 'hipError %d' % rc)
+        raise NativeLibraryError('%s failed: %s' % (what, kind))
+
+
+def ptr_array(ptrs):
+    """host array of device pointers (for the pointer-table arguments)"""
+    arr = (c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

@@ -1,0 +1,331 @@
+// Windowed multi-head attention over z-order octree windows and ragged relay-token
+// self-attention for gfx950 (MI355X), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation).
+//
+// What the reference does for this step (models/octformer_backbone.py:59-88):
+// materialise an int64 (N,K,K,3) relative-position tensor and an int64 (N,K,K) mask per
+// depth (models/octree.py:186-222,272-283), gather the RPE table into an (N,H,K,K) fp32
+// bias (models/layers/octformer_layers.py:159-170), pad/permute tokens into windows
+// (models/octree.py:346-386) and call SDPA.  None of that is materialised here:
+//
+//   * one workgroup = one window, one wave = one head (head dim 16);
+//   * K and V fragments of the wave's head are loaded once, straight into the MFMA
+//     operand layout (16-B lane loads for Q/K), and stay in registers;
+//   * S^T = K Q^T per 16-query tile, so a lane owns ONE query column and 4T keys:
+//     the softmax reduction is over registers plus two 16-lane hops;
+//   * the additive bias is computed in registers: -1e3 where the batch ids differ
+//     (models/octree.py:66,267-270) + sum over axes of rpe_table[clamp(dx)+bnd+axis*n, h]
+//     read from an LDS copy of the table (head-major so a wave stays on one row);
+//   * P feeds the second MFMA directly as the A operand (key order inside a k-step is
+//     a permutation shared with the V fragment), O is normalised and scattered to the
+//     token rows: window (un)packing, dilation and padding are pure index arithmetic.
+#include "hfl_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kMaskValue = -1e3f;     // models/octree.py:66
+constexpr float kDeadValue = -1e30f;    // sequence positions that do not exist
+
+struct WinParams {
+  float* out;
+  const float* qkv;
+  const uint32_t* meta;
+  const float* table;
+  int64_t n_tokens;
+  int64_t rt_row0;
+  int n_windows;
+  int K;
+  int D;
+  int H;
+  int bnd;
+  int batch;
+  float scale;
+};
+
+// T = number of 16-wide tiles of the padded sequence (K/16 + G), G = relay tokens
+template <int T, int G>
+__global__ void __launch_bounds__(1024)
+window_attn_kernel(const WinParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LP = T * 16;                       // padded sequence length
+  const int H = p.H, K = p.K;
+  const int C = H * 16;
+  const int nrpe = 2 * p.bnd + 1;
+  int64_t* s_row = reinterpret_cast<int64_t*>(smem);                   // [LP]  qkv/out row
+  uint32_t* s_xyz = reinterpret_cast<uint32_t*>(s_row + LP);           // [LP]
+  int* s_bid = reinterpret_cast<int*>(s_xyz + LP);                     // [LP]  (-1 = dead)
+  float* s_tab = reinterpret_cast<float*>(s_bid + LP);                 // [H][3*nrpe]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, h = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+
+  if (p.table)
+    for (int i = tid; i < 3 * nrpe * H; i += blockDim.x) {
+      const int r = i / H, hh = i % H;               // table is (3*nrpe, H) row-major
+      s_tab[hh * 3 * nrpe + r] = p.table[i];
+    }
+  const float* tab = s_tab + h * 3 * nrpe + p.bnd;   // index by clamped delta directly
+
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
+    __syncthreads();
+    // sequence position j: j < K window token, j == K relay token (G), else dead
+    for (int j = tid; j < LP; j += blockDim.x) {
+      int bid = -1;
+      uint32_t xyz = 0;
+      int64_t row = 0;
+      if (j < K) {
+        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
+                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
+        if (t < p.n_tokens) {
+          xyz = p.meta[2 * t];
+          bid = (int)p.meta[2 * t + 1];
+          row = t;
+        }
+      } else if (G > 0 && j == K) {
+        const int64_t t0 = (int64_t)w * K;            // owner = batch id of the first token
+        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
+        row = p.rt_row0 + w;
+      }
+      s_xyz[j] = xyz;
+      s_bid[j] = bid;
+      s_row[j] = row;
+    }
+    __syncthreads();
+
+    // ---- K, V fragments of this head ------------------------------------------------
+    float4 kf[T];
+    float vf[T][4];
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      const int j = kt * 16 + c;
+      kf[kt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (s_bid[j] >= 0)
+        kf[kt] = *reinterpret_cast<const float4*>(p.qkv + s_row[j] * 3 * C + C + h * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jv = kt * 16 + 4 * g + r;
+        vf[kt][r] = s_bid[jv] >= 0 ? p.qkv[s_row[jv] * 3 * C + 2 * C + h * 16 + c] : 0.f;
+      }
+    }
+
+    // ---- one 16-query tile at a time ---------------------------------------------
+#pragma unroll 1
+    for (int qt = 0; qt < T; ++qt) {
+      const int qi = qt * 16 + c;                       // this lane's query
+      const int qbid = s_bid[qi];
+      const uint32_t qxyz = s_xyz[qi];
+      const bool q_is_rt = (G > 0) && qi == K;
+      float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qbid >= 0)
+        qf = *reinterpret_cast<const float4*>(p.qkv + s_row[qi] * 3 * C + h * 16 + 4 * g);
+      const int qx = (int)(qxyz & 1023u), qy = (int)((qxyz >> 10) & 1023u), qz = (int)(qxyz >> 20);
+
+      f32x4 s[T];
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf.w, acc, 0, 0, 0);
+        s[kt] = acc;
+      }
+
+      // bias + running max.  s[kt][r] is (key kt*16+4g+r, query qi)
+      float mx = kDeadValue;
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kj = kt * 16 + 4 * g + r;
+          const int kbid = s_bid[kj];
+          float v = s[kt][r] * p.scale;
+          if (kbid < 0) {
+            v = kDeadValue;
+          } else {
+            if (kbid != qbid) v += kMaskValue;
+            const bool k_is_rt = (G > 0) && kj == K;
+            if (p.table && !k_is_rt && !q_is_rt) {
+              const uint32_t kx = s_xyz[kj];
+              int dx = qx - (int)(kx & 1023u);
+              int dy = qy - (int)((kx >> 10) & 1023u);
+              int dz = qz - (int)(kx >> 20);
+              dx = min(max(dx, -p.bnd), p.bnd);
+              dy = min(max(dy, -p.bnd), p.bnd);
+              dz = min(max(dz, -p.bnd), p.bnd);
+              v += tab[dx] + tab[nrpe + dy] + tab[2 * nrpe + dz];
+            }
+          }
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(s[kt][r] - mx);
+          s[kt][r] = e;
+          sum += e;
+        }
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+
+      // O[query, d] = sum_keys P V : A = P (lane: query c, k-slot g), B = V (k-slot g, d = c)
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r] * inv, vf[kt][r], o, 0, 0, 0);
+      }
+      // o[r] is (query qt*16+4g+r, d = c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oq = qt * 16 + 4 * g + r;
+        if (s_bid[oq] >= 0) p.out[s_row[oq] * C + h * 16 + c] = o[r];
+      }
+    }
+  }
+}
+
+template <int T, int G>
+static int launch_window(const WinParams& p, hipStream_t s) {
+  constexpr int LP = T * 16;
+  const int nrpe = 2 * p.bnd + 1;
+  const size_t lds = (p.table ? (size_t)p.H * 3 * nrpe * 4 : 0) + (size_t)LP * (4 + 4 + 8);
+  int blocks = p.n_windows;
+  const int cap = hfl_num_cus() * 4;
+  if (blocks > cap) blocks = cap;
+  window_attn_kernel<T, G><<<blocks, p.H * 64, lds, s>>>(p);
+  HFL_RETURN_LAST_ERROR();
+}
+
+// ------------------------------------------------------------------------------
+// Relay-token self-attention.  One wave = (cloud, head, 16-query tile); keys are the
+// cloud's relay tokens listed in seq_rows; two passes over the key tiles (statistics,
+// then P V) so no accumulator rescaling is needed.
+__global__ void __launch_bounds__(256)
+relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
+                  const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ seq_off,
+                  int H, float scale) {
+  const int b = blockIdx.x;
+  const int r0 = seq_off[b];
+  const int R = seq_off[b + 1] - r0;
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int C = H * 16;
+  const int ntile = (R + 15) / 16;
+  const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  // work items of this block: (head, query tile)
+  for (int item = blockIdx.y * nwave + wave; item < H * ntile; item += gridDim.y * nwave) {
+    const int h = item / ntile, qt = item % ntile;
+    const int qi = qt * 16 + c;
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qi < R)
+      qf = *reinterpret_cast<const float4*>(qkv + (int64_t)seq_rows[r0 + qi] * 3 * C + h * 16 + 4 * g);
+    float m = kDeadValue, l = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      float inv = 0.f;
+      if (pass == 1) {
+        // combine the four k-slot groups' running (m, l)
+        float m2 = fmaxf(m, __shfl_xor(m, 16, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, 32, 64));
+        float l2 = l * __expf(m - m2);
+        l2 += __shfl_xor(l2, 16, 64);
+        l2 += __shfl_xor(l2, 32, 64);
+        m = m2;
+        inv = 1.0f / l2;
+      }
+      for (int kt = 0; kt < ntile; ++kt) {
+        const int kj = kt * 16 + c;
+        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kj < R)
+          kf = *reinterpret_cast<const float4*>(qkv + (int64_t)seq_rows[r0 + kj] * 3 * C + C + h * 16 + 4 * g);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = kt * 16 + 4 * g + r;
+          const float v = kk < R ? acc[r] * scale : kDeadValue;
+          if (pass == 0) {
+            const float mn = fmaxf(m, v);
+            l = l * __expf(m - mn) + __expf(v - mn);
+            m = mn;
+          } else {
+            const float pv = __expf(v - m) * inv;
+            const float vv = kk < R ? qkv[(int64_t)seq_rows[r0 + kk] * 3 * C + 2 * C + h * 16 + c] : 0.f;
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vv, o, 0, 0, 0);
+          }
+        }
+      }
+      if (pass == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int oq = qt * 16 + 4 * g + r;
+          if (oq < R) out[(int64_t)seq_rows[r0 + oq] * C + h * 16 + c] = o[r];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_meta,
+                             const float* rpe_table, const hfl_window_attn_desc* d,
+                             hfl_stream_t stream) {
+  if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
+  if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
+  if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
+  if (d->n_windows == 0) return HFL_OK;
+  WinParams p;
+  p.out = out; p.qkv = qkv; p.meta = tok_meta; p.table = rpe_table;
+  p.n_tokens = d->n_tokens; p.rt_row0 = d->rt_row0; p.n_windows = d->n_windows;
+  p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd;
+  p.batch = d->batch_size; p.scale = d->scale;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int T = d->patch_size / 16 + d->n_relay;
+  if (d->n_relay == 0) {
+    switch (T) {
+      case 1: return launch_window<1, 0>(p, s);
+      case 2: return launch_window<2, 0>(p, s);
+      case 3: return launch_window<3, 0>(p, s);
+      case 4: return launch_window<4, 0>(p, s);
+      default: return HFL_EINVAL;
+    }
+  }
+  switch (T) {
+    case 2: return launch_window<2, 1>(p, s);
+    case 3: return launch_window<3, 1>(p, s);
+    case 4: return launch_window<4, 1>(p, s);
+    case 5: return launch_window<5, 1>(p, s);
+    default: return HFL_EINVAL;
+  }
+}
+
+int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_rows,
+                            const int32_t* seq_off, int batch, int n_heads, float scale,
+                            hfl_stream_t stream) {
+  if (batch <= 0 || n_heads <= 0) return HFL_EINVAL;
+  dim3 grid((unsigned)batch, 4);
+  relay_attn_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(out, qkv, seq_rows, seq_off,
+                                                                        n_heads, scale);
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // extern "C"

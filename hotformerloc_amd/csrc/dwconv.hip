@@ -1,0 +1,374 @@
+// Octree depth-wise convolution for gfx950 (MI355X): forward / input-gradient,
+// weight-gradient, inverse neighbour table, and the fused CPE
+// (dwconv -> LayerNorm -> residual) used by the transformer blocks.
+//
+// Semantics: libs/dwconv/csrc/dwconv.cu:24-85 of the reference (3 CUDA kernels).
+// This is not a translation of them: the reference maps one thread to one output
+// float and re-reads the row's neighbour list per float.  Here a row is owned by
+// C/4 lanes that move 16 B each (a 256-channel row is one 1 KiB wave access), the
+// neighbour list is staged once per row through LDS, the 27xC tap weights live in
+// LDS for the whole persistent block, and taps are issued in batches of independent
+// 16-B gathers so a CU keeps tens of KiB in flight (HBM/L2-latency bound op).
+#include "hfl_common.h"
+
+namespace {
+
+constexpr int kMaxTaps = 27;
+constexpr int kMaxRowsPerBlock = 16;
+
+struct RowGeom {
+  int tpr;   // lanes per row = C/4
+  int rpb;   // rows per block
+};
+
+static RowGeom row_geom(int64_t channels) {
+  RowGeom g;
+  g.tpr = (int)(channels / 4);
+  g.rpb = 256 / g.tpr;
+  if (g.rpb < 1) g.rpb = 1;
+  if (g.rpb > kMaxRowsPerBlock) g.rpb = kMaxRowsPerBlock;
+  return g;
+}
+
+// ---------------------------------------------------------------- forward
+// LDS: [K*C] weights | [rpb*K] row indices
+template <typename IdxT, int KFIX>
+__global__ void __launch_bounds__(256) dwconv_fwd_vec4(float* __restrict__ out, const float* __restrict__ data,
+                                const float* __restrict__ weight, const IdxT* __restrict__ neigh,
+                                int64_t n_out, int C, int kngh, int tpr, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int K = KFIX > 0 ? KFIX : kngh;
+  float4* s_w = reinterpret_cast<float4*>(smem);
+  IdxT* s_idx = reinterpret_cast<IdxT*>(smem + (size_t)K * C * sizeof(float));
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+  const int c4n = C / 4;
+  for (int i = threadIdx.x; i < K * c4n; i += blockDim.x)
+    s_w[i] = reinterpret_cast<const float4*>(weight)[i];
+
+  for (int64_t base = (int64_t)blockIdx.x * rpb; base < n_out; base += (int64_t)gridDim.x * rpb) {
+    const int64_t h = base + ty;
+    const bool live = h < n_out;
+    __syncthreads();   // previous iteration's readers are done (and weights are staged)
+    if (live)
+      for (int k = tx; k < K; k += tpr) s_idx[ty * K + k] = neigh[h * K + k];
+    __syncthreads();
+    if (!live) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int B = 9;   // taps in flight per lane
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += B) {
+      float4 v[B];
+      bool ok[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int k = k0 + j;
+        int64_t ni = (k < K) ? (int64_t)s_idx[ty * K + k] : -1;
+        ok[j] = ni >= 0;
+        if (!ok[j]) ni = 0;
+        v[j] = reinterpret_cast<const float4*>(data + ni * C)[tx];
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int k = k0 + j;
+        if (k < K && ok[j]) acc = hfl_fma4(s_w[k * c4n + tx], v[j], acc);
+      }
+    }
+    reinterpret_cast<float4*>(out + h * C)[tx] = acc;
+  }
+}
+
+// any channel count (scalar lanes), used when C % 4 != 0 or C > 1024
+template <typename IdxT>
+__global__ void dwconv_fwd_scalar(float* __restrict__ out, const float* __restrict__ data,
+                                  const float* __restrict__ weight, const IdxT* __restrict__ neigh,
+                                  int64_t n_out, int64_t C, int K) {
+  const int64_t total = n_out * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t h = i / C, c = i % C;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int64_t ni = (int64_t)neigh[h * K + k];
+      if (ni >= 0) acc = fmaf(weight[k * C + c], data[ni * C + c], acc);
+    }
+    out[i] = acc;
+  }
+}
+
+template <typename IdxT>
+static int launch_fwd(float* out, const float* data, const float* weight, const IdxT* neigh,
+                      int64_t n_out, int64_t C, int K, hipStream_t s) {
+  if (n_out == 0) return HFL_OK;
+  if (C % 4 == 0 && C <= 1024 && K <= kMaxTaps) {
+    RowGeom g = row_geom(C);
+    const size_t lds = (size_t)K * C * sizeof(float) + (size_t)g.rpb * K * sizeof(IdxT);
+    const int64_t need = hfl_cdiv(n_out, g.rpb);
+    const int blocks = (int)(need < (int64_t)hfl_num_cus() * 8 ? need : (int64_t)hfl_num_cus() * 8);
+    if (K == 27)
+      dwconv_fwd_vec4<IdxT, 27><<<blocks, g.tpr * g.rpb, lds, s>>>(out, data, weight, neigh, n_out,
+                                                                   (int)C, K, g.tpr, g.rpb);
+    else
+      dwconv_fwd_vec4<IdxT, 0><<<blocks, g.tpr * g.rpb, lds, s>>>(out, data, weight, neigh, n_out,
+                                                                  (int)C, K, g.tpr, g.rpb);
+  } else {
+    const int64_t total = n_out * C;
+    const int64_t need = hfl_cdiv(total, 256);
+    const int blocks = (int)(need < 2048 ? need : 2048);
+    dwconv_fwd_scalar<IdxT><<<blocks, 256, 0, s>>>(out, data, weight, neigh, n_out, C, K);
+  }
+  HFL_RETURN_LAST_ERROR();
+}
+
+// ---------------------------------------------------------- weight gradient
+// partial[(block*rpb+ty), k, c] = sum over the rows this lane-row visited.
+template <typename IdxT>
+__global__ void __launch_bounds__(256) dwconv_wgrad_partial(float* __restrict__ partial, const float* __restrict__ grad,
+                                     const float* __restrict__ data, const IdxT* __restrict__ neigh,
+                                     int64_t n_rows, int C, int K, int tpr, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  IdxT* s_idx = reinterpret_cast<IdxT*>(smem);
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+  float4 acc[kMaxTaps];
+#pragma unroll
+  for (int k = 0; k < kMaxTaps; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t base = (int64_t)blockIdx.x * rpb; base < n_rows; base += (int64_t)gridDim.x * rpb) {
+    const int64_t h = base + ty;
+    const bool live = h < n_rows;
+    __syncthreads();
+    if (live)
+      for (int k = tx; k < K; k += tpr) s_idx[ty * K + k] = neigh[h * K + k];
+    __syncthreads();
+    if (!live) continue;
+    const float4 g = reinterpret_cast<const float4*>(grad + h * C)[tx];
+#pragma unroll
+    for (int k = 0; k < kMaxTaps; ++k) {
+      if (k < K) {
+        const int64_t ni = (int64_t)s_idx[ty * K + k];
+        if (ni >= 0) {
+          const float4 d = reinterpret_cast<const float4*>(data + ni * C)[tx];
+          acc[k] = hfl_fma4(d, g, acc[k]);
+        }
+      }
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * rpb + ty) * K * C);
+#pragma unroll
+  for (int k = 0; k < kMaxTaps; ++k)
+    if (k < K) dst[k * (C / 4) + tx] = acc[k];
+}
+
+// out[i] = sum_p partial[p, i] in a fixed order (bitwise reproducible)
+__global__ void dwconv_wgrad_reduce(float* __restrict__ out, const float* __restrict__ partial,
+                                    int n_partial, int64_t kc) {
+  __shared__ float s[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (i < kc)
+    for (int p = grp; p < n_partial; p += 4) acc += partial[(int64_t)p * kc + i];
+  s[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && i < kc) out[i] = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+}
+
+template <typename IdxT>
+__global__ void dwconv_wgrad_scalar(float* __restrict__ out, const float* __restrict__ grad,
+                                    const float* __restrict__ data, const IdxT* __restrict__ neigh,
+                                    int64_t n_rows, int64_t C, int K) {
+  // one thread per (k,c): slow generic path for odd channel counts
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)K * C) return;
+  const int k = (int)(i / C);
+  const int64_t c = i % C;
+  float acc = 0.f;
+  for (int64_t h = 0; h < n_rows; ++h) {
+    const int64_t ni = (int64_t)neigh[h * K + k];
+    if (ni >= 0) acc = fmaf(data[ni * C + c], grad[h * C + c], acc);
+  }
+  out[i] = acc;
+}
+
+static int wgrad_blocks(int64_t n_rows, int rpb) {
+  const int64_t need = hfl_cdiv(n_rows, (int64_t)rpb * 8);
+  int64_t b = need < 256 ? need : 256;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <typename IdxT>
+static int launch_wgrad(float* out, const float* grad, const float* data, const IdxT* neigh,
+                        int64_t n_rows, int64_t C, int K, void* workspace, hipStream_t s) {
+  if (C % 4 == 0 && C <= 1024 && K <= kMaxTaps) {
+    RowGeom g = row_geom(C);
+    const int blocks = wgrad_blocks(n_rows, g.rpb);
+    const size_t lds = (size_t)g.rpb * K * sizeof(IdxT);
+    float* partial = static_cast<float*>(workspace);
+    dwconv_wgrad_partial<IdxT><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows,
+                                                                  (int)C, K, g.tpr, g.rpb);
+    const int64_t kc = (int64_t)K * C;
+    dwconv_wgrad_reduce<<<(int)hfl_cdiv(kc, 64), 256, 0, s>>>(out, partial, blocks * g.rpb, kc);
+  } else {
+    const int64_t kc = (int64_t)K * C;
+    dwconv_wgrad_scalar<IdxT><<<(int)hfl_cdiv(kc, 256), 256, 0, s>>>(out, grad, data, neigh, n_rows, C, K);
+  }
+  HFL_RETURN_LAST_ERROR();
+}
+
+// ------------------------------------------------------------ inverse table
+template <typename IdxT>
+__global__ void inverse_neigh_kernel(IdxT* __restrict__ ineigh, const IdxT* __restrict__ neigh,
+                                     int64_t n_rows, int K) {
+  const int64_t total = n_rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t h = i / K;
+    const int k = (int)(i % K);
+    const int64_t j = (int64_t)neigh[i];
+    if (j >= 0) ineigh[j * K + k] = (IdxT)h;   // injective per column: no atomics needed
+  }
+}
+
+// ------------------------------------------------------------------ fused CPE
+// TPR lanes own one row (C = 4*TPR); LayerNorm statistics by butterfly over TPR lanes.
+template <int TPR>
+__global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, const float* __restrict__ x,
+                               const float* __restrict__ weight, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const int32_t* __restrict__ neigh,
+                               int64_t n_rows, int K, float eps, int residual) {
+  constexpr int C = TPR * 4;
+  constexpr int RPB = 256 / TPR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4* s_w = reinterpret_cast<float4*>(smem);
+  int32_t* s_idx = reinterpret_cast<int32_t*>(smem + (size_t)K * C * sizeof(float));
+  const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
+  for (int i = threadIdx.x; i < K * TPR; i += blockDim.x)
+    s_w[i] = reinterpret_cast<const float4*>(weight)[i];
+  const float4 gm = reinterpret_cast<const float4*>(gamma)[tx];
+  const float4 bt = reinterpret_cast<const float4*>(beta)[tx];
+
+  for (int64_t base = (int64_t)blockIdx.x * RPB; base < n_rows; base += (int64_t)gridDim.x * RPB) {
+    const int64_t h = base + ty;
+    const bool live = h < n_rows;
+    __syncthreads();
+    if (live)
+      for (int k = tx; k < K; k += TPR) s_idx[ty * K + k] = neigh[h * K + k];
+    __syncthreads();
+    // all lanes of a wave stay in the loop body: the butterflies below need every lane
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int B = 9;
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += B) {
+      float4 v[B];
+      bool ok[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int k = k0 + j;
+        int64_t ni = (live && k < K) ? (int64_t)s_idx[ty * K + k] : -1;
+        ok[j] = ni >= 0;
+        if (!ok[j]) ni = 0;
+        v[j] = reinterpret_cast<const float4*>(x + ni * C)[tx];
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int k = k0 + j;
+        if (k < K && ok[j]) acc = hfl_fma4(s_w[k * TPR + tx], v[j], acc);
+      }
+    }
+    const float inv_c = 1.0f / (float)C;
+    const float mean = hfl_group_sum<TPR>((acc.x + acc.y) + (acc.z + acc.w)) * inv_c;
+    const float4 d = make_float4(acc.x - mean, acc.y - mean, acc.z - mean, acc.w - mean);
+    const float var = hfl_group_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * inv_c;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float4 y = make_float4(fmaf(d.x * rstd, gm.x, bt.x), fmaf(d.y * rstd, gm.y, bt.y),
+                           fmaf(d.z * rstd, gm.z, bt.z), fmaf(d.w * rstd, gm.w, bt.w));
+    if (live) {
+      if (residual) {
+        const float4 xv = reinterpret_cast<const float4*>(x + h * C)[tx];
+        y.x += xv.x; y.y += xv.y; y.z += xv.z; y.w += xv.w;
+      }
+      reinterpret_cast<float4*>(out + h * C)[tx] = y;
+    }
+  }
+}
+
+template <int TPR>
+static int launch_cpe(float* out, const float* x, const float* w, const float* gamma,
+                      const float* beta, const int32_t* neigh, int64_t n, int K, float eps,
+                      int residual, hipStream_t s) {
+  constexpr int RPB = 256 / TPR;
+  const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * sizeof(int32_t);
+  const int64_t need = hfl_cdiv(n, RPB);
+  const int blocks = (int)(need < (int64_t)hfl_num_cus() * 8 ? need : (int64_t)hfl_num_cus() * 8);
+  cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual);
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" {
+
+int hfl_dwconv_forward_backward(float* out, const float* data, const float* weight,
+                                const void* neigh, int idx64, int64_t n_out, int64_t channels,
+                                int kngh, hfl_stream_t stream) {
+  if (n_out < 0 || channels <= 0 || kngh <= 0) return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (idx64)
+    return launch_fwd<int64_t>(out, data, weight, static_cast<const int64_t*>(neigh), n_out,
+                               channels, kngh, s);
+  return launch_fwd<int32_t>(out, data, weight, static_cast<const int32_t*>(neigh), n_out,
+                             channels, kngh, s);
+}
+
+int64_t hfl_dwconv_weight_backward_workspace(int64_t n_rows, int64_t channels, int kngh) {
+  if (channels % 4 != 0 || channels > 1024 || kngh > kMaxTaps) return 16;
+  RowGeom g = row_geom(channels);
+  return (int64_t)wgrad_blocks(n_rows, g.rpb) * g.rpb * kngh * channels * (int64_t)sizeof(float);
+}
+
+int hfl_dwconv_weight_backward(float* out, const float* grad, const float* data,
+                               const void* neigh, int idx64, int64_t n_rows, int64_t channels,
+                               int kngh, void* workspace, hfl_stream_t stream) {
+  if (n_rows < 0 || channels <= 0 || kngh <= 0) return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (idx64)
+    return launch_wgrad<int64_t>(out, grad, data, static_cast<const int64_t*>(neigh), n_rows,
+                                 channels, kngh, workspace, s);
+  return launch_wgrad<int32_t>(out, grad, data, static_cast<const int32_t*>(neigh), n_rows,
+                               channels, kngh, workspace, s);
+}
+
+int hfl_inverse_neigh(void* ineigh, const void* neigh, int idx64, int64_t n_rows, int kngh,
+                      hfl_stream_t stream) {
+  if (n_rows < 0 || kngh <= 0) return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t esz = idx64 ? 8 : 4;
+  hipError_t e = hipMemsetAsync(ineigh, 0xFF, (size_t)n_rows * kngh * esz, s);   // all -1
+  if (e != hipSuccess) return (int)e;
+  if (n_rows == 0) return HFL_OK;
+  const int64_t need = hfl_cdiv(n_rows * kngh, 256);
+  const int blocks = (int)(need < 4096 ? need : 4096);
+  if (idx64)
+    inverse_neigh_kernel<int64_t><<<blocks, 256, 0, s>>>(static_cast<int64_t*>(ineigh),
+                                                         static_cast<const int64_t*>(neigh), n_rows, kngh);
+  else
+    inverse_neigh_kernel<int32_t><<<blocks, 256, 0, s>>>(static_cast<int32_t*>(ineigh),
+                                                         static_cast<const int32_t*>(neigh), n_rows, kngh);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_cpe_forward(float* out, const float* x, const float* weight, const float* gamma,
+                    const float* beta, const int32_t* neigh, int64_t n_rows, int64_t channels,
+                    int kngh, float eps, int residual, hfl_stream_t stream) {
+  if (n_rows < 0 || kngh <= 0 || kngh > kMaxTaps) return HFL_EINVAL;
+  if (n_rows == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (channels) {
+    case 256: return launch_cpe<64>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 128: return launch_cpe<32>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 64:  return launch_cpe<16>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 32:  return launch_cpe<8>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    default:  return HFL_EINVAL;
+  }
+}
+
+}  // extern "C"

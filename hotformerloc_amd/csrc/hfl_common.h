@@ -1,0 +1,56 @@
+// Shared helpers for the HOTFormerLoc gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hotformerloc_hip.h"
+
+#define HFL_WAVE 64
+
+#define HFL_RETURN_LAST_ERROR()            \
+  do {                                     \
+    hipError_t e__ = hipGetLastError();    \
+    return e__ == hipSuccess ? HFL_OK : (int)e__; \
+  } while (0)
+
+static inline int hfl_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+      cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+static inline int64_t hfl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// index-table element access for int32 / int64 neighbour tables
+template <typename IdxT>
+__device__ __forceinline__ int64_t hfl_ld_idx(const IdxT* p, int64_t i) {
+  return (int64_t)p[i];
+}
+
+// wave-wide butterfly reductions over the low `width` lanes groups (width power of 2)
+template <int WIDTH>
+__device__ __forceinline__ float hfl_group_sum(float v) {
+#pragma unroll
+  for (int m = WIDTH / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, HFL_WAVE);
+  return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float hfl_group_max(float v) {
+#pragma unroll
+  for (int m = WIDTH / 2; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, HFL_WAVE));
+  return v;
+}
+
+__device__ __forceinline__ float4 hfl_fma4(float4 a, float4 b, float4 c) {
+  c.x = fmaf(a.x, b.x, c.x);
+  c.y = fmaf(a.y, b.y, c.y);
+  c.z = fmaf(a.z, b.z, c.z);
+  c.w = fmaf(a.w, b.w, c.w);
+  return c;
+}

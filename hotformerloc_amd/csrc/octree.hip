@@ -1,0 +1,465 @@
+// Batched octree construction on gfx950 (MI355X).
+//
+// What it replaces (reference call sites): ocnn `Octree.build_octree` per cloud in
+// dataloader workers + `merge_octrees` (datasets/dataset_utils.py:89-94,
+// eval/pnv_evaluate.py:173-175,123) and `construct_all_neigh` after the H2D copy
+// (misc/torch_utils.py:47-51).  Semantics restated in SURVEY.md Appendix A and pinned
+// by ocnn's fixtures (tests/golden/ocnn).
+//
+// MI355X-first design: one 1024-lane workgroup owns one cloud.  The cloud's
+// (shuffled key << 32 | point index) pairs are sorted by a bitonic network that
+// lives in the CU's 160 KiB LDS (up to 16384 points = 128 KiB resident; larger clouds run
+// the strides >= 16384 of the same network through L2), leaves are
+// found with a workgroup scan, per-leaf point averages are accumulated in original
+// point order (the order of a sequential scatter-add), and every coarser level is
+// produced by one more scan over the previous level's unique keys.  A second launch
+// merges the per-cloud pieces into batch arrays once the host has sized them.
+#include "hfl_common.h"
+
+namespace {
+
+constexpr int kBuildThreads = 1024;
+constexpr int kLdsChunk = 16384;   // 128 KiB of (key,index) pairs per workgroup
+constexpr int kMaxDepthSlots = HFL_OCTREE_MAX_DEPTH + 1;
+
+__device__ __forceinline__ uint32_t shuffle_key(uint32_t x, uint32_t y, uint32_t z, int depth) {
+  uint32_t key = 0;
+  for (int i = 0; i < depth; ++i)
+    key |= (((x >> i) & 1u) << (3 * i + 2)) | (((y >> i) & 1u) << (3 * i + 1)) |
+           (((z >> i) & 1u) << (3 * i));
+  return key;
+}
+
+__device__ __forceinline__ void unshuffle_key(uint32_t key, int depth, int& x, int& y, int& z) {
+  x = y = z = 0;
+  for (int i = 0; i < depth; ++i) {
+    x |= ((key >> (3 * i + 2)) & 1u) << i;
+    y |= ((key >> (3 * i + 1)) & 1u) << i;
+    z |= ((key >> (3 * i)) & 1u) << i;
+  }
+}
+
+// exclusive scan of one int per thread over a 1024-thread block; returns the
+// exclusive prefix, *total = block sum.  s_wave: 17 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int* s_wave, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  __syncthreads();                       // s_wave may still be read from a previous call
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < kBuildThreads / 64; ++w) {
+      const int t = s_wave[w];
+      s_wave[w] = run;
+      run += t;
+    }
+    s_wave[16] = run;
+  }
+  __syncthreads();
+  *total = s_wave[16];
+  return s_wave[wave] + incl - v;
+}
+
+struct ScratchView {
+  uint32_t* skey;   // [(depth-full_depth+1)][P]  sorted unique keys per level, per cloud
+  uint32_t* slot;   // [(depth-full_depth)][P]    8*parent_rank + octant
+  unsigned long long* spairs;   // [B][np_stride]  sorted (key << 32 | point index) per cloud
+  int64_t np_stride;
+  int64_t P;
+  int full_depth;
+  __device__ __host__ uint32_t* key_at(int d) const { return skey + (int64_t)(d - full_depth) * P; }
+  __device__ __host__ uint32_t* slot_at(int d) const { return slot + (int64_t)(d - full_depth - 1) * P; }
+};
+
+static int next_pow2(int64_t n) {
+  int p = 2;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+static int64_t level_words(int64_t P, int depth) {
+  // (depth - full_depth + 1) key levels + (depth - full_depth) slot levels <= 2*depth + 1,
+  // rounded up to an even count so the u64 pair region behind it stays 8-byte aligned
+  return (int64_t)(2 * depth + 2) * P + (((int64_t)(2 * depth + 2) * P) & 1);
+}
+
+static ScratchView make_view(void* scratch, int64_t P, int max_points, int depth, int full_depth) {
+  ScratchView v;
+  v.skey = static_cast<uint32_t*>(scratch);
+  v.slot = v.skey + (int64_t)(depth - full_depth + 1) * P;
+  v.spairs = reinterpret_cast<unsigned long long*>(v.skey + level_words(P, depth));
+  v.np_stride = next_pow2(max_points);
+  v.P = P;
+  v.full_depth = full_depth;
+  return v;
+}
+
+// ------------------------------------------------------------------ stage 1
+__global__ void __launch_bounds__(kBuildThreads)
+build_cloud_kernel(const float* __restrict__ points, const int64_t* __restrict__ cloud_off,
+                   int batch, int depth, int full_depth, ScratchView sv,
+                   float* __restrict__ leaf_points, int32_t* __restrict__ counts, int ch_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* pairs = reinterpret_cast<unsigned long long*>(smem);
+  int* s_wave = reinterpret_cast<int*>(smem + (size_t)ch_cap * 8);
+
+  const int b = blockIdx.x;
+  const int64_t base = cloud_off[b];
+  const int n = (int)(cloud_off[b + 1] - base);
+  const int tid = threadIdx.x;
+  const float scale = (float)(1 << (depth - 1));
+  const uint32_t mask = (1u << depth) - 1u;
+  unsigned long long* gp = sv.spairs + (int64_t)b * sv.np_stride;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  const int CH = np2 < ch_cap ? np2 : ch_cap;        // LDS-resident chunk of the bitonic network
+
+  // 1+2a. keys, and a full bitonic sort of every CH-chunk inside LDS.
+  //       p = (x + 1) * 2^(depth-1), truncated, masked to `depth` bits (ocnn xyz2key).
+  for (int c0 = 0; c0 < np2; c0 += CH) {
+    for (int i = tid; i < CH; i += kBuildThreads) {
+      const int gi = c0 + i;
+      unsigned long long pr = ~0ull;
+      if (gi < n) {
+        const float* p = points + (base + gi) * 3;
+        const uint32_t ix = (uint32_t)(int)((p[0] + 1.0f) * scale) & mask;
+        const uint32_t iy = (uint32_t)(int)((p[1] + 1.0f) * scale) & mask;
+        const uint32_t iz = (uint32_t)(int)((p[2] + 1.0f) * scale) & mask;
+        pr = ((unsigned long long)shuffle_key(ix, iy, iz, depth) << 32) | (uint32_t)gi;
+      }
+      pairs[i] = pr;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CH; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (CH >> 1); t += kBuildThreads) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool up = ((c0 + lo) & k) == 0;
+          const unsigned long long a = pairs[lo], c = pairs[hi];
+          if ((a > c) == up) {
+            pairs[lo] = c;
+            pairs[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = tid; i < CH; i += kBuildThreads) gp[c0 + i] = pairs[i];
+    __syncthreads();
+  }
+  // 2b. clouds larger than one chunk: the remaining network stages, strides >= CH through
+  //     global memory (L2-resident, one workgroup), strides < CH back inside LDS.
+  for (int k = 2 * CH; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j >= CH; j >>= 1) {
+      for (int t = tid; t < (np2 >> 1); t += kBuildThreads) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = gp[lo], c = gp[hi];
+        if ((a > c) == up) {
+          gp[lo] = c;
+          gp[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+    for (int c0 = 0; c0 < np2; c0 += CH) {
+      for (int i = tid; i < CH; i += kBuildThreads) pairs[i] = gp[c0 + i];
+      __syncthreads();
+      for (int j = CH >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (CH >> 1); t += kBuildThreads) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool up = ((c0 + lo) & k) == 0;
+          const unsigned long long a = pairs[lo], c = pairs[hi];
+          if ((a > c) == up) {
+            pairs[lo] = c;
+            pairs[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+      for (int i = tid; i < CH; i += kBuildThreads) gp[c0 + i] = pairs[i];
+      __syncthreads();
+    }
+  }
+
+  // 3. leaves: heads of equal-key runs; averages in original point order
+  const int per = (np2 + kBuildThreads - 1) / kBuildThreads;
+  const int i0 = tid * per, i1 = min(i0 + per, n);
+  int heads = 0;
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t ki = (uint32_t)(gp[i] >> 32);
+    heads += (i == 0 || (uint32_t)(gp[i - 1] >> 32) != ki) ? 1 : 0;
+  }
+  int total = 0;
+  int rank = block_excl_scan(heads, s_wave, &total);
+  uint32_t* key_d = sv.key_at(depth) + base;
+  for (int i = i0; i < i1; ++i) {
+    const uint32_t ki = (uint32_t)(gp[i] >> 32);
+    if (i == 0 || (uint32_t)(gp[i - 1] >> 32) != ki) {
+      key_d[rank] = ki;
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      int cnt = 0;
+      for (int j = i; j < n && (uint32_t)(gp[j] >> 32) == ki; ++j) {
+        const float* p = points + (base + (uint32_t)gp[j]) * 3;
+        sx += (p[0] + 1.0f) * scale;
+        sy += (p[1] + 1.0f) * scale;
+        sz += (p[2] + 1.0f) * scale;
+        ++cnt;
+      }
+      const float c = (float)cnt;
+      float* o = leaf_points + (base + rank) * 3;
+      o[0] = sx / c;
+      o[1] = sy / c;
+      o[2] = sz / c;
+      ++rank;
+    }
+  }
+  int cur = total;
+  if (tid == 0) counts[depth * batch + b] = cur;
+  __syncthreads();   // key_d written by this workgroup, read below by other lanes
+
+  // 4. coarser levels: parents of the unique keys of level d
+  for (int d = depth; d > full_depth; --d) {
+    const uint32_t* kd = sv.key_at(d) + base;
+    uint32_t* kp = sv.key_at(d - 1) + base;
+    uint32_t* sl = sv.slot_at(d) + base;
+    const int perd = (cur + kBuildThreads - 1) / kBuildThreads;
+    const int a0 = min(tid * perd, cur), a1 = min(a0 + perd, cur);
+    int h = 0;
+    for (int i = a0; i < a1; ++i) h += (i == 0 || (kd[i - 1] >> 3) != (kd[i] >> 3)) ? 1 : 0;
+    int tot = 0;
+    int r = block_excl_scan(h, s_wave, &tot);   // heads before this lane's chunk
+    for (int i = a0; i < a1; ++i) {
+      const uint32_t ki = kd[i];
+      if (i == 0 || (kd[i - 1] >> 3) != (ki >> 3)) {
+        kp[r] = ki >> 3;
+        ++r;
+      }
+      sl[i] = (uint32_t)(r - 1) * 8u + (ki & 7u);   // parent rank = heads in [0..i] - 1
+    }
+    cur = tot;
+    if (tid == 0) counts[(d - 1) * batch + b] = cur;
+    __syncthreads();
+  }
+  if (tid < full_depth) counts[tid * batch + b] = 1 << (3 * tid);
+}
+
+// ------------------------------------------------------------------ stage 2
+struct MergeArgs {
+  int64_t* keys[kMaxDepthSlots];
+  int32_t* children[kMaxDepthSlots];
+  int64_t* nkeys[kMaxDepthSlots];
+  int32_t* nidx[kMaxDepthSlots];
+};
+
+__device__ __forceinline__ int find_cloud(const int64_t* __restrict__ off, int batch, int64_t t) {
+  int lo = 0, hi = batch;   // largest b with off[b] <= t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (off[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// grid.y = level index (d = full_depth + y); one thread per scratch slot
+__global__ void merge_sparse_kernel(ScratchView sv, const int64_t* __restrict__ cloud_off,
+                                    const int32_t* __restrict__ cum_nne, int batch, int depth,
+                                    int full_depth, MergeArgs a,
+                                    const float* __restrict__ leaf_points,
+                                    float* __restrict__ points_out) {
+  const int d = full_depth + blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= sv.P) return;
+  const int b = find_cloud(cloud_off, batch, t);
+  const int64_t i = t - cloud_off[b];
+  const int32_t* cum_d = cum_nne + (int64_t)d * (batch + 1);
+  const int64_t cnt = cum_d[b + 1] - cum_d[b];
+  if (i >= cnt) return;
+  const int64_t g = cum_d[b] + i;
+  const uint32_t key = sv.key_at(d)[t];
+  const int64_t bbits = (int64_t)b << 48;
+  a.nkeys[d][g] = bbits | (int64_t)key;
+  int64_t pos;
+  if (d == full_depth) {
+    pos = ((int64_t)b << (3 * d)) + key;
+  } else {
+    const int32_t* cum_p = cum_nne + (int64_t)(d - 1) * (batch + 1);
+    pos = 8 * (int64_t)cum_p[b] + sv.slot_at(d)[t];
+  }
+  a.nidx[d][g] = (int32_t)pos;
+  a.children[d][pos] = (int32_t)g;
+  if (d < depth && a.keys[d + 1] != nullptr) {
+    int64_t* kc = a.keys[d + 1] + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kc[j] = bbits | (int64_t)(key * 8u + j);
+  }
+  if (d == depth) {
+    const float* src = leaf_points + t * 3;
+    float* dst = points_out + g * 3;
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+  }
+}
+
+// depths <= full_depth are full: B * 8^d nodes
+__global__ void merge_full_kernel(int batch, int full_depth, MergeArgs a) {
+  const int d = blockIdx.y;
+  const int64_t per = (int64_t)1 << (3 * d);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * batch) return;
+  const int64_t b = t / per, m = t % per;
+  if (a.keys[d] != nullptr) a.keys[d][t] = (b << 48) | m;
+  if (d < full_depth) {
+    a.children[d][t] = (int32_t)t;
+    a.nkeys[d][t] = (b << 48) | m;
+    a.nidx[d][t] = (int32_t)t;
+  }
+}
+
+// ---------------------------------------------------------------- neighbours
+__global__ void neigh_full_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ children,
+                                  const int64_t* __restrict__ nkeys, int64_t nne, int depth) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nne * 27) return;
+  const int64_t g = t / 27;
+  const int o = (int)(t % 27);
+  const int64_t key = nkeys[g];
+  const int64_t b = key >> 48;
+  int x, y, z;
+  unshuffle_key((uint32_t)(key & 0xFFFFFFFFll), depth, x, y, z);
+  x += o / 9 - 1;
+  y += (o / 3) % 3 - 1;
+  z += o % 3 - 1;
+  const int bound = 1 << depth;
+  int32_t res = -1;
+  if (x >= 0 && y >= 0 && z >= 0 && x < bound && y < bound && z < bound)
+    res = children[(b << (3 * depth)) + shuffle_key((uint32_t)x, (uint32_t)y, (uint32_t)z, depth)];
+  out[t] = res;
+}
+
+__global__ void neigh_walk_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ neigh_parent,
+                                  const int32_t* __restrict__ nidx,
+                                  const int32_t* __restrict__ children, int64_t nne) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nne * 27) return;
+  const int64_t g = t / 27;
+  const int o = (int)(t % 27);
+  const int32_t pos = nidx[g];
+  const int64_t parent = pos >> 3;
+  const int oct = pos & 7;
+  const int tx = ((oct >> 2) & 1) + o / 9 - 1;        // in [-1, 2]
+  const int ty = ((oct >> 1) & 1) + (o / 3) % 3 - 1;
+  const int tz = (oct & 1) + o % 3 - 1;
+  const int po = ((tx >> 1) + 1) * 9 + ((ty >> 1) + 1) * 3 + ((tz >> 1) + 1);   // floor(t/2)+1
+  const int co = ((tx & 1) << 2) | ((ty & 1) << 1) | (tz & 1);
+  const int32_t q = neigh_parent[parent * 27 + po];
+  out[t] = q < 0 ? -1 : children[(int64_t)q * 8 + co];
+}
+
+__global__ void token_meta_kernel(uint32_t* __restrict__ meta, const int64_t* __restrict__ nkeys,
+                                  int64_t n, int depth) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int64_t key = nkeys[t];
+  int x, y, z;
+  unshuffle_key((uint32_t)(key & 0xFFFFFFFFll), depth, x, y, z);
+  meta[2 * t] = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+  meta[2 * t + 1] = (uint32_t)(key >> 48);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hfl_octree_scratch_bytes(int64_t total_points, int batch, int max_points, int depth) {
+  return level_words(total_points, depth) * (int64_t)sizeof(uint32_t) +
+         (int64_t)batch * next_pow2(max_points) * (int64_t)sizeof(unsigned long long) + 64;
+}
+
+int hfl_octree_build_clouds(const float* points, const int64_t* cloud_offsets, int batch,
+                              int64_t total_points, int max_points, int depth, int full_depth,
+                              void* scratch, float* leaf_points, int32_t* counts,
+                              hfl_stream_t stream) {
+  if (batch <= 0 || depth < 1 || depth > HFL_OCTREE_MAX_DEPTH || full_depth < 0 || full_depth > depth)
+    return HFL_EINVAL;
+  if (max_points > HFL_OCTREE_MAX_POINTS) return HFL_ECAPACITY;
+  if (max_points < 1) return HFL_EINVAL;
+  int ch_cap = next_pow2(max_points);
+  if (ch_cap > kLdsChunk) ch_cap = kLdsChunk;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ScratchView sv = make_view(scratch, total_points, max_points, depth, full_depth);
+  const size_t lds = (size_t)ch_cap * 8 + 32 * sizeof(int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(build_cloud_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  build_cloud_kernel<<<batch, kBuildThreads, lds, s>>>(points, cloud_offsets, batch, depth, full_depth,
+                                                       sv, leaf_points, counts, ch_cap);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_octree_merge(const void* scratch, const int64_t* cloud_offsets, const int32_t* cum_nne,
+                     int batch, int depth, int full_depth, int64_t total_points,
+                     int64_t* const* keys, int32_t* const* children, int64_t* const* nkeys,
+                     int32_t* const* nidx, const float* leaf_points, float* points_out,
+                     hfl_stream_t stream) {
+  if (batch <= 0 || depth < 1 || depth > HFL_OCTREE_MAX_DEPTH || full_depth < 0 || full_depth > depth)
+    return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MergeArgs a;
+  for (int d = 0; d < kMaxDepthSlots; ++d) {
+    const bool in = d <= depth;
+    a.keys[d] = (in && keys != nullptr) ? keys[d] : nullptr;
+    a.children[d] = in ? children[d] : nullptr;
+    a.nkeys[d] = in ? nkeys[d] : nullptr;
+    a.nidx[d] = in ? nidx[d] : nullptr;
+  }
+  ScratchView sv = make_view(const_cast<void*>(scratch), total_points, 2, depth, full_depth);
+  {
+    const int64_t per = ((int64_t)1 << (3 * full_depth)) * batch;
+    dim3 grid((unsigned)hfl_cdiv(per, 256), (unsigned)(full_depth + 1));
+    merge_full_kernel<<<grid, 256, 0, s>>>(batch, full_depth, a);
+  }
+  if (total_points > 0) {
+    dim3 grid((unsigned)hfl_cdiv(total_points, 256), (unsigned)(depth - full_depth + 1));
+    merge_sparse_kernel<<<grid, 256, 0, s>>>(sv, cloud_offsets, cum_nne, batch, depth, full_depth, a,
+                                             leaf_points, points_out);
+  }
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_octree_neigh(int32_t* neigh_out, const int32_t* neigh_parent, const int32_t* nidx,
+                     const int32_t* children, const int64_t* nkeys, int64_t nne, int depth,
+                     int full_depth, hfl_stream_t stream) {
+  if (nne < 0 || depth < 0) return HFL_EINVAL;
+  if (nne == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)hfl_cdiv(nne * 27, 256);
+  if (depth <= full_depth)
+    neigh_full_kernel<<<blocks, 256, 0, s>>>(neigh_out, children, nkeys, nne, depth);
+  else
+    neigh_walk_kernel<<<blocks, 256, 0, s>>>(neigh_out, neigh_parent, nidx, children, nne);
+  HFL_RETURN_LAST_ERROR();
+}
+
+/* tok_meta (n,2) uint32 from the non-empty node keys of one depth:
+ * [x | y<<10 | z<<20, batch id]  (ocnn key2xyz / batch_id, models/octree.py:132,273-275) */
+int hfl_token_meta(uint32_t* tok_meta, const int64_t* nkeys, int64_t n, int depth,
+                   hfl_stream_t stream) {
+  if (n < 0 || depth < 0 || depth > HFL_OCTREE_MAX_DEPTH) return HFL_EINVAL;
+  if (n == 0) return HFL_OK;
+  token_meta_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      tok_meta, nkeys, n, depth);
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // extern "C"

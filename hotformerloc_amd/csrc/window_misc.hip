@@ -1,0 +1,206 @@
+// HBM-bound helpers of the HOTFormerLoc hot path on gfx950: octree-conv gather
+// (octree2col), relay-token initialisation (masked window mean), ADaPE window
+// statistics and the segment softmax of the attentional pooling head.
+#include "hfl_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------- gather
+// out[m, k*C + c] = neigh[m,k] >= 0 ? data[neigh[m,k], c] : 0
+// VEC=4: one lane moves 16 B; a (m,k) slab of C floats is contiguous in `out`.
+template <int VEC>
+__global__ void gather_kernel(float* __restrict__ out, const float* __restrict__ data,
+                              const int32_t* __restrict__ neigh, int64_t n_out, int K, int C) {
+  const int cv = C / VEC;
+  const int64_t total = n_out * K * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t mk = i / cv;
+    const int c = (int)(i % cv);
+    const int32_t ni = neigh[mk];
+    if (VEC == 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ni >= 0) v = reinterpret_cast<const float4*>(data + (int64_t)ni * C)[c];
+      reinterpret_cast<float4*>(out + mk * C)[c] = v;
+    } else {
+      out[mk * C + c] = ni >= 0 ? data[(int64_t)ni * C + c] : 0.f;
+    }
+  }
+}
+
+// --------------------------------------------------------------- relay tokens
+// one block per window; thread c4 owns 4 channels; owner = batch id of first token
+__global__ void relay_init_kernel(float* __restrict__ rt, const float* __restrict__ x,
+                                  const uint32_t* __restrict__ meta, int64_t n_tokens,
+                                  int32_t n_windows, int K, int C) {
+  const int cv = C / 4;
+  const int c = threadIdx.x;
+  for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
+    const int64_t t0 = (int64_t)w * K;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cnt = 0;
+    if (t0 < n_tokens) {
+      const uint32_t owner = meta[2 * t0 + 1];
+      for (int k = 0; k < K; ++k) {
+        const int64_t t = t0 + k;
+        // batch ids are non-decreasing along the token stream: the owner's tokens lead
+        if (t >= n_tokens || meta[2 * t + 1] != owner) break;
+        ++cnt;
+        if (c < cv) {
+          const float4 v = reinterpret_cast<const float4*>(x + t * C)[c];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    }
+    if (c < cv) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cnt > 0) {
+        const float n = (float)cnt;
+        o = make_float4(acc.x / n, acc.y / n, acc.z / n, acc.w / n);
+      }
+      reinterpret_cast<float4*>(rt + (int64_t)w * C)[c] = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------- window stats
+// one thread per window: mean (3) + upper-triangular Bessel covariance (6)
+__global__ void window_stats_kernel(float* __restrict__ stats, const uint32_t* __restrict__ meta,
+                                    int64_t n_tokens, int32_t n_windows, int K, float scale) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_windows) return;
+  float* o = stats + (int64_t)w * 9;
+  const int64_t t0 = (int64_t)w * K;
+  float out[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (t0 < n_tokens) {
+    const uint32_t owner = meta[2 * t0 + 1];
+    int cnt = 0;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int64_t t = t0 + k;
+      if (t >= n_tokens || meta[2 * t + 1] != owner) break;
+      const uint32_t p = meta[2 * t];
+      sx += (float)(p & 1023u) * scale - 1.0f;
+      sy += (float)((p >> 10) & 1023u) * scale - 1.0f;
+      sz += (float)((p >> 20) & 1023u) * scale - 1.0f;
+      ++cnt;
+    }
+    const float c = (float)cnt;
+    const float cs = c < 1.f ? 1.f : c;
+    const float mx = sx / cs, my = sy / cs, mz = sz / cs;
+    out[0] = mx; out[1] = my; out[2] = mz;
+    if (cnt >= 2) {
+      float cxx = 0.f, cxy = 0.f, cxz = 0.f, cyy = 0.f, cyz = 0.f, czz = 0.f;
+      for (int k = 0; k < cnt; ++k) {
+        const uint32_t p = meta[2 * (t0 + k)];
+        const float dx = ((float)(p & 1023u) * scale - 1.0f) - mx;
+        const float dy = ((float)((p >> 10) & 1023u) * scale - 1.0f) - my;
+        const float dz = ((float)((p >> 20) & 1023u) * scale - 1.0f) - mz;
+        cxx += dx * dx; cxy += dx * dy; cxz += dx * dz;
+        cyy += dy * dy; cyz += dy * dz; czz += dz * dz;
+      }
+      const float den = c - 1.0f;
+      out[3] = cxx / den; out[4] = cxy / den; out[5] = cxz / den;
+      out[6] = cyy / den; out[7] = cyz / den; out[8] = czz / den;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o[i] = out[i];
+}
+
+// ---------------------------------------------------------- segment softmax
+// block = 64 query columns x 16 row groups; one block per (cloud, 64-column chunk)
+__global__ void __launch_bounds__(1024)
+segment_softmax_kernel(float* __restrict__ scores, const int64_t* __restrict__ row_off,
+                       int n_queries, float scale) {
+  __shared__ float s_m[16][64];
+  __shared__ float s_l[16][64];
+  const int b = blockIdx.x;
+  const int q = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  const int64_t r0 = row_off[b], r1 = row_off[b + 1];
+  const bool live = q < n_queries;
+  float m = -INFINITY, l = 0.f;
+  if (live) {
+    for (int64_t r = r0 + grp; r < r1; r += 16) {
+      const float s = scores[r * n_queries + q] * scale;
+      const float mn = fmaxf(m, s);
+      l = l * __expf(m - mn) + __expf(s - mn);
+      m = mn;
+    }
+  }
+  s_m[grp][threadIdx.x & 63] = m;
+  s_l[grp][threadIdx.x & 63] = l;
+  __syncthreads();
+  float M = -INFINITY;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) M = fmaxf(M, s_m[g][threadIdx.x & 63]);
+  float L = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const float mg = s_m[g][threadIdx.x & 63];
+    if (mg > -INFINITY) L += s_l[g][threadIdx.x & 63] * __expf(mg - M);
+  }
+  if (live && L > 0.f) {
+    const float inv = 1.0f / L;
+    for (int64_t r = r0 + grp; r < r1; r += 16) {
+      const int64_t idx = r * n_queries + q;
+      scores[idx] = __expf(scores[idx] * scale - M) * inv;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hfl_octree_gather(float* out, const float* data, const int32_t* neigh, int64_t n_out, int kngh,
+                      int64_t channels, hfl_stream_t stream) {
+  if (n_out < 0 || kngh <= 0 || channels <= 0) return HFL_EINVAL;
+  if (n_out == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int vec = (channels % 4 == 0) ? 4 : 1;
+  const int64_t total = n_out * kngh * (channels / vec);
+  const int64_t need = hfl_cdiv(total, 256);
+  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  const int blocks = (int)(need < cap ? need : cap);
+  if (vec == 4)
+    gather_kernel<4><<<blocks, 256, 0, s>>>(out, data, neigh, n_out, kngh, (int)channels);
+  else
+    gather_kernel<1><<<blocks, 256, 0, s>>>(out, data, neigh, n_out, kngh, (int)channels);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_relay_token_init(float* rt, const float* x, const uint32_t* tok_meta, int64_t n_tokens,
+                         int32_t n_windows, int32_t patch_size, int64_t channels,
+                         hfl_stream_t stream) {
+  if (n_windows < 0 || patch_size <= 0 || channels <= 0 || channels % 4 != 0 || channels > 4096)
+    return HFL_EINVAL;
+  if (n_windows == 0) return HFL_OK;
+  int threads = (int)(channels / 4);
+  threads = ((threads + 63) / 64) * 64;
+  relay_init_kernel<<<n_windows, threads, 0, static_cast<hipStream_t>(stream)>>>(
+      rt, x, tok_meta, n_tokens, n_windows, patch_size, (int)channels);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_window_stats(float* stats, const uint32_t* tok_meta, int64_t n_tokens, int32_t n_windows,
+                     int32_t patch_size, int depth, hfl_stream_t stream) {
+  if (n_windows < 0 || patch_size <= 0 || depth < 1) return HFL_EINVAL;
+  if (n_windows == 0) return HFL_OK;
+  const float scale = 1.0f / (float)(1 << (depth - 1));   // 2^(1-depth), misc/utils.py:301
+  window_stats_kernel<<<(unsigned)hfl_cdiv(n_windows, 128), 128, 0, static_cast<hipStream_t>(stream)>>>(
+      stats, tok_meta, n_tokens, n_windows, patch_size, scale);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_segment_softmax(float* scores, const int64_t* row_off, int batch, int n_queries, float scale,
+                        hfl_stream_t stream) {
+  if (batch <= 0 || n_queries <= 0) return HFL_EINVAL;
+  dim3 grid((unsigned)batch, (unsigned)hfl_cdiv(n_queries, 64));
+  segment_softmax_kernel<<<grid, 1024, 0, static_cast<hipStream_t>(stream)>>>(scores, row_off,
+                                                                              n_queries, scale);
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // extern "C"

@@ -1,0 +1,549 @@
+"""HOTFormerLoc on MI355X: module tree with the reference's parameter names, forward
+re-designed around the HIP kernels.
+
+Drop-in contract: `model_factory(ModelParams)` returns a
+`torch.nn.Module` whose `forward({'octree': O}) -> {'global': (B, output_dim)}` and whose
+`state_dict()` keys/shapes equal the reference's (Appendix D), so reference checkpoints load
+with `load_state_dict`.  Reference files followed: `models/hotformerloc.py`,
+`models/hotformerloc_backbone.py`, `models/octformer_backbone.py`,
+`models/layers/{octformer_layers,pooling,pooling_wrapper,salsa}.py`.
+
+What is different from the reference (same function, different dataflow):
+  * tokens are never padded, permuted into windows or concatenated with relay tokens in
+    HBM: per-token ops (LayerNorm, Linear, MLP -- hipBLASLt fp32 through PyTorch-ROCm) run
+    on the octree-ordered (N_t, C) stream, windows exist only as index arithmetic inside
+    the attention kernel (`ops.window_attention`);
+  * in the pyramid stage every depth keeps ONE buffer [tokens | relay tokens] so the
+    token and relay-token rows share each GEMM launch;
+  * relay-token self-attention is ragged per cloud (`ops.relay_attention`), no
+    concat/pad/split, no host sync;
+  * CPE = depth-wise octree conv + LayerNorm + residual is one kernel (`ops.cpe_forward`).
+Only the options the shipped configs use are implemented; anything else raises.
+"""
+
+import contextlib
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .plan import WindowPlan
+
+
+def _ln(x, m: nn.LayerNorm):
+    return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+
+
+def _require_layernorm(conv_norm: str):
+    if conv_norm.lower() != 'layernorm':
+        raise NotImplementedError("conv_norm=%r: every shipped config uses 'layernorm'" % conv_norm)
+
+
+# --------------------------------------------------------------------------- convs
+class OctreeConv(nn.Module):
+    """`ocnn.nn.OctreeConv` (nempty=True): parameter `weights` (kdim, Cin, Cout) [+ `bias`].
+    gather through the neighbour / child table (HIP) then one fp32 GEMM."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: List[int] = [3],
+                 stride: int = 1, nempty: bool = True, use_bias: bool = False):
+        super().__init__()
+        if not nempty:
+            raise NotImplementedError('nempty=False octree conv is off the HOTFormerLoc path')
+        ks = list(kernel_size) * 3 if len(kernel_size) == 1 else list(kernel_size)
+        self.kernel = ''.join(str(k) for k in ks)
+        self.kdim = ks[0] * ks[1] * ks[2]
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.weights = nn.Parameter(torch.empty(self.kdim, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
+        nn.init.xavier_uniform_(self.weights)
+
+    def forward(self, data: torch.Tensor, octree, depth: int):
+        neigh = octree.get_neigh(depth, self.kernel, self.stride, nempty=True)
+        col = ops.octree_gather(data, neigh)
+        w = self.weights.reshape(self.kdim * self.in_channels, self.out_channels)
+        if self.bias is not None:
+            return torch.addmm(self.bias, col, w)
+        return torch.mm(col, w)
+
+
+class OctreeDWConvParams(nn.Module):
+    """Holder of the depth-wise conv parameter `weights` (27, 1, C) (reference
+    `dwconv.OctreeDWConv`, libs/dwconv/dwconv/nn.py:49-63); the op itself is fused into CPE."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.weights = nn.Parameter(torch.empty(27, 1, channels))
+        nn.init.xavier_uniform_(self.weights)
+
+
+class OctreeConvNormRelu(nn.Module):
+    """models/layers/octformer_layers.py:80-98"""
+
+    def __init__(self, in_channels, out_channels, kernel_size=[3], stride=1, conv_norm='layernorm'):
+        super().__init__()
+        _require_layernorm(conv_norm)
+        self.conv = OctreeConv(in_channels, out_channels, kernel_size, stride, nempty=True)
+        self.norm = nn.LayerNorm(out_channels)
+
+    def forward(self, data, octree, depth):
+        return F.relu_(_ln(self.conv(data, octree, depth), self.norm))
+
+
+class PatchEmbed(nn.Module):
+    """models/octformer_backbone.py:424-461 (downsample_input_embeddings=True)"""
+
+    def __init__(self, in_channels=3, dim=96, num_down=2, conv_norm='layernorm'):
+        super().__init__()
+        self.num_stages = num_down
+        ch = [int(dim * 2 ** i) for i in range(-num_down, 1)]
+        self.convs = nn.ModuleList([OctreeConvNormRelu(in_channels if i == 0 else ch[i], ch[i], [3], 1,
+                                                       conv_norm) for i in range(num_down)])
+        self.downsamples = nn.ModuleList([OctreeConvNormRelu(ch[i], ch[i + 1], [2], 2, conv_norm)
+                                          for i in range(num_down)])
+        self.proj = OctreeConvNormRelu(ch[-1], dim, [3], 1, conv_norm)
+
+    def forward(self, data, octree, depth):
+        for i in range(self.num_stages):
+            data = self.convs[i](data, octree, depth - i)
+            data = self.downsamples[i](data, octree, depth - i)
+        return self.proj(data, octree, depth - self.num_stages)
+
+
+class Downsample(nn.Module):
+    """models/octformer_backbone.py:464-477"""
+
+    def __init__(self, in_channels, out_channels, conv_norm='layernorm'):
+        super().__init__()
+        _require_layernorm(conv_norm)
+        self.conv = OctreeConv(in_channels, out_channels, [2], stride=2, nempty=True, use_bias=True)
+        self.norm = nn.LayerNorm(out_channels)
+
+    def forward(self, data, octree, depth):
+        return _ln(self.conv(data, octree, depth), self.norm)
+
+
+# ---------------------------------------------------------------- transformer parts
+class MLP(nn.Module):
+    """models/layers/octformer_layers.py:38-59"""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class CPE(nn.Module):
+    """models/layers/octformer_layers.py:122-142 (xcpe=False)"""
+
+    def __init__(self, dim, conv_norm='layernorm'):
+        super().__init__()
+        _require_layernorm(conv_norm)
+        self.conv = OctreeDWConvParams(dim)
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, data, plan: WindowPlan, depth: int, residual: bool):
+        return ops.cpe_forward(data, self.conv.weights, self.norm.weight, self.norm.bias,
+                               plan.neigh(depth), residual, self.norm.eps)
+
+
+class RPE(nn.Module):
+    """models/layers/octformer_layers.py:144-174: only the table; the gather happens in
+    registers inside the attention kernel."""
+
+    def __init__(self, patch_size, num_heads, dilation=1):
+        super().__init__()
+        self.pos_bnd = int(0.8 * patch_size * dilation ** 0.5)
+        self.rpe_num = 2 * self.pos_bnd + 1
+        self.rpe_table = nn.Parameter(torch.zeros(3 * self.rpe_num, num_heads))
+        nn.init.trunc_normal_(self.rpe_table, std=0.02)
+
+
+class OctreeAttention(nn.Module):
+    """models/octformer_backbone.py:24-106"""
+
+    def __init__(self, dim, patch_size, num_heads, dilation=1, rt_per_window=0, use_rpe=True):
+        super().__init__()
+        if dim // num_heads != 16:
+            raise NotImplementedError('head dim must be 16 (all shipped configs)')
+        self.dim, self.patch_size, self.num_heads = dim, patch_size, num_heads
+        self.dilation, self.rt_per_window = dilation, rt_per_window
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self.rpe = RPE(patch_size, num_heads, dilation) if use_rpe else None
+
+    def forward(self, x, plan: WindowPlan, depth: int):
+        """x: (N_t [+ W], C) token rows [followed by the relay-token rows]."""
+        nt = plan.n_tokens[depth]
+        qkv = self.qkv(x)
+        out = ops.window_attention(qkv, plan.meta[depth],
+                                   None if self.rpe is None else self.rpe.rpe_table,
+                                   n_tokens=nt, n_windows=plan.n_windows[depth],
+                                   patch_size=self.patch_size, dilation=self.dilation,
+                                   n_relay=self.rt_per_window, n_heads=self.num_heads,
+                                   batch_size=plan.B, rt_row0=nt)
+        return self.proj(out)
+
+
+class OctFormerBlock(nn.Module):
+    """models/octformer_backbone.py:182-299 (use_rt=False)"""
+
+    def __init__(self, dim, num_heads, patch_size, dilation, disable_RPE=False, conv_norm='layernorm'):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attention = OctreeAttention(dim, patch_size, num_heads, dilation, 0, not disable_RPE)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MLP(dim, int(dim * 4.0), dim)
+        self.cpe = CPE(dim, conv_norm)
+
+    def forward(self, x, plan: WindowPlan, depth: int):
+        x = self.cpe(x, plan, depth, residual=True)
+        x = x + self.attention(_ln(x, self.norm1), plan, depth)
+        return x + self.mlp(_ln(x, self.norm2))
+
+
+class OctFormerStage(nn.Module):
+    """models/octformer_backbone.py:363-421"""
+
+    def __init__(self, dim, num_heads, patch_size, dilation, num_blocks, disable_RPE=False,
+                 conv_norm='layernorm'):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            OctFormerBlock(dim, num_heads, patch_size, 1 if i % 2 == 0 else dilation, disable_RPE,
+                           conv_norm) for i in range(num_blocks)])
+
+    def forward(self, x, plan, depth):
+        for blk in self.blocks:
+            x = blk(x, plan, depth)
+        return x
+
+
+class HOTFormerBlock(nn.Module):
+    """models/hotformerloc_backbone.py:130-236 (rt_propagation off): operates on the
+    [tokens | relay tokens] buffer of one depth."""
+
+    def __init__(self, dim, num_heads, patch_size, disable_RPE=False, conv_norm='layernorm'):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attention = OctreeAttention(dim, patch_size, num_heads, 1, 1, not disable_RPE)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MLP(dim, int(dim * 4.0), dim)
+        self.cpe = CPE(dim, conv_norm)
+
+    def forward(self, buf, plan: WindowPlan, depth: int):
+        nt = plan.n_tokens[depth]
+        tok = self.cpe(buf[:nt], plan, depth, residual=True)
+        buf = torch.cat([tok, buf[nt:]], 0)
+        buf = buf + self.attention(_ln(buf, self.norm1), plan, depth)
+        return buf + self.mlp(_ln(buf, self.norm2))
+
+
+class RTAttention(nn.Module):
+    """models/hotformerloc_backbone.py:56-127"""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.dim, self.num_heads = dim, num_heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, rt, plan: WindowPlan):
+        out = ops.relay_attention(self.qkv(rt), plan.seq_rows, plan.seq_off, plan.B, self.num_heads)
+        return self.proj(out)
+
+
+class RelayTokenTransformerBlock(nn.Module):
+    """models/hotformerloc_backbone.py:239-302 on the concatenated (sum W_d, C) relay rows."""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.rt_attention = RTAttention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MLP(dim, int(dim * 4.0), dim)
+
+    def forward(self, rt, plan):
+        rt = rt + self.rt_attention(_ln(rt, self.norm1), plan)
+        return rt + self.mlp(_ln(rt, self.norm2))
+
+
+class RelayTokenInitialiser(nn.Module):
+    """models/hotformerloc_backbone.py:305-363"""
+
+    def __init__(self, dim, patch_size, conv_norm='layernorm', use_cpe=False):
+        super().__init__()
+        self.patch_size = patch_size
+        self.use_cpe = use_cpe
+        if use_cpe:
+            self.cpe = CPE(dim, conv_norm)
+
+    def forward(self, x, plan: WindowPlan, depth: int):
+        if self.use_cpe:
+            x = self.cpe(x, plan, depth, residual=False)
+        return ops.relay_token_init(x, plan.meta[depth], plan.n_windows[depth], self.patch_size)
+
+
+class ADaPE(nn.Module):
+    """models/layers/octformer_layers.py:177-210"""
+
+    def __init__(self, dim, mode='cov'):
+        super().__init__()
+        self.mlp = MLP({'pos': 3, 'var': 6, 'cov': 9}[mode], dim, dim)
+
+    def forward(self, plan: WindowPlan, depth: int):
+        return self.mlp(plan.window_stats[depth])
+
+
+class HOTFormerStage(nn.Module):
+    """models/hotformerloc_backbone.py:366-635 (one channel width for all levels)."""
+
+    def __init__(self, channels, num_heads, num_blocks, num_pyramid_levels, patch_size,
+                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm'):
+        super().__init__()
+        if len(channels) != 1 or len(num_heads) != 1:
+            raise NotImplementedError('per-level channel widths (projection layers) are not used '
+                                      'by any shipped config')
+        C, H = channels[0], num_heads[0]
+        self.num_pyramid_levels, self.num_blocks = num_pyramid_levels, num_blocks
+        self.use_ADaPE = ADaPE_mode is not None
+        self.hosa_blocks = nn.ModuleList([
+            nn.ModuleList([HOTFormerBlock(C, H, patch_size, disable_RPE, conv_norm)
+                           for _ in range(num_blocks)]) for _ in range(num_pyramid_levels)])
+        self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(C, H) for _ in range(num_blocks)])
+        self.relay_tokeniser = RelayTokenInitialiser(C, patch_size, conv_norm,
+                                                     use_cpe=not self.use_ADaPE)
+        if self.use_ADaPE:
+            self.rt_adape = ADaPE(C, ADaPE_mode)
+        self.downsamples = nn.ModuleList([Downsample(C, C, conv_norm)
+                                          for _ in range(num_pyramid_levels - 1)])
+        self._streams = None
+
+    def _side_streams(self, device):
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=device) for _ in range(self.num_pyramid_levels - 1)]
+        return self._streams
+
+    def forward(self, data, plan: WindowPlan, depth: int):
+        depths = [depth - j for j in range(self.num_pyramid_levels)]
+        octree = plan.octree
+        feats = {depths[0]: data}
+        bufs: Dict[int, torch.Tensor] = {}
+        for j, d in enumerate(depths):                                  # init_pyramid_feats, 540-572
+            rt = self.relay_tokeniser(feats[d], plan, d)
+            if self.use_ADaPE:
+                rt = rt + self.rt_adape(plan, d)
+            bufs[d] = torch.cat([feats[d], rt], 0)
+            if j < self.num_pyramid_levels - 1:
+                feats[d - 1] = self.downsamples[j](feats[d], octree, d)
+        nts = [plan.n_tokens[d] for d in depths]
+        for i in range(self.num_blocks):                                # 593-633
+            rt_all = torch.cat([bufs[d][nt:] for d, nt in zip(depths, nts)], 0)
+            rt_all = self.rtsa_blocks[i](rt_all, plan)
+            for d, nt in zip(depths, nts):
+                off = plan.rt_offset[d]
+                bufs[d] = torch.cat([bufs[d][:nt], rt_all[off:off + plan.n_windows[d]]], 0)
+            for j, d in enumerate(depths):
+                bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+        local = {d: bufs[d][:nt] for d, nt in zip(depths, nts)}
+        relay = {d: bufs[d][nt:] for d, nt in zip(depths, nts)}
+        return local, relay
+
+
+class HOTFormerBase(nn.Module):
+    """models/hotformerloc_backbone.py:638-723"""
+
+    def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels,
+                 num_octf_levels, patch_size, dilation, stem_down, ADaPE_mode, disable_RPE, conv_norm):
+        super().__init__()
+        self.patch_size, self.dilation = patch_size, dilation
+        self.num_pyramid_levels, self.num_octf_levels = num_pyramid_levels, num_octf_levels
+        self.num_stages = num_octf_levels + num_pyramid_levels
+        self.stem_down = stem_down
+        self.ADaPE_mode = ADaPE_mode
+        if num_heads is None:
+            num_heads = [c // 16 for c in channels]
+        self.patch_embed = PatchEmbed(in_channels, channels[0], stem_down, conv_norm)
+        self.octf_stage = nn.ModuleList([
+            OctFormerStage(channels[i], num_heads[i], patch_size, dilation, num_blocks[i], disable_RPE,
+                           conv_norm) for i in range(num_octf_levels)])
+        self.downsample = nn.ModuleList([Downsample(channels[i], channels[i + 1], conv_norm)
+                                         for i in range(num_octf_levels)])
+        self.hotf_stage = HOTFormerStage(list(channels[num_octf_levels:]),
+                                         list(num_heads[num_octf_levels:]), num_blocks[-1],
+                                         num_pyramid_levels, patch_size, disable_RPE, ADaPE_mode,
+                                         conv_norm)
+
+    def forward(self, data, octree, depth):
+        data = self.patch_embed(data, octree, depth)
+        depth = depth - self.stem_down
+        plan = WindowPlan(octree, self.patch_size, self.dilation, max_depth=depth,
+                          start_depth=depth - self.num_stages + 1,
+                          num_pyramid_levels=self.num_pyramid_levels,
+                          num_octf_levels=self.num_octf_levels, adape_mode=self.ADaPE_mode)
+        for i in range(self.num_octf_levels):
+            data = self.octf_stage[i](data, plan, depth)
+            data = self.downsample[i](data, octree, depth)
+            depth -= 1
+        local, relay = self.hotf_stage(data, plan, depth)
+        return local, relay, plan
+
+
+class HOTFormer(nn.Module):
+    """models/hotformerloc_backbone.py:726-849 (init: 817-843)"""
+
+    def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels=3,
+                 num_octf_levels=1, patch_size=32, dilation=4, stem_down=2, ADaPE_mode=None,
+                 disable_RPE=False, conv_norm='layernorm', qkv_init=('trunc_normal', 0.02)):
+        super().__init__()
+        self.backbone = HOTFormerBase(in_channels, list(channels), list(num_blocks),
+                                      None if num_heads is None else list(num_heads),
+                                      num_pyramid_levels, num_octf_levels, patch_size, dilation,
+                                      stem_down, ADaPE_mode, disable_RPE, conv_norm)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        if qkv_init[0] == 'trunc_normal':
+            for name, m in self.named_modules():
+                if 'qkv' in name and isinstance(m, nn.Linear):
+                    nn.init.trunc_normal_(m.weight, std=qkv_init[1])
+
+    def forward(self, data, octree, depth):
+        return self.backbone(data, octree, depth)
+
+
+# -------------------------------------------------------------------------- pooling
+class AdaptivePooling(nn.Module):
+    """models/layers/salsa.py:12-55: learned queries attend over one cloud's tokens."""
+
+    def __init__(self, feature_dim, k_pooled_tokens):
+        super().__init__()
+        self.query = nn.Parameter(torch.randn(k_pooled_tokens, feature_dim))
+        self.scale = feature_dim ** -0.5
+
+    def forward(self, x, plan: WindowPlan, depth: int):
+        """x (N_t, C) ragged over clouds -> (B, k, C)."""
+        scores = torch.mm(x, self.query.t())                              # (N_t, k)
+        ops.segment_softmax_(scores, plan.cloud_off[depth], plan.B, self.scale)
+        idx = plan.pad_index[depth]
+        zero = x.new_zeros(1, x.shape[1])
+        xp = torch.cat([x, zero], 0).index_select(0, idx).view(plan.B, -1, x.shape[1])
+        pp = torch.cat([scores, scores.new_zeros(1, scores.shape[1])], 0) \
+            .index_select(0, idx).view(plan.B, -1, scores.shape[1])
+        return torch.bmm(pp.transpose(1, 2), xp)
+
+
+class FeatureMixerLayer(nn.Module):
+    """models/layers/salsa.py:58-75"""
+
+    def __init__(self, in_dim, mlp_ratio=1):
+        super().__init__()
+        self.mix = nn.Sequential(nn.LayerNorm(in_dim), nn.Linear(in_dim, int(in_dim * mlp_ratio)),
+                                 nn.GELU(), nn.Linear(int(in_dim * mlp_ratio), in_dim))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        return x + self.mix(x)
+
+
+class Mixer(nn.Module):
+    """models/layers/salsa.py:78-111"""
+
+    def __init__(self, k_input_tokens, k_output_tokens, in_d, mix_depth, mlp_ratio, out_d):
+        super().__init__()
+        self.mix = nn.Sequential(*[FeatureMixerLayer(in_d, mlp_ratio) for _ in range(mix_depth)])
+        self.row_proj = nn.Linear(in_d, out_d)
+        self.channel_proj = nn.Linear(k_input_tokens, k_output_tokens)
+
+    def forward(self, x):
+        x = self.mix(x)
+        x = self.channel_proj(x.permute(0, 2, 1)).permute(0, 2, 1)
+        return self.row_proj(x).flatten(1)
+
+
+class PyramidAttnPoolWrapper(nn.Module):
+    """models/layers/pooling.py:106-233 (aggregator='mixer')"""
+
+    def __init__(self, feature_size, output_dim, channels, num_pyramid_levels, k_pooled_tokens,
+                 mlp_ratio=1, mix_depth=4):
+        super().__init__()
+        if len(channels) != 1:
+            raise NotImplementedError('per-level channel widths are not used by any shipped config')
+        assert len(k_pooled_tokens) == num_pyramid_levels, \
+            'k_pooled_tokens must be list of k for each pyramid level'
+        self.k_pooled_tokens = list(k_pooled_tokens)
+        total = sum(k_pooled_tokens)
+        self.attpool = nn.ModuleList([AdaptivePooling(channels[0], k) for k in k_pooled_tokens])
+        k_out = total // 4
+        out_d = output_dim // k_out
+        assert k_out * out_d == output_dim, \
+            f'Invalid k for k_pooled_tokens: {k_pooled_tokens}, not compatible with output dim {output_dim}'
+        self.descriptor_extractor = Mixer(total, k_out, feature_size, mix_depth, mlp_ratio, out_d)
+
+    def forward(self, local_feat_dict, plan: WindowPlan, depth=None):
+        toks = [self.attpool[j](local_feat_dict[d], plan, d)
+                for j, d in enumerate(local_feat_dict.keys())]
+        return self.descriptor_extractor(torch.cat(toks, 1))
+
+
+class PoolingWrapper(nn.Module):
+    """models/layers/pooling_wrapper.py:11-77"""
+
+    def __init__(self, pool_method, in_dim, output_dim, num_pyramid_levels=None, channels=None,
+                 k_pooled_tokens=None):
+        super().__init__()
+        self.pool_method, self.in_dim, self.output_dim = pool_method, in_dim, output_dim
+        self.pooled_feats = 'local'
+        if pool_method != 'PyramidAttnPoolMixer':
+            raise NotImplementedError('pooling=%r: every shipped config uses PyramidAttnPoolMixer'
+                                      % pool_method)
+        self.pooling = PyramidAttnPoolWrapper(in_dim, output_dim, list(channels), num_pyramid_levels,
+                                              k_pooled_tokens)
+
+    def forward(self, x, octree=None, depth=None):
+        return self.pooling(x, octree, depth)
+
+
+# ------------------------------------------------------------------------- wrapper
+class HOTFormerLoc(nn.Module):
+    """models/hotformerloc.py:18-82"""
+
+    def __init__(self, backbone: nn.Module, pooling: PoolingWrapper, normalize_embeddings=False,
+                 input_features='P'):
+        super().__init__()
+        if input_features != 'P':
+            raise NotImplementedError("input_features=%r: every shipped config uses 'P'" % input_features)
+        self.backbone = backbone
+        self.pooling = pooling
+        self.normalize_embeddings = normalize_embeddings
+        self.input_features = input_features
+        self.stats = {}
+
+    def forward(self, batch):
+        octree = batch['octree']
+        if octree.device.type != 'cuda':
+            raise RuntimeError('HOTFormerLoc (MI355X build) needs the octree on a GPU; '
+                               'call to_device(batch, "cuda") first -- there is no CPU path')
+        octree.construct_all_neigh()                     # no-op when misc/torch_utils.to_device did it
+        data = octree.get_input_feature(self.input_features, nempty=True)
+        local, relay, plan = self.backbone(data, octree, octree.depth)
+        x = self.pooling(local, octree=plan)
+        assert x.dim() == 2 and x.shape[1] == self.pooling.output_dim
+        if self.normalize_embeddings:
+            x = F.normalize(x, dim=1)
+        return {'global': x}
+
+    def print_info(self):
+        n = sum(p.nelement() for p in self.parameters())
+        print('Model class: HOTFormerLoc (MI355X build)')
+        print(f'Total parameters: {n}')
+        print(f'Pooling method: {self.pooling.pool_method}')
+        print(f'Embedding normalization: {self.normalize_embeddings}')

@@ -1,0 +1,289 @@
+"""`Points` / `Octree` / `merge_octrees`: the ocnn-side API the reference's callers use,
+re-designed for the MI355X path.
+
+Reference call sites (the contract): `datasets/dataset_utils.py:89-94`
+(`Points(cloud)`; `Octree(depth, full_depth).build_octree(points)`; `merge_octrees`),
+`eval/pnv_evaluate.py:122-126,173-175`, `misc/torch_utils.py:47-51`
+(`octree.to(device)`, `octree.construct_all_neigh()`), `models/octree.py:51-52`
+(attributes copied into `OctreeT`).
+
+Design (not ocnn's): an `Octree` here is *deferred*.  `build_octree` only records the
+cloud; dataloader workers therefore ship raw points (48 KB per 4096-point cloud, not
+a 7 MB octree).  The structure is materialised for the whole batch by ONE pair of HIP
+launches (one workgroup per cloud, LDS bitonic sort -- csrc/octree.hip) the first time
+the octree is on the GPU: `merge_octrees([...]).to('cuda')`, or immediately when the
+points already live there.  The result is laid out for the kernels: int32 child and
+neighbour tables over the *non-empty* nodes only, int64 keys kept for the API.
+There is no CPU construction path: materialising without a GPU raises.
+"""
+
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _native, ops
+from ._native import check
+
+_KERNEL_LUT = {   # ocnn kernel-string -> columns of the 27-neighbourhood
+    '333': list(range(27)),
+    '222': [13, 14, 16, 17, 22, 23, 25, 26],
+    '311': [4, 13, 22], '131': [10, 13, 16], '113': [12, 13, 14],
+    '331': [1, 4, 7, 10, 13, 16, 19, 22, 25],
+    '313': [3, 4, 5, 12, 13, 14, 21, 22, 23],
+    '133': [9, 10, 11, 12, 13, 14, 15, 16, 17],
+}
+
+
+class Points:
+    """`ocnn.octree.Points` as the reference uses it: `Points(tensor (n,3) in [-1,1])`."""
+
+    def __init__(self, points: torch.Tensor, normals=None, features=None, labels=None,
+                 batch_id=None, batch_size: int = 1):
+        if normals is not None or features is not None:
+            raise NotImplementedError('only input feature "P" is on the HOTFormerLoc path')
+        self.points = points
+        self.normals = normals
+        self.features = features
+        self.labels = labels
+        self.batch_id = batch_id
+        self.batch_size = batch_size
+        self.device = points.device
+
+    def to(self, device, non_blocking: bool = False):
+        return Points(self.points.to(device, non_blocking=non_blocking), batch_size=self.batch_size)
+
+    def cuda(self, non_blocking: bool = False):
+        return self.to('cuda', non_blocking)
+
+    def cpu(self):
+        return self.to('cpu')
+
+
+class Octree:
+    def __init__(self, depth: int, full_depth: int = 2, batch_size: int = 1,
+                 device: Union[torch.device, str] = 'cpu', **kwargs):
+        if depth > _native.HFL_OCTREE_MAX_DEPTH:
+            raise ValueError('octree depth %d > %d unsupported' % (depth, _native.HFL_OCTREE_MAX_DEPTH))
+        self.depth = depth
+        self.full_depth = full_depth
+        self.batch_size = batch_size
+        self.device = torch.device(device)
+        self._clouds: List[torch.Tensor] = []
+        self._built = False
+        num = depth + 1
+        self.keys = [None] * num          # int64 (nnum_d)      all nodes
+        self.children = [None] * num      # int32 (nnum_d)      non-empty rank or -1
+        self.nkeys = [None] * num         # int64 (nne_d)       non-empty nodes only
+        self.nidx = [None] * num          # int32 (nne_d)       position among all nodes
+        self.neighs = [None] * num        # int32 (nne_d, 27)   non-empty -> non-empty
+        self.points = [None] * num        # float32 (nne_depth, 3) at [depth]
+        self.features = [None] * num
+        self.normals = [None] * num
+        self.nnum = torch.zeros(num, dtype=torch.int32)
+        self.nnum_nempty = torch.zeros(num, dtype=torch.int32)
+        self.batch_nnum = torch.zeros(num, batch_size, dtype=torch.int32)
+        self.batch_nnum_nempty = torch.zeros(num, batch_size, dtype=torch.int32)
+
+    # ------------------------------------------------------------- construction
+    def build_octree(self, point_cloud: Points):
+        pts = point_cloud.points
+        if pts.dim() != 2 or pts.shape[1] != 3:
+            raise ValueError('points must be (n, 3)')
+        if pts.shape[0] < 1:
+            raise ValueError('empty point cloud')
+        self._clouds = [pts.detach().to(torch.float32).contiguous()]
+        self.batch_size = 1
+        self.device = pts.device
+        self._built = False
+        if pts.is_cuda:
+            self._materialise()
+        return None
+
+    def _materialise(self):
+        """Run the batched device builder on the recorded clouds."""
+        if self._built:
+            return
+        if self.device.type != 'cuda':
+            raise _native.NativeLibraryError(
+                'octree construction runs on the GPU (HIP kernels); move the octree to a '
+                'cuda device first -- there is no CPU construction path')
+        lib = _native.load()
+        dev = self.device
+        B, D, F = len(self._clouds), self.depth, self.full_depth
+        sizes = [int(c.shape[0]) for c in self._clouds]
+        if max(sizes) > _native.HFL_OCTREE_MAX_POINTS:
+            raise _native.NativeLibraryError(
+                'cloud with %d points exceeds HFL_OCTREE_MAX_POINTS=%d'
+                % (max(sizes), _native.HFL_OCTREE_MAX_POINTS))
+        P = sum(sizes)
+        pts = torch.cat([c.to(dev, non_blocking=True) for c in self._clouds]) if B > 1 \
+            else self._clouds[0].to(dev)
+        off_host = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int64)
+        off = off_host.to(dev, non_blocking=True)
+        scratch = torch.empty(int(lib.hfl_octree_scratch_bytes(P, B, max(sizes), D)), dtype=torch.uint8, device=dev)
+        leaf_pts = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        counts = torch.zeros((D + 1, B), dtype=torch.int32, device=dev)
+        st = ops._stream()
+        check(lib.hfl_octree_build_clouds(pts.data_ptr(), off.data_ptr(), B, P, max(sizes), D, F,
+                                          scratch.data_ptr(), leaf_pts.data_ptr(),
+                                          counts.data_ptr(), st), 'hfl_octree_build_clouds')
+        cnt = counts.cpu()                                   # the one host sync of a batch build
+        self.batch_nnum_nempty = cnt.clone()
+        bn = torch.zeros_like(cnt)
+        for d in range(D + 1):
+            bn[d] = (8 ** d) if d <= F else cnt[d - 1] * 8
+        self.batch_nnum = bn
+        self.nnum_nempty = cnt.sum(1).to(torch.int32)
+        self.nnum = bn.sum(1).to(torch.int32)
+        cum = torch.zeros((D + 1, B + 1), dtype=torch.int32)
+        cum[:, 1:] = torch.cumsum(cnt, dim=1)
+        cum_dev = cum.to(dev, non_blocking=True)
+        for d in range(D + 1):
+            nn_, ne = int(self.nnum[d]), int(self.nnum_nempty[d])
+            self.keys[d] = torch.empty(nn_, dtype=torch.int64, device=dev)
+            self.children[d] = torch.full((nn_,), -1, dtype=torch.int32, device=dev)
+            self.nkeys[d] = torch.empty(ne, dtype=torch.int64, device=dev)
+            self.nidx[d] = torch.empty(ne, dtype=torch.int32, device=dev)
+        self.points[D] = torch.empty((int(self.nnum_nempty[D]), 3), dtype=torch.float32, device=dev)
+        tab = lambda lst: _native.ptr_array([t.data_ptr() for t in lst])
+        check(lib.hfl_octree_merge(scratch.data_ptr(), off.data_ptr(), cum_dev.data_ptr(), B, D, F, P,
+                                   tab(self.keys), tab(self.children), tab(self.nkeys),
+                                   tab(self.nidx), leaf_pts.data_ptr(), self.points[D].data_ptr(),
+                                   st), 'hfl_octree_merge')
+        self.batch_size = B
+        self._built = True
+
+    def construct_all_neigh(self):
+        """ocnn builds (nnum_d,27) tables over all nodes; this builds the tables of the
+        NON-EMPTY nodes (what `get_neigh(..., nempty=True)` returns) for d >= 1."""
+        self._need_built()
+        for d in range(1, self.depth + 1):
+            if self.neighs[d] is None:
+                self.neighs[d] = ops.octree_neigh(self.neighs[d - 1] if d > self.full_depth else None,
+                                                  self.nidx[d], self.children[d], self.nkeys[d],
+                                                  d, self.full_depth)
+
+    def _need_built(self):
+        if not self._built:
+            self._materialise()
+
+    # ---------------------------------------------------------------- accessors
+    def nempty_mask(self, depth: int):
+        self._need_built()
+        return self.children[depth] >= 0
+
+    def key(self, depth: int, nempty: bool = False):
+        self._need_built()
+        return self.nkeys[depth] if nempty else self.keys[depth]
+
+    def batch_id(self, depth: int, nempty: bool = False):
+        return self.key(depth, nempty) >> 48
+
+    def xyzb(self, depth: int, nempty: bool = False):
+        key = self.key(depth, nempty)
+        meta = ops.token_meta(key, depth) if nempty else None
+        if meta is None:
+            k = key & ((1 << 48) - 1)
+            x = torch.zeros_like(k); y = torch.zeros_like(k); z = torch.zeros_like(k)
+            for i in range(depth):
+                x |= ((k >> (3 * i + 2)) & 1) << i
+                y |= ((k >> (3 * i + 1)) & 1) << i
+                z |= ((k >> (3 * i)) & 1) << i
+            return x, y, z, key >> 48
+        p = meta[:, 0].long()
+        return p & 1023, (p >> 10) & 1023, (p >> 20) & 1023, meta[:, 1].long()
+
+    def get_neigh(self, depth: int, kernel: str = '333', stride: int = 1, nempty: bool = False):
+        """ocnn `get_neigh`; only the non-empty form is on the hot path (all shipped cfgs
+        use nempty=True).  stride 1: (nne_d, K) table; stride 2 + '222': the eight children
+        of every non-empty parent = `children[d].view(-1, 8)`."""
+        self._need_built()
+        if not nempty:
+            raise NotImplementedError('tables over empty nodes are off the HOTFormerLoc path')
+        if stride == 2:
+            if kernel != '222':
+                raise NotImplementedError('stride-2 octree conv is only used with kernel 2x2x2')
+            return self.children[depth].view(-1, 8)
+        if stride != 1:
+            raise ValueError('unsupported stride %d' % stride)
+        if self.neighs[depth] is None:
+            self.construct_all_neigh()
+        neigh = self.neighs[depth]
+        if kernel == '333':
+            return neigh
+        cols = torch.tensor(_KERNEL_LUT[kernel], device=neigh.device)
+        return neigh[:, cols].contiguous()
+
+    def get_input_feature(self, feature: str = 'P', nempty: bool = True):
+        """`ocnn.modules.InputFeature('P', nempty=True)` (models/hotformerloc.py:28-31):
+        leaf averages rescaled from [0, 2^depth] to [-1, 1]."""
+        self._need_built()
+        if feature.upper() != 'P' or not nempty:
+            raise NotImplementedError('only InputFeature("P", nempty=True) is supported')
+        return self.points[self.depth] * (2.0 ** (1 - self.depth)) - 1.0
+
+    # ------------------------------------------------------------------- device
+    def to(self, device: Union[torch.device, str], non_blocking: bool = False):
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self.device == device:
+            if device.type == 'cuda':
+                self._need_built()
+            return self
+        out = Octree(self.depth, self.full_depth, self.batch_size, device)
+        out._clouds = [c.to(device, non_blocking=non_blocking) for c in self._clouds]
+        if self._built:
+            mv = lambda lst: [t.to(device, non_blocking=non_blocking) if isinstance(t, torch.Tensor)
+                              else None for t in lst]
+            for name in ('keys', 'children', 'nkeys', 'nidx', 'neighs', 'points'):
+                setattr(out, name, mv(getattr(self, name)))
+            for name in ('nnum', 'nnum_nempty', 'batch_nnum', 'batch_nnum_nempty'):
+                setattr(out, name, getattr(self, name).clone())          # stay on the host
+            out._built = True
+        elif device.type == 'cuda':
+            out._materialise()
+        return out
+
+    def cuda(self, non_blocking: bool = False):
+        return self.to('cuda', non_blocking)
+
+    def cpu(self):
+        return self.to('cpu')
+
+
+def merge_octrees(octrees: List[Octree]) -> Octree:
+    """`ocnn.octree.merge_octrees`: batch = the clouds in list order.  Deferred octrees are
+    merged by concatenating their recorded clouds; the batch structure (keys with
+    `batch << 48`, child offsets, stacked `batch_nnum*`) comes out of the batched builder."""
+    if not octrees:
+        raise ValueError('empty octree list')
+    first = octrees[0]
+    out = Octree(first.depth, first.full_depth, batch_size=0, device=first.device)
+    for o in octrees:
+        if o.depth != first.depth or o.full_depth != first.full_depth:
+            raise ValueError('octrees of different depth cannot be merged')
+        if not o._clouds:
+            raise ValueError('octree without a point cloud')
+        out._clouds.extend(o._clouds)
+    out.batch_size = len(out._clouds)
+    out.batch_nnum = torch.zeros(first.depth + 1, out.batch_size, dtype=torch.int32)
+    out.batch_nnum_nempty = torch.zeros(first.depth + 1, out.batch_size, dtype=torch.int32)
+    if all(c.is_cuda for c in out._clouds):
+        out._materialise()
+    return out
+
+
+def build_batch_octree(clouds, depth: int, full_depth: int = 2, device='cuda',
+                       construct_neigh: bool = True) -> Octree:
+    """One-call fast path: list of (n,3) float32 arrays/tensors -> batch octree on `device`."""
+    octree = Octree(depth, full_depth, batch_size=len(clouds), device=device)
+    octree._clouds = [torch.as_tensor(c, dtype=torch.float32).contiguous() for c in clouds]
+    octree.device = torch.device(device)
+    if octree.device.type == 'cuda' and octree.device.index is None:
+        octree.device = torch.device('cuda', torch.cuda.current_device())
+    octree._materialise()
+    if construct_neigh:
+        octree.construct_all_neigh()
+    return octree

@@ -1,0 +1,247 @@
+"""Torch-facing wrappers over the C-ABI: tensors in, tensors out, current stream.
+
+PyTorch is plumbing here (device memory + streams): every function hands raw
+device pointers to libhotformerloc_hip.so on `torch.cuda.current_stream()` and
+never synchronises.  Inputs must live on the GPU -- there is no CPU path.
+"""
+
+import ctypes
+
+import torch
+
+from . import _native
+from ._native import WindowAttnDesc, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing on the launch stream (bench.py roofline leg).
+    `with KernelTimer() as t: ...; t.summary()` -> {kernel: (launches, ms, bytes, flops)}."""
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, nbytes, flops in self.records:
+            n, ms, b, f = out.get(name, (0, 0.0, 0, 0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), b + nbytes, f + flops)
+        return out
+
+
+class _timed:
+    def __init__(self, name, nbytes, flops=0):
+        self.t = KernelTimer.active
+        if self.t is not None:
+            self.name, self.nbytes, self.flops = name, int(nbytes), int(flops)
+
+    def __enter__(self):
+        if self.t is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            self.e1.record()
+            self.t.records.append((self.name, self.e0, self.e1, self.nbytes, self.flops))
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _native.NativeLibraryError(
+                'hotformerloc_amd ops need GPU tensors (got %s); there is no CPU fallback' % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError('float32 expected, got %s' % t.dtype)
+    return t.contiguous()
+
+
+def _idx(neigh):
+    if neigh.dtype == torch.int64:
+        return neigh.contiguous(), 1
+    if neigh.dtype == torch.int32:
+        return neigh.contiguous(), 0
+    raise TypeError('neighbour table must be int32 or int64, got %s' % neigh.dtype)
+
+
+# ------------------------------------------------------------------ dwconv.core API
+def dwconv_forward_backward(data: torch.Tensor, weight: torch.Tensor, neigh: torch.Tensor):
+    """libs/dwconv/csrc/dwconv.h:13 -- data (N,C), weight (K,1,C), neigh (M,K) -> (M,C)."""
+    _dev(data, weight, neigh)
+    data, weight = _f32c(data), _f32c(weight)
+    neigh, i64 = _idx(neigh)
+    m, k = neigh.shape
+    c = data.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=data.device)
+    check(_native.load().hfl_dwconv_forward_backward(
+        out.data_ptr(), data.data_ptr(), weight.data_ptr(), neigh.data_ptr(), i64, m, c, k,
+        _stream()), 'hfl_dwconv_forward_backward')
+    return out
+
+
+def dwconv_weight_backward(grad: torch.Tensor, data: torch.Tensor, neigh: torch.Tensor):
+    """libs/dwconv/csrc/dwconv.h:14 -- -> (K,1,C)."""
+    _dev(grad, data, neigh)
+    grad, data = _f32c(grad), _f32c(data)
+    neigh, i64 = _idx(neigh)
+    n, k = neigh.shape
+    c = data.shape[1]
+    lib = _native.load()
+    ws = torch.empty(int(lib.hfl_dwconv_weight_backward_workspace(n, c, k)), dtype=torch.uint8,
+                     device=data.device)
+    out = torch.empty((k, 1, c), dtype=torch.float32, device=data.device)
+    check(lib.hfl_dwconv_weight_backward(out.data_ptr(), grad.data_ptr(), data.data_ptr(),
+                                         neigh.data_ptr(), i64, n, c, k, ws.data_ptr(), _stream()),
+          'hfl_dwconv_weight_backward')
+    return out
+
+
+def inverse_neigh(neigh: torch.Tensor):
+    """libs/dwconv/csrc/dwconv.h:15."""
+    _dev(neigh)
+    neigh, i64 = _idx(neigh)
+    out = torch.empty_like(neigh)
+    check(_native.load().hfl_inverse_neigh(out.data_ptr(), neigh.data_ptr(), i64, neigh.shape[0],
+                                           neigh.shape[1], _stream()), 'hfl_inverse_neigh')
+    return out
+
+
+def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5):
+    """out = [x +] LayerNorm(dwconv(x, weight, neigh)) * gamma + beta (fused)."""
+    _dev(x, weight, gamma, beta, neigh)
+    x = _f32c(x)
+    assert neigh.dtype == torch.int32 and neigh.is_contiguous()
+    out = torch.empty_like(x)
+    n, c = x.shape
+    # algorithmic bytes: read x once, write out once, read the int32 neighbour rows
+    with _timed('hfl_cpe_forward', n * c * 8 + n * neigh.shape[1] * 4, 2 * neigh.shape[1] * n * c):
+        check(_native.load().hfl_cpe_forward(
+            out.data_ptr(), x.data_ptr(), _f32c(weight).data_ptr(), _f32c(gamma).data_ptr(),
+            _f32c(beta).data_ptr(), neigh.data_ptr(), n, c, neigh.shape[1],
+            float(eps), int(bool(residual)), _stream()), 'hfl_cpe_forward')
+    return out
+
+
+# ------------------------------------------------------------------------- gather
+def octree_gather(data, neigh):
+    """(N,C),(M,K) int32 -> (M, K*C): ocnn octree2col with zero fill."""
+    _dev(data, neigh)
+    data = _f32c(data)
+    assert neigh.dtype == torch.int32 and neigh.is_contiguous()
+    m, k = neigh.shape
+    c = data.shape[1]
+    out = torch.empty((m, k * c), dtype=torch.float32, device=data.device)
+    with _timed('hfl_octree_gather', data.numel() * 4 + m * k * c * 4 + m * k * 4):
+        check(_native.load().hfl_octree_gather(out.data_ptr(), data.data_ptr(), neigh.data_ptr(), m, k,
+                                               c, _stream()), 'hfl_octree_gather')
+    return out
+
+
+# ---------------------------------------------------------------------- attention
+def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, patch_size: int,
+                     dilation: int, n_relay: int, n_heads: int, batch_size: int, rt_row0: int = 0):
+    """qkv (rows, 3*H*16) -> out (rows, H*16); see hfl_window_attention_fwd."""
+    _dev(qkv, tok_meta, rpe_table)
+    qkv = _f32c(qkv)
+    rows = qkv.shape[0]
+    c = n_heads * 16
+    assert qkv.shape[1] == 3 * c
+    out = torch.empty((rows, c), dtype=torch.float32, device=qkv.device)
+    desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=rt_row0, n_windows=n_windows,
+                          patch_size=patch_size, dilation=dilation, n_relay=n_relay,
+                          n_heads=n_heads, pos_bnd=int(0.8 * patch_size * dilation ** 0.5),
+                          batch_size=batch_size, scale=16 ** -0.5)
+    table_ptr = None
+    if rpe_table is not None:
+        rpe_table = _f32c(rpe_table)
+        assert tuple(rpe_table.shape) == (3 * (2 * desc.pos_bnd + 1), n_heads)
+        table_ptr = rpe_table.data_ptr()
+    used = n_tokens + (n_windows if n_relay else 0)          # rows the kernel touches
+    seq = patch_size + n_relay
+    real_windows = -(-n_tokens // patch_size)
+    # algorithmic work: read q,k,v + write out, 16 B per (row, channel); QK^T + PV = 4 L^2 C per window
+    with _timed('hfl_window_attention_fwd', used * c * 16 + n_tokens * 8, 4 * seq * seq * c * real_windows):
+        check(_native.load().hfl_window_attention_fwd(out.data_ptr(), qkv.data_ptr(),
+                                                      tok_meta.data_ptr(), table_ptr,
+                                                      ctypes.byref(desc), _stream()),
+              'hfl_window_attention_fwd')
+    return out
+
+
+def relay_attention(qkv, seq_rows, seq_off, batch: int, n_heads: int):
+    """Ragged per-cloud attention over relay-token rows; rows in no sequence -> 0."""
+    _dev(qkv, seq_rows, seq_off)
+    qkv = _f32c(qkv)
+    c = n_heads * 16
+    out = torch.zeros((qkv.shape[0], c), dtype=torch.float32, device=qkv.device)
+    with _timed('hfl_relay_attention_fwd', qkv.shape[0] * c * 16):
+        check(_native.load().hfl_relay_attention_fwd(out.data_ptr(), qkv.data_ptr(),
+                                                     seq_rows.data_ptr(), seq_off.data_ptr(), batch,
+                                                     n_heads, 16 ** -0.5, _stream()),
+              'hfl_relay_attention_fwd')
+    return out
+
+
+def relay_token_init(x, tok_meta, n_windows: int, patch_size: int):
+    _dev(x, tok_meta)
+    x = _f32c(x)
+    rt = torch.empty((n_windows, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(_native.load().hfl_relay_token_init(rt.data_ptr(), x.data_ptr(), tok_meta.data_ptr(),
+                                              x.shape[0], n_windows, patch_size, x.shape[1],
+                                              _stream()), 'hfl_relay_token_init')
+    return rt
+
+
+def window_stats(tok_meta, n_tokens: int, n_windows: int, patch_size: int, depth: int):
+    _dev(tok_meta)
+    stats = torch.empty((n_windows, 9), dtype=torch.float32, device=tok_meta.device)
+    check(_native.load().hfl_window_stats(stats.data_ptr(), tok_meta.data_ptr(), n_tokens, n_windows,
+                                          patch_size, depth, _stream()), 'hfl_window_stats')
+    return stats
+
+
+def segment_softmax_(scores, row_off, batch: int, scale: float):
+    """In place: softmax over each cloud's rows, per query column."""
+    _dev(scores, row_off)
+    assert scores.dtype == torch.float32 and scores.is_contiguous() and row_off.dtype == torch.int64
+    check(_native.load().hfl_segment_softmax(scores.data_ptr(), row_off.data_ptr(), batch,
+                                             scores.shape[1], float(scale), _stream()),
+          'hfl_segment_softmax')
+    return scores
+
+
+# --------------------------------------------------------------------------- octree
+def token_meta(nkeys, depth: int):
+    _dev(nkeys)
+    assert nkeys.dtype == torch.int64
+    meta = torch.empty((nkeys.shape[0], 2), dtype=torch.int32, device=nkeys.device)
+    check(_native.load().hfl_token_meta(meta.data_ptr(), nkeys.data_ptr(), nkeys.shape[0], depth,
+                                        _stream()), 'hfl_token_meta')
+    return meta
+
+
+def octree_neigh(neigh_parent, nidx, children, nkeys, depth: int, full_depth: int):
+    _dev(nidx, children, nkeys)
+    nne = nkeys.shape[0]
+    out = torch.empty((nne, 27), dtype=torch.int32, device=nkeys.device)
+    check(_native.load().hfl_octree_neigh(
+        out.data_ptr(), None if neigh_parent is None else neigh_parent.data_ptr(), nidx.data_ptr(),
+        children.data_ptr(), nkeys.data_ptr(), nne, depth, full_depth, _stream()), 'hfl_octree_neigh')
+    return out

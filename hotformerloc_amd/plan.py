@@ -1,0 +1,130 @@
+"""Window / relay-token bookkeeping: the MI355X counterpart of `OctreeT`
+(`models/octree.py:38-433` of the reference).
+
+The reference materialises, per depth, int64 masks (N,K,K), relative positions
+(N,K,K,3), padded batch-id streams and a (B,Rmax,Rmax) relay-token mask, and drives
+ragged splits with `.tolist()` loops inside the forward.  Here the only things kept are
+
+  * host integers derived from `batch_nnum_nempty` (already on the host after the
+    octree build): token/window counts, per-cloud relay-token runs -- `window_layout`,
+    pure numpy, testable without a GPU;
+  * per depth one (N_t,2) uint32 token-meta array [x|y<<10|z<<20, batch id] on the
+    device, from which the attention kernels derive masks and relative positions;
+  * two small int32 index arrays describing each cloud's relay-token sequence.
+
+The forward pass therefore contains no device->host synchronisation.
+Formulas: SURVEY.md Appendix E (restating `models/octree.py:73-75,130-184,229-265`).
+"""
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def window_layout(batch_nne: np.ndarray, patch_size: int, dilation: int, max_depth: int,
+                  start_depth: int, pyramid_depths: List[int]) -> dict:
+    """Host-side integers of the window structure.
+
+    batch_nne: (depth+1, B) non-empty node counts per depth and cloud.
+    Returns per depth d in [start_depth, max_depth]:
+        n_tokens[d], n_padded[d] (multiple of K*D, octree.py:73-75), n_windows[d] = n_padded/K,
+      and per pyramid depth:
+        num_windows[d] (B,)  windows owned by each cloud, straddling windows counted for the
+                             left cloud, padding windows for the last (octree.py:163-184)
+        first_window[d] (B,) index of each cloud's first window
+        n_pad_windows[d]     windows that contain no real token
+      plus the relay-token sequences of RTSA (relay_token_utils.py:25-39, octree.py:229-265):
+        rt_offset[d]         first row of depth d inside the concatenated relay-token matrix
+        seq_rows, seq_off    cloud b attends rows seq_rows[seq_off[b]:seq_off[b+1]]
+        rt_counts (B,)       R_b including the padding windows of the last cloud (reference
+                             `batch_num_relay_tokens_combined`)
+    """
+    K, D = patch_size, dilation
+    B = batch_nne.shape[1]
+    block = K * D
+    out = dict(n_tokens={}, n_padded={}, n_windows={}, num_windows={}, first_window={},
+               n_pad_windows={}, rt_offset={})
+    for d in range(start_depth, max_depth + 1):
+        nt = int(batch_nne[d].sum())
+        na = -(-nt // block) * block
+        out['n_tokens'][d] = nt
+        out['n_padded'][d] = na
+        out['n_windows'][d] = na // K
+    row = 0
+    for d in pyramid_depths:
+        nt, na, W = out['n_tokens'][d], out['n_padded'][d], out['n_windows'][d]
+        cum = np.cumsum(batch_nne[d].astype(np.int64))
+        cum[-1] += na - nt
+        boundary = cum // K + (cum % K != 0)
+        nwin = np.diff(boundary, prepend=0)
+        out['num_windows'][d] = nwin
+        out['first_window'][d] = boundary - nwin
+        out['n_pad_windows'][d] = W - (-(-nt // K))
+        out['rt_offset'][d] = row
+        row += W
+    out['rt_rows_total'] = row
+    seq_rows, seq_off = [], [0]
+    rt_counts = np.zeros(B, dtype=np.int64)
+    for b in range(B):
+        for d in pyramid_depths:
+            n = int(out['num_windows'][d][b])
+            rt_counts[b] += n
+            if b == B - 1:
+                n -= out['n_pad_windows'][d]        # padding windows attend nothing (id B)
+            start = out['rt_offset'][d] + int(out['first_window'][d][b])
+            seq_rows.extend(range(start, start + max(n, 0)))
+        seq_off.append(len(seq_rows))
+    out['seq_rows'] = np.asarray(seq_rows, dtype=np.int32)
+    out['seq_off'] = np.asarray(seq_off, dtype=np.int32)
+    out['rt_counts'] = rt_counts
+    return out
+
+
+class WindowPlan:
+    """Device-side view of one batch octree for the attention stages."""
+
+    def __init__(self, octree, patch_size: int, dilation: int, max_depth: int, start_depth: int,
+                 num_pyramid_levels: int, num_octf_levels: int, adape_mode: Optional[str] = None):
+        assert start_depth >= 1, 'Octree not deep enough for model depth'    # octree.py:71
+        self.octree = octree
+        self.K, self.D = patch_size, dilation
+        self.B = octree.batch_size
+        self.max_depth, self.start_depth = max_depth, start_depth
+        self.pyramid_depths = [max_depth - num_octf_levels - j for j in range(num_pyramid_levels)]
+        self.adape_mode = adape_mode
+        self.device = octree.device
+        lay = window_layout(octree.batch_nnum_nempty.numpy(), patch_size, dilation, max_depth,
+                            start_depth, self.pyramid_depths)
+        self.layout = lay
+        self.n_tokens: Dict[int, int] = lay['n_tokens']
+        self.n_windows: Dict[int, int] = lay['n_windows']
+        self.rt_offset: Dict[int, int] = lay['rt_offset']
+        dev = self.device
+        self.meta = {d: ops.token_meta(octree.nkeys[d], d) for d in range(start_depth, max_depth + 1)}
+        self.seq_rows = torch.from_numpy(lay['seq_rows']).to(dev, non_blocking=True)
+        self.seq_off = torch.from_numpy(lay['seq_off']).to(dev, non_blocking=True)
+        # per-cloud row offsets of the token stream (attentional pooling segments)
+        self.cloud_off = {}
+        self.pad_index = {}
+        nne = octree.batch_nnum_nempty.numpy().astype(np.int64)
+        for d in self.pyramid_depths:
+            off = np.concatenate([[0], np.cumsum(nne[d])])
+            self.cloud_off[d] = torch.from_numpy(off).to(dev, non_blocking=True)
+            nmax = int(nne[d].max())
+            idx = np.full((self.B, nmax), int(off[-1]), dtype=np.int64)   # sentinel = zero row
+            for b in range(self.B):
+                idx[b, :nne[d][b]] = np.arange(off[b], off[b + 1])
+            self.pad_index[d] = torch.from_numpy(idx.reshape(-1)).to(dev, non_blocking=True)
+        self.window_stats = {}
+        if adape_mode is not None:
+            if adape_mode != 'cov':
+                raise NotImplementedError('ADaPE mode %r (shipped configs use "cov")' % adape_mode)
+            for d in self.pyramid_depths:
+                self.window_stats[d] = ops.window_stats(self.meta[d], self.n_tokens[d],
+                                                        self.n_windows[d], self.K, d)
+
+    def neigh(self, depth: int):
+        return self.octree.get_neigh(depth, '333', 1, nempty=True)

@@ -1,0 +1,220 @@
+/*
+ * hotformerloc_hip.h -- C-ABI of libhotformerloc_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the native side of the HOTFormerLoc hot path.  Every entry
+ * point takes plain device pointers and sizes (no torch types), enqueues work on
+ * the given HIP stream WITHOUT synchronising (the reference's extension launches
+ * on the current stream: libs/dwconv/csrc/dwconv.cu:92,106,124) and returns 0 on
+ * success or a hipError_t value (> 0) / a negative HFL_E* code on failure; the
+ * reference aborts on launch errors (libs/dwconv/csrc/utils.h:12-24), the host
+ * wrapper turns non-zero into a Python exception.
+ *
+ * All feature matrices are row-major float32.  "neigh" tables hold row indices,
+ * -1 = no neighbour.  Tables may be int64 (the reference's dtype, dwconv.cu:27)
+ * or int32 (what this library builds itself): `idx64` selects.
+ *
+ * The reference interface each function replaces is cited as file:line of
+ * csiro-robotics/HOTFormerLoc; ocnn==2.2.2 is the un-vendored dependency
+ * (requirements.txt:6) whose behaviour SURVEY.md Appendix A restates.
+ */
+#ifndef HOTFORMERLOC_HIP_H
+#define HOTFORMERLOC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hfl_stream_t; /* hipStream_t */
+
+#define HFL_OK 0
+#define HFL_EINVAL (-1)      /* unsupported shape / argument            */
+#define HFL_ECAPACITY (-2)   /* input exceeds a documented kernel limit */
+
+/* library / device identification: returns the version as major*100+minor */
+int hfl_version(void);
+/* name of the code-object architecture this library was compiled for */
+const char* hfl_arch(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Octree depth-wise convolution  (replaces dwconv.core, libs/dwconv)
+ * ---------------------------------------------------------------------- */
+
+/* out[h,c] = sum_k [neigh[h,k] >= 0] * weight[k,c] * data[neigh[h,k], c]
+ *   replaces  Tensor dwconv_forward_backward(Tensor data, Tensor weight, Tensor neigh)
+ *             libs/dwconv/csrc/dwconv.h:13, dwconv.cu:24-42,99-113, pybind.cpp:11
+ *   data (n_in,C) ; weight (K,1,C) ; neigh (n_out,K) ; out (n_out,C).  Also used for
+ *   the input gradient with the inverse table (libs/dwconv/dwconv/nn.py:36-38). */
+int hfl_dwconv_forward_backward(float* out, const float* data, const float* weight,
+                                const void* neigh, int idx64, int64_t n_out,
+                                int64_t channels, int kngh, hfl_stream_t stream);
+
+/* gW[k,c] = sum_h [neigh[h,k] >= 0] data[neigh[h,k], c] * grad[h,c]
+ *   replaces  Tensor dwconv_weight_backward(Tensor grad, Tensor data, Tensor neigh)
+ *             libs/dwconv/csrc/dwconv.h:14, dwconv.cu:44-72,115-131, pybind.cpp:12
+ *   out (K,1,C).  `workspace` must hold hfl_dwconv_weight_backward_workspace() bytes. */
+int64_t hfl_dwconv_weight_backward_workspace(int64_t n_rows, int64_t channels, int kngh);
+int hfl_dwconv_weight_backward(float* out, const float* grad, const float* data,
+                               const void* neigh, int idx64, int64_t n_rows,
+                               int64_t channels, int kngh, void* workspace,
+                               hfl_stream_t stream);
+
+/* ineigh[neigh[h,k], k] = h on a -1-filled (n_rows,K) table
+ *   replaces  Tensor inverse_neigh(Tensor neigh)
+ *             libs/dwconv/csrc/dwconv.h:15, dwconv.cu:74-97, pybind.cpp:13 */
+int hfl_inverse_neigh(void* ineigh, const void* neigh, int idx64, int64_t n_rows,
+                      int kngh, hfl_stream_t stream);
+
+/* Fused conditional position encoding:
+ *   y = LayerNorm_C( dwconv(x) ) * gamma + beta ;  out = residual ? x + y : y
+ *   replaces  CPE.forward + the residual of its callers
+ *             models/layers/octformer_layers.py:138-142,
+ *             models/octformer_backbone.py:258, models/hotformerloc_backbone.py:204,351
+ *   x,out (n,C) with C in {128,256} (C % 64 == 0, C <= 512); neigh int32 (n,27). */
+int hfl_cpe_forward(float* out, const float* x, const float* weight, const float* gamma,
+                    const float* beta, const int32_t* neigh, int64_t n_rows,
+                    int64_t channels, int kngh, float eps, int residual,
+                    hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 2. Octree construction  (replaces ocnn.octree.Octree.build_octree /
+ *    merge_octrees / construct_all_neigh; call sites datasets/dataset_utils.py:89-94,
+ *    eval/pnv_evaluate.py:173-175,123, misc/torch_utils.py:47-51)
+ * ---------------------------------------------------------------------- */
+
+/* Limits of the one-workgroup-per-cloud builder. */
+#define HFL_OCTREE_MAX_POINTS (1 << 20) /* points per cloud; <= 16384 sort entirely in LDS */
+#define HFL_OCTREE_MAX_DEPTH 10         /* 30-bit shuffled keys                            */
+
+/* Bytes of scratch hfl_octree_build_clouds needs. */
+int64_t hfl_octree_scratch_bytes(int64_t total_points, int batch, int max_points, int depth);
+
+/* Stage 1: one workgroup per cloud.  points (P,3) in [-1,1]; cloud_offsets (B+1)
+ * int64 on the DEVICE; total_points = P and max_points = the largest cloud are the
+ * host's copies of the same numbers (they size the scratch strides and the LDS sort).
+ * Writes per-cloud sorted unique node keys and child slots for depths
+ * full_depth..depth into `scratch`, the per-leaf point averages (scaled to
+ * [0,2^depth], ocnn's `points[depth]`) into leaf_points (P,3) at the cloud's point
+ * offset, and counts[(depth+1) * B] int32 = non-empty nodes per depth and cloud
+ * (`batch_nnum_nempty`, layout (depth+1,B) as models/octree.py:163 reads it).
+ * Returns HFL_ECAPACITY when max_points > HFL_OCTREE_MAX_POINTS. */
+int hfl_octree_build_clouds(const float* points, const int64_t* cloud_offsets, int batch,
+                            int64_t total_points, int max_points, int depth, int full_depth,
+                            void* scratch, float* leaf_points, int32_t* counts,
+                            hfl_stream_t stream);
+
+/* Stage 2 (after the host has read `counts` and allocated exact-size outputs):
+ * merge into batch arrays, ocnn `merge_octrees` layout.  For every depth d in
+ * [0,depth], pointers indexed by d:
+ *   keys[d]     int64 (nnum_d)      shuffled key | batch << 48      (may be NULL)
+ *   children[d] int32 (nnum_d)      index among non-empty nodes of depth d, or -1
+ *   nkeys[d]    int64 (nne_d)       keys of the non-empty nodes only
+ *   nidx[d]     int32 (nne_d)       position of each non-empty node among all nodes
+ * children[d] for d >= full_depth must be pre-filled with -1 by the caller.
+ * points_out (nne_depth,3) receives the compacted leaf averages.
+ * cum_nne (depth+1, B+1) int32 DEVICE: exclusive prefix of counts over clouds. */
+int hfl_octree_merge(const void* scratch, const int64_t* cloud_offsets, const int32_t* cum_nne,
+                     int batch, int depth, int full_depth, int64_t total_points,
+                     int64_t* const* keys, int32_t* const* children,
+                     int64_t* const* nkeys, int32_t* const* nidx,
+                     const float* leaf_points, float* points_out, hfl_stream_t stream);
+
+/* 27-neighbour table of the non-empty nodes of one depth, equal to ocnn
+ * `get_neigh(depth,'333',stride=1,nempty=True)`:
+ *   depth <= full_depth : by key arithmetic (children_d maps key -> non-empty rank)
+ *   depth  > full_depth : parent walk through neigh_parent (nne_{d-1},27),
+ *                         nidx_d and children_d.
+ * neigh_out int32 (nne_d,27). */
+int hfl_octree_neigh(int32_t* neigh_out, const int32_t* neigh_parent, const int32_t* nidx,
+                     const int32_t* children, const int64_t* nkeys, int64_t nne, int depth,
+                     int full_depth, hfl_stream_t stream);
+
+/* tok_meta (n,2) uint32 per non-empty node of one depth: [x | y<<10 | z<<20, batch id]
+ * (ocnn key2xyz / batch_id as read by models/octree.py:132,273-275). */
+int hfl_token_meta(uint32_t* tok_meta, const int64_t* nkeys, int64_t n, int depth,
+                   hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 3. Octree convolution gather  (ocnn.nn.OctreeConv's octree2col; call sites
+ *    models/layers/octformer_layers.py:89-95, models/octformer_backbone.py:470-475)
+ * ---------------------------------------------------------------------- */
+
+/* out[m, k*C + c] = neigh[m,k] >= 0 ? data[neigh[m,k], c] : 0 ;  out (n_out, K*C) */
+int hfl_octree_gather(float* out, const float* data, const int32_t* neigh, int64_t n_out,
+                      int kngh, int64_t channels, hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 4. Windowed multi-head attention over z-order octree windows
+ *    (replaces OctreeAttention.forward's bias build + SDPA,
+ *     models/octformer_backbone.py:59-88, RPE models/layers/octformer_layers.py:159-170,
+ *     masks models/octree.py:186-222,267-283, window (un)packing models/octree.py:346-386)
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int64_t n_tokens;     /* N_t: real tokens of this depth (rows 0..N_t-1 of qkv/out)    */
+  int64_t rt_row0;      /* first relay-token row in qkv/out (G=1), ignored when G=0     */
+  int32_t n_windows;    /* W = ceil(N_t / (K*D_pad)) * D_pad   (models/octree.py:73-75) */
+  int32_t patch_size;   /* K  (48 or 64)                                                 */
+  int32_t dilation;     /* D  (1, or the stage dilation 4 for odd OctFormer blocks)     */
+  int32_t n_relay;      /* G  (0 or 1)                                                   */
+  int32_t n_heads;      /* H, head dim is fixed at 16                                    */
+  int32_t pos_bnd;      /* int(0.8*K*sqrt(D)), rpe table has 3*(2*pos_bnd+1) rows        */
+  int32_t batch_size;   /* B: batch id given to padding                                  */
+  float scale;          /* 16^-0.5                                                       */
+} hfl_window_attn_desc;
+
+/* qkv (rows, 3*H*16): per row [q(H,16) | k(H,16) | v(H,16)], the layout produced by
+ * `self.qkv(data).reshape(-1, K+G, 3, H, C//H)`.  tok_meta (N_t) uint2 per token:
+ * .x = x | y<<10 | z<<20 (node coords at this depth), .y = batch id.
+ * rpe_table (3*(2*pos_bnd+1), H) float32 or NULL (disable_RPE).
+ * out (rows, H*16).  Window w covers tokens  w*K+k  (D=1)  or
+ * (w/D)*K*D + k*D + (w%D)  (dilated), k in [0,K).  Relay token of window w is row
+ * rt_row0 + w and carries the batch id of the window's first token. */
+int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_meta,
+                             const float* rpe_table, const hfl_window_attn_desc* desc,
+                             hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 5. Relay-token self-attention, ragged per cloud
+ *    (replaces concat_and_pad_rt + RTAttention SDPA + unpad_and_split_rt,
+ *     models/relay_token_utils.py:12-79, models/hotformerloc_backbone.py:83-119,
+ *     mask models/octree.py:229-265)
+ * ---------------------------------------------------------------------- */
+/* qkv (rows, 3*H*16), out (rows, H*16).  Cloud b attends over the rows
+ * seq_rows[seq_off[b] .. seq_off[b+1]) (its relay tokens of all pyramid depths,
+ * fine to coarse; relay tokens of pure-padding windows are in no sequence).  Rows not
+ * listed in seq_rows are left untouched (the caller zero-fills `out`). */
+int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_rows,
+                            const int32_t* seq_off, int batch, int n_heads, float scale,
+                            hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 6. Relay-token initialisation and window statistics
+ * ---------------------------------------------------------------------- */
+/* rt[w,:] = mean over tokens k of window w with batch id == id of the window's first
+ * token (models/hotformerloc_backbone.py:352-360, mask models/octree.py:142-145).
+ * Windows past the last token give 0.  x (N_t,C), rt (W,C). */
+int hfl_relay_token_init(float* rt, const float* x, const uint32_t* tok_meta,
+                         int64_t n_tokens, int32_t n_windows, int32_t patch_size,
+                         int64_t channels, hfl_stream_t stream);
+
+/* ADaPE window statistics, mode 'cov' (models/octree.py:285-344): per window mean (3)
+ * and upper-triangular Bessel covariance (6) of the owner's node coordinates rescaled
+ * to [-1,1] (misc/utils.py:293-304).  stats (W,9). */
+int hfl_window_stats(float* stats, const uint32_t* tok_meta, int64_t n_tokens,
+                     int32_t n_windows, int32_t patch_size, int depth, hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 7. Attentional pooling helpers (models/layers/salsa.py:25-55,
+ *    models/layers/pooling.py:209-233)
+ * ---------------------------------------------------------------------- */
+/* In place, per cloud b and pooled token q: scores[r, q] over rows
+ * r in [row_off[b], row_off[b+1]) -> softmax over r of scores * scale.
+ * scores (rows, n_queries). */
+int hfl_segment_softmax(float* scores, const int64_t* row_off, int batch, int n_queries,
+                        float scale, hfl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOTFORMERLOC_HIP_H */

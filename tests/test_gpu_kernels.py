@@ -1,0 +1,333 @@
+"""GPU parity tests, kernel by kernel: HIP path (through the C-ABI) vs the CPU oracle on the
+same seeded inputs.  Bit-exact for integer/index work, stated tolerances for fp32."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hotformerloc_amd import Octree, Points, merge_octrees, build_batch_octree, load_config, ops
+from hotformerloc_amd import dwconv as hdw
+from hotformerloc_amd import synthetic as syn
+from hotformerloc_amd.plan import WindowPlan
+from oracle import hotformer_ref
+from oracle.ocnn_ref import nn as onn
+from oracle.ocnn_ref.octree import Octree as OOctree, Points as OPoints, merge_octrees as omerge
+from oracle.testing import oracle_octree
+
+DEV = 'cuda'
+
+
+def _fixture_clouds(golden_dir, ids=(4, 5)):
+    out = []
+    for i in ids:
+        d = np.load(os.path.join(golden_dir, 'ocnn', 'test_%03d.npz' % i))
+        out.append(d['points'])
+    return out
+
+
+# ------------------------------------------------------------------------- octree
+def _compare_octree(dev_oct, ref_oct, check_points=True):
+    D = ref_oct.depth
+    assert np.array_equal(dev_oct.nnum.numpy(), ref_oct.nnum.numpy())
+    assert np.array_equal(dev_oct.nnum_nempty.numpy(), ref_oct.nnum_nempty.numpy())
+    assert np.array_equal(dev_oct.batch_nnum_nempty.numpy(), ref_oct.batch_nnum_nempty.numpy())
+    assert np.array_equal(dev_oct.batch_nnum.numpy(), ref_oct.batch_nnum.numpy())
+    for d in range(D + 1):
+        assert torch.equal(dev_oct.keys[d].cpu(), ref_oct.keys[d]), 'keys depth %d' % d
+        assert torch.equal(dev_oct.children[d].cpu(), ref_oct.children[d]), 'children depth %d' % d
+        assert torch.equal(dev_oct.key(d, nempty=True).cpu(), ref_oct.key(d, nempty=True))
+    for d in range(1, D + 1):
+        want = ref_oct.get_neigh(d, '333', 1, nempty=True)
+        got = dev_oct.get_neigh(d, '333', 1, nempty=True).cpu().long()
+        assert torch.equal(got, want), 'neigh depth %d' % d
+    for d in range(3, D + 1):
+        assert torch.equal(dev_oct.get_neigh(d, '222', 2, nempty=True).cpu().long(),
+                           ref_oct.get_neigh(d, '222', 2, nempty=True))
+    if check_points:
+        a = dev_oct.get_input_feature('P', True).cpu()
+        b = ref_oct.get_input_feature('P', nempty=True)
+        assert (a - b).abs().max() < 1e-6
+
+
+def test_octree_build_matches_ocnn_fixture(golden_dir):
+    """Batch of ocnn's test clouds 4+5 (depth 6, full depth 3): keys/children/counts bit-exact
+    against the vendored ocnn golden file batch_45.npz, neighbours against the oracle."""
+    clouds = _fixture_clouds(golden_dir)
+    o = build_batch_octree(clouds, depth=6, full_depth=3, device=DEV)
+    b = np.load(os.path.join(golden_dir, 'ocnn', 'batch_45.npz'))
+    assert np.array_equal(torch.cat(o.keys).cpu().numpy(), b['key'])
+    assert np.array_equal(torch.cat(o.children).cpu().numpy(), b['child'])
+    assert np.array_equal(o.nnum.numpy(), b['nnum'])
+    assert np.array_equal(o.nnum_nempty.numpy(), b['nnum_nempty'])
+    ref = omerge([_obuild(c, 6, 3) for c in clouds])
+    ref.construct_all_neigh()
+    _compare_octree(o, ref, check_points=False)
+    # fixture neighbour table (all nodes): rows of non-empty nodes, remapped, equal ours
+    neigh_all = torch.from_numpy(b['neigh']).long()
+    row0 = 0
+    for d in range(1, 7):
+        n = int(b['nnum'][d])
+        tab = neigh_all[row0:row0 + n]
+        row0 += n
+        child = ref.children[d]
+        tab = tab[child >= 0]
+        valid = tab >= 0
+        tab[valid] = child[tab[valid]].long()
+        assert torch.equal(o.get_neigh(d, '333', 1, True).cpu().long(), tab)
+
+
+def _obuild(pc, depth, full_depth=2):
+    o = OOctree(depth, full_depth)
+    o.build_octree(OPoints(torch.from_numpy(np.ascontiguousarray(pc, dtype=np.float32))))
+    return o
+
+
+@pytest.mark.parametrize('depth,sizes,kind', [
+    (7, [4096, 4096, 4096], 'ball'), (9, [4096, 3000], 'ball'), (7, [9, 60, 1, 700, 16384], 'mixed'),
+    (5, [5], 'ball'), (10, [8192], 'forest')])
+def test_octree_build_matches_oracle(depth, sizes, kind):
+    clouds = []
+    for i, n in enumerate(sizes):
+        seed = 40000 + 100 * depth + i
+        pc = syn.forest_cloud(seed, n) if (kind == 'forest' or (kind == 'mixed' and i % 2)) \
+            else syn.unit_ball_cloud(seed, n)
+        clouds.append(pc)
+    ref = oracle_octree(clouds, depth)
+    dev = build_batch_octree(clouds, depth, 2, DEV)
+    _compare_octree(dev, ref)
+
+
+def test_octree_api_deferred_build_and_merge():
+    """The reference's call sequence (dataset_utils.py:89-94 + torch_utils.py:47-51)."""
+    clouds = [syn.unit_ball_cloud(7 + i, 1000 + 300 * i) for i in range(3)]
+    octs = []
+    for pc in clouds:
+        o = Octree(7, 2)
+        o.build_octree(Points(torch.from_numpy(pc)))       # CPU points: deferred
+        octs.append(o)
+    m = merge_octrees(octs)
+    assert m.batch_size == 3
+    m = m.to(DEV)
+    m.construct_all_neigh()
+    _compare_octree(m, oracle_octree(clouds, 7))
+    back = m.cpu()
+    assert back.children[7].device.type == 'cpu' and torch.equal(back.keys[5], m.keys[5].cpu())
+    # coordinates exactly on the upper bound wrap like ocnn's masked key (documented edge case)
+    edge = np.array([[0.999, -1.0, 0.5], [1.0, 0.25, -0.25]], dtype=np.float32)
+    e = build_batch_octree([edge], 6, 2, DEV)
+    r = oracle_octree([edge], 6)
+    assert torch.equal(e.key(6, True).cpu(), r.key(6, True))
+
+
+def test_octree_large_cloud_multi_chunk_sort():
+    """> 16384 points: the bitonic network's wide strides run through L2 (two and four chunks)."""
+    clouds = [syn.unit_ball_cloud(1, 40000), syn.forest_cloud(2, 16385), syn.unit_ball_cloud(3, 100)]
+    _compare_octree(build_batch_octree(clouds, 8, 2, DEV), oracle_octree(clouds, 8))
+
+
+# ------------------------------------------------------------------------- dwconv
+def test_dwconv_matches_ocnn_semantics(golden_dir):
+    """Port of the reference's own test (`libs/dwconv/test/test_octree_dwconv.py:13-68`):
+    depth 4, C=256, 8 kernel shapes x nempty in {True, False}; the three raw functions, the
+    autograd Function and the Module against `ocnn.nn.OctreeDWConv` (oracle) fwd + both grads;
+    tolerances from the reference test: 1e-6 (out, data grad), 5e-5 (weight grad)."""
+    depth, channel = 4, 256
+    ref = omerge([_obuild(c, 6, 3) for c in _fixture_clouds(golden_dir)])
+    ref.construct_all_neigh()
+    kernel_size = [[3, 3, 3], [3, 1, 1], [1, 3, 1], [1, 1, 3], [2, 2, 2], [3, 3, 1], [1, 3, 3], [3, 1, 3]]
+    g = torch.Generator().manual_seed(0)
+    for ks in kernel_size:
+        for nempty in (True, False):
+            nnum = int(ref.nnum_nempty[depth] if nempty else ref.nnum[depth])
+            rnd = torch.randn(nnum, channel, generator=g)
+            oc = onn.OctreeDWConv(channel, ks, nempty=nempty)
+            od = rnd.clone().requires_grad_()
+            oout = oc(od, ref, depth)
+            oout.sum().backward()
+            kernel = ''.join(str(k) for k in ks)
+            neigh = ref.get_neigh(depth, kernel, 1, nempty).to(DEV)          # int64, as the reference
+            data = rnd.clone().to(DEV).requires_grad_()
+            weights = oc.weights.detach().clone().to(DEV).requires_grad_()
+            out = hdw.dwconv_forward_backward(data.detach(), weights.detach(), neigh)
+            grad = torch.ones_like(out)
+            ineigh = hdw.inverse_neigh(neigh)
+            grad_d = hdw.dwconv_forward_backward(grad, weights.detach(), ineigh)
+            grad_w = hdw.dwconv_weight_backward(grad, data.detach(), neigh)
+            assert torch.allclose(out.cpu(), oout.detach(), atol=1e-6), (ks, nempty)
+            assert torch.allclose(grad_d.cpu(), od.grad, atol=1e-6), (ks, nempty)
+            assert torch.allclose(grad_w.cpu(), oc.weights.grad, atol=5e-5), (ks, nempty)
+            o2 = hdw.octree_dwconv(data, weights, neigh)
+            o2.sum().backward()
+            assert torch.allclose(o2.detach().cpu(), oout.detach(), atol=1e-6)
+            assert torch.allclose(data.grad.cpu(), od.grad, atol=1e-6)
+            assert torch.allclose(weights.grad.cpu(), oc.weights.grad, atol=5e-5)
+            # int32 tables (what the library builds itself) give identical results
+            o3 = hdw.dwconv_forward_backward(data.detach(), weights.detach(), neigh.int())
+            assert torch.equal(o3, out)
+            assert torch.equal(hdw.inverse_neigh(neigh.int()).long(), ineigh)
+
+
+def test_dwconv_module_and_odd_channels():
+    clouds = [syn.unit_ball_cloud(91, 2000), syn.forest_cloud(92, 1500)]
+    ref = oracle_octree(clouds, 6)
+    dev = build_batch_octree(clouds, 6, 2, DEV)
+    g = torch.Generator().manual_seed(1)
+    for C in (96, 30, 7):       # vector path with 24 lanes/row, 4-aligned small, scalar path
+        n = int(ref.nnum_nempty[5])
+        x = torch.randn(n, C, generator=g)
+        mod = hdw.OctreeDWConv(C, [3], nempty=True).to(DEV)
+        oc = onn.OctreeDWConv(C, [3], nempty=True)
+        with torch.no_grad():
+            oc.weights.copy_(mod.weights.cpu())
+        xo = x.clone().requires_grad_()
+        oo = oc(xo, ref, 5)
+        (oo * oo).sum().backward()
+        xd = x.clone().to(DEV).requires_grad_()
+        od = mod(xd, dev, 5)
+        (od * od).sum().backward()
+        assert torch.allclose(od.detach().cpu(), oo.detach(), atol=2e-6, rtol=1e-5)
+        assert torch.allclose(xd.grad.cpu(), xo.grad, atol=1e-5, rtol=1e-4)
+        assert torch.allclose(mod.weights.grad.cpu(), oc.weights.grad, atol=2e-3, rtol=1e-4)
+
+
+def test_cpe_fused_and_gather():
+    clouds = [syn.unit_ball_cloud(11, 3000), syn.unit_ball_cloud(12, 2500)]
+    ref = oracle_octree(clouds, 7)
+    dev = build_batch_octree(clouds, 7, 2, DEV)
+    g = torch.Generator().manual_seed(2)
+    for depth, C in ((5, 128), (4, 256), (3, 256)):
+        n = int(ref.nnum_nempty[depth])
+        x = torch.randn(n, C, generator=g)
+        sd = {'c.conv.weights': torch.randn(27, 1, C, generator=g) * 0.3,
+              'c.norm.weight': 1 + 0.1 * torch.randn(C, generator=g),
+              'c.norm.bias': 0.1 * torch.randn(C, generator=g)}
+        want = hotformer_ref.cpe(x, sd, 'c', ref, depth)
+        neigh = dev.get_neigh(depth, '333', 1, True)
+        for residual in (False, True):
+            got = ops.cpe_forward(x.to(DEV), sd['c.conv.weights'].to(DEV), sd['c.norm.weight'].to(DEV),
+                                  sd['c.norm.bias'].to(DEV), neigh, residual).cpu()
+            w = want + x if residual else want
+            assert torch.allclose(got, w, atol=2e-5, rtol=1e-5), (depth, C, residual)
+    # gather == octree2col, both neighbour kinds and a 3-channel input
+    for depth, C, kernel, stride in ((7, 3, '333', 1), (6, 64, '333', 1), (6, 64, '222', 2), (7, 32, '222', 2)):
+        n = int(ref.nnum_nempty[depth])
+        x = torch.randn(n, C, generator=g)
+        want = onn.octree_gather(x, ref.get_neigh(depth, kernel, stride, True)).flatten(1)
+        got = ops.octree_gather(x.to(DEV), dev.get_neigh(depth, kernel, stride, True).contiguous()).cpu()
+        assert torch.equal(got, want)
+
+
+# ---------------------------------------------------------------------- attention
+def _plans(clouds, cfg, octree_depth):
+    params, _ = load_config(cfg)
+    ref = oracle_octree(clouds, octree_depth)
+    dev = build_batch_octree(clouds, octree_depth, 2, DEV)
+    md = octree_depth - 2
+    args = dict(patch_size=params.patch_size, dilation=params.dilation, max_depth=md,
+                start_depth=md - 3, num_pyramid_levels=3, num_octf_levels=1,
+                adape_mode=params.ADaPE_mode)
+    return params, ref, dev, hotformer_ref.WindowPlan(ref, **args), WindowPlan(dev, **args)
+
+
+@pytest.mark.parametrize('cfg,sizes', [('wild-places', [4096, 30, 2500]), ('cs-wild-places', [5000, 3000])])
+def test_window_attention_matches_oracle(cfg, sizes):
+    clouds = [syn.unit_ball_cloud(500 + i, n) for i, n in enumerate(sizes)]
+    params, ref, dev, oplan, plan = _plans(clouds, cfg, 7)
+    K, D = params.patch_size, params.dilation
+    g = torch.Generator().manual_seed(3)
+    B = len(sizes)
+    for depth, H, G, dil in ((5, 8, 0, 1), (5, 8, 0, D), (4, 16, 1, 1), (3, 16, 1, 1), (2, 16, 1, 1)):
+        C = H * 16
+        nt, W = plan.n_tokens[depth], plan.n_windows[depth]
+        assert nt == int(oplan.nnum_t[depth]) and W == int(oplan.nnum_a[depth]) // K
+        qkv_tok = torch.randn(nt, 3 * C, generator=g)
+        qkv_rt = torch.randn(W, 3 * C, generator=g)
+        bnd = int(0.8 * K * dil ** 0.5)
+        table = torch.randn(3 * (2 * bnd + 1), H, generator=g) * 0.5
+        # oracle on the reference's materialised windows
+        xw = oplan.to_windows(qkv_tok, depth, dil > 1)
+        if G:
+            xw = torch.cat([qkv_rt.unsqueeze(1), xw], 1)
+        q, k, v = xw.reshape(-1, K + G, 3, H, 16).permute(2, 0, 3, 1, 4)
+        if dil > 1:
+            mask, pos = oplan.dilate_mask[depth], oplan.dilate_pos[depth]
+        else:
+            mask, pos = (oplan.hat_mask[depth] if G else oplan.patch_mask[depth]), oplan.rel_pos[depth]
+        rpe = hotformer_ref.rpe_bias(table, pos, K, dil)
+        if G:
+            rpe = torch.nn.functional.pad(rpe, (G, 0, G, 0))
+        want = hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1) + rpe, 0.25).transpose(1, 2).reshape(-1, K + G, C)
+        want_tok = oplan.from_windows(want[:, G:], depth, dil > 1)
+        got = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth],
+                                   table.to(DEV), nt, W, K, dil, G, H, B, rt_row0=nt).cpu()
+        err = (got[:nt] - want_tok).abs().max().item()
+        assert err < 2e-5, (cfg, depth, G, dil, err)
+        if G:
+            real = -(-nt // K)                       # windows that hold at least one token
+            err = (got[nt:nt + real] - want[:real, 0]).abs().max().item()
+            assert err < 2e-5, ('relay rows', cfg, depth, err)
+            assert torch.isfinite(got).all()
+        # no RPE (disable_RPE=True path)
+        got0 = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth], None,
+                                    nt, W, K, dil, G, H, B, rt_row0=nt).cpu()
+        want0 = hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(-1, K + G, C)
+        assert (got0[:nt] - oplan.from_windows(want0[:, G:], depth, dil > 1)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize('cfg,sizes,depth', [('wild-places', [4096, 30, 2500, 4096], 7),
+                                             ('oxford', [4096, 4096], 9)])
+def test_relay_attention_init_and_stats(cfg, sizes, depth):
+    clouds = [syn.unit_ball_cloud(700 + i, n) for i, n in enumerate(sizes)]
+    params, ref, dev, oplan, plan = _plans(clouds, cfg, depth)
+    K, H, C, B = params.patch_size, 16, 256, len(sizes)
+    g = torch.Generator().manual_seed(4)
+    depths = oplan.pyramid_depths
+    # relay-token init (masked window mean) and ADaPE statistics
+    for d in depths:
+        x = torch.randn(plan.n_tokens[d], C, generator=g)
+        xw = oplan.pad(x, d).view(-1, K, C).masked_fill(oplan.rt_init_mask[d].unsqueeze(-1), float('nan'))
+        want = torch.nanmean(xw, 1)
+        got = ops.relay_token_init(x.to(DEV), plan.meta[d], plan.n_windows[d], K).cpu()
+        assert torch.allclose(got, want, atol=1e-6, rtol=1e-5)
+        if params.ADaPE_mode is not None:
+            assert torch.allclose(plan.window_stats[d].cpu(), oplan.window_stats[d], atol=2e-6, rtol=1e-5)
+    # RTSA attention core: oracle on padded (B,R,R) masks vs ragged kernel
+    rts = {d: torch.randn(plan.n_windows[d], 3 * C, generator=g) for d in depths}
+    counts = [oplan.batch_num_windows[d].tolist() for d in depths]
+    split = [rts[d].split(counts[j]) for j, d in enumerate(depths)]
+    x = hotformer_ref._pad_rows([torch.cat([split[j][b] for j in range(3)]) for b in range(B)])
+    q, k, v = x.reshape(B, -1, 3, H, 16).permute(2, 0, 3, 1, 4)
+    want = hotformer_ref._sdpa(q, k, v, oplan.rt_attn_mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(B, -1, C)
+    got = ops.relay_attention(torch.cat([rts[d] for d in depths]).to(DEV), plan.seq_rows, plan.seq_off,
+                              B, H).cpu()
+    lay = plan.layout
+    for b in range(B):
+        rows = lay['seq_rows'][lay['seq_off'][b]:lay['seq_off'][b + 1]]
+        # position of each listed row inside the padded per-cloud sequence of the reference
+        pos, p = [], 0
+        for j, d in enumerate(depths):
+            n = counts[j][b]
+            keep = n - (lay['n_pad_windows'][d] if b == B - 1 else 0)
+            pos.extend(range(p, p + keep))
+            p += n
+        assert len(pos) == len(rows)
+        err = (got[rows] - want[b, pos]).abs().max().item()
+        assert err < 2e-5, (cfg, b, err)
+    listed = np.zeros(got.shape[0], bool)
+    listed[lay['seq_rows']] = True
+    assert torch.all(got[~torch.from_numpy(listed)] == 0)
+
+
+def test_segment_softmax():
+    g = torch.Generator().manual_seed(5)
+    counts = [700, 1, 2075, 33]
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int64)
+    for nq in (148, 36, 7):
+        s = torch.randn(sum(counts), nq, generator=g) * 3
+        want = torch.cat([torch.softmax(s[off[b]:off[b + 1]] * 0.0625, dim=0) for b in range(4)])
+        got = ops.segment_softmax_(s.clone().to(DEV), off.to(DEV), 4, 0.0625).cpu()
+        assert torch.allclose(got, want, atol=1e-6, rtol=1e-5)
