@@ -43,7 +43,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='clouds per GPU')
     ap.add_argument('--points', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=4, help='clouds in the CPU baseline sample')
+    ap.add_argument('--cpu-sample', type=int, default=8, help='clouds in the CPU baseline sample')
+    ap.add_argument('--cpu-threads', type=int, default=16,
+                    help='torch threads of the CPU baseline (8-16 is the optimum measured on the 2x64-core host; more threads are slower)')
     return ap.parse_args()
 
 
@@ -54,11 +56,13 @@ def cpu_baseline(params, depth, args):
     from hotformerloc_amd import synthetic as syn
     from oracle import hotformer_ref
     from oracle.testing import oracle_octree, synthetic_state_dict
-    cores = os.cpu_count() or 1
+    cores = min(args.cpu_threads, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     sd = synthetic_state_dict(params, 'init')
-    warm = syn.make_clouds(2, 1, args.points, params.coordinates)
-    hotformer_ref.forward(sd, params, oracle_octree(warm, depth))            # warm-up, B=1
+    warm = syn.make_clouds(2, 2, args.points, params.coordinates)
+    log('cpu baseline: warm-up on %d threads' % cores)
+    hotformer_ref.forward(sd, params, oracle_octree(warm, depth))            # warm-up, B=2
+    log('cpu baseline: timed sample')
     clouds = syn.make_clouds(2, args.cpu_sample, args.points, params.coordinates)
     octree = oracle_octree(clouds, depth)                                    # boundary: prebuilt
     t0 = time.perf_counter()
@@ -66,8 +70,17 @@ def cpu_baseline(params, depth, args):
     dt = time.perf_counter() - t0
     return {'value': round(args.cpu_sample / dt, 4), 'unit': 'clouds/s', 'cores': cores,
             'kind': 'port',
-            'sample': 'oracle forward, 1 batch of %d clouds x %d pts, %s cfg, %.1f s, torch %d threads'
-                      % (args.cpu_sample, args.points, args.config, dt, torch.get_num_threads())}
+            'sample': 'oracle forward, 1 batch of %d clouds x %d pts, %s cfg, %.1f s, torch %d threads '
+                      '(host has %d logical CPUs)'
+                      % (args.cpu_sample, args.points, args.config, dt, torch.get_num_threads(),
+                         os.cpu_count() or 1)}
+
+
+_T0 = time.perf_counter()
+
+
+def log(*a):
+    print('[bench %.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
 
 def main():
@@ -93,12 +106,15 @@ def main():
     model = model_factory(params)
     syn.fill_synthetic_weights(model, 'init')
     model = model.to(dev).eval()
+    log('model ready')
 
     # this rank's contiguous slice of the global batch (ordered)
     clouds = syn.make_clouds(2, args.batch, args.points, params.coordinates,
                              first_index=rank * args.batch)
     octree = build_batch_octree(clouds, depth, 2, dev, construct_neigh=True)
     batch = {'octree': octree}
+    torch.cuda.synchronize()
+    log('octree ready', octree.nnum_nempty.tolist())
     gathered = [torch.empty((args.batch, params.output_dim), device=dev) for _ in range(world)] \
         if world > 1 else None
 
@@ -109,8 +125,10 @@ def main():
         return y
 
     with torch.inference_mode():
-        for _ in range(args.warmup):
+        for i in range(args.warmup):
             step()
+            torch.cuda.synchronize()
+            log('warmup step', i)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -123,6 +141,7 @@ def main():
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         kern = timer.summary()
+    log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
     assert torch.isfinite(y).all()
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
