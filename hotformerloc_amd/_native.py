@@ -25,7 +25,7 @@ class WindowAttnDesc(ctypes.Structure):
     _fields_ = [('n_tokens', c_int64), ('rt_row0', c_int64), ('n_windows', c_int32),
                 ('patch_size', c_int32), ('dilation', c_int32), ('n_relay', c_int32),
                 ('n_heads', c_int32), ('pos_bnd', c_int32), ('batch_size', c_int32),
-                ('scale', c_float)]
+                ('scale', c_float), ('depth', c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
@@ -52,11 +52,16 @@ SIGNATURES = {
     'hfl_octree_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
+    'hfl_set_variant': (c_int, [c_char_p, c_int]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                        c_float, c_void_p]),
+                                        c_float, c_int, c_void_p]),
     'hfl_relay_token_init': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                      c_int64, c_void_p]),
     'hfl_window_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),
+    'hfl_layer_norm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float,
+                               c_void_p]),
+    'hfl_add_layer_norm': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_int64, c_float, c_void_p]),
     'hfl_segment_softmax': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
 }
 

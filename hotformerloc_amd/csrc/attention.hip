@@ -41,6 +41,7 @@ struct WinParams {
   int H;
   int bnd;
   int batch;
+  int clamp;      // 1 when a coordinate difference can exceed pos_bnd
   float scale;
 };
 
@@ -197,15 +198,218 @@ window_attn_kernel(const WinParams p) {
   }
 }
 
+
+// ----------------------------------------------------------------------------------
+// v2: same decomposition, instruction diet.  The v1 body spends ~44 VALU per score (unpack,
+// six min/max, address math, dead/relay branches) against 2 MFMA per 16 scores, so it is
+// VALU-bound 20:1.  Here
+//   * per-position metadata is pre-digested once per window into LDS as int4
+//     {4*(bnd-x), 4*(bnd-y), 4*(bnd-z), batch id} for keys and {4x,4y,4z,id} for queries:
+//     one ds_read_b128 per key, RPE byte offset = med3(q4 + k4, 0, 8*bnd) per axis;
+//   * the RPE table copy in LDS is pre-multiplied by log2(e) and scores live in the exp2
+//     domain (v_exp_f32 directly, no per-score multiply);
+//   * dead positions are just "another batch" (-1e3 mask, exp2 underflows to exactly 0, the
+//     same mechanism the reference relies on for padding), so no per-score dead test;
+//   * the relay token sits alone in the last 16-tile: that key tile and that query tile are
+//     special-cased statically (no RPE, one live key column), never tested per score;
+//   * all Q fragments are fetched together with K and V (one memory round trip per window).
+template <int T, int G, bool CLAMP>
+__global__ void __launch_bounds__(1024)
+window_attn_kernel_v2(const WinParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LP = T * 16;
+  constexpr int TW = T - G;                        // tiles that hold window tokens
+  constexpr float kLog2e = 1.4426950408889634f;
+  const int H = p.H, K = p.K;
+  const int C = H * 16;
+  const int nrpe = 2 * p.bnd + 1;
+  int4* s_key = reinterpret_cast<int4*>(smem);                         // [LP]
+  int4* s_qry = s_key + LP;                                            // [LP]
+  int* s_row = reinterpret_cast<int*>(s_qry + LP);                     // [LP] qkv/out row, -1 dead
+  float* s_tab = reinterpret_cast<float*>(s_row + LP);                 // [H][3*nrpe] * log2e
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int hw = tid >> 6;                       // wave inside the workgroup
+  const int nhw = blockDim.x >> 6;               // heads handled by this workgroup
+  const int h = blockIdx.y * nhw + hw;           // head of this wave
+  const int c = lane & 15, g = lane >> 4;
+  const bool rpe = p.table != nullptr;
+
+  if (rpe)
+    for (int i = tid; i < 3 * nrpe * nhw; i += blockDim.x) {
+      const int r = i / nhw, hh = i % nhw;       // table is (3*nrpe, H) row-major
+      s_tab[hh * 3 * nrpe + r] = p.table[r * H + blockIdx.y * nhw + hh] * kLog2e;
+    }
+  // LDS byte addresses of this head's three axis tables; the query-side offsets carry them,
+  // so `q' + k` is already the address of the table entry (clamped to the axis table)
+  const int hu = __builtin_amdgcn_readfirstlane(hw);
+  const int tabx = (int)(size_t)(s_tab + hu * 3 * nrpe) ;
+  const int taby = tabx + nrpe * 4;
+  const int tabz = taby + nrpe * 4;
+  const int hi4 = 8 * p.bnd;                                           // 4 * (2*bnd)
+  const float scale2 = p.scale * kLog2e;
+  const float mask2 = kMaskValue * kLog2e;
+
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
+    __syncthreads();
+    for (int j = tid; j < LP; j += blockDim.x) {
+      int bid = -1, row = -1;
+      int x = 0, y = 0, z = 0;
+      if (j < K) {
+        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
+                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
+        if (t < p.n_tokens) {
+          const uint32_t xyz = p.meta[2 * t];
+          x = (int)(xyz & 1023u); y = (int)((xyz >> 10) & 1023u); z = (int)(xyz >> 20);
+          bid = (int)p.meta[2 * t + 1];
+          row = (int)t;
+        }
+      } else if (G > 0 && j == K) {
+        const int64_t t0 = (int64_t)w * K;
+        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
+        row = (int)(p.rt_row0 + w);
+      }
+      s_key[j] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), bid);
+      s_qry[j] = make_int4(4 * x, 4 * y, 4 * z, row >= 0 ? bid : -2);
+      s_row[j] = row;
+    }
+    __syncthreads();
+
+    // ---- all fragments of this head in one round trip ---------------------------------
+    float4 kf[T], qf[T];
+    float vf[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int row = s_row[t * 16 + c];
+      kf[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      qf[t] = kf[t];
+      if (row >= 0) {
+        const float* base = p.qkv + (int64_t)row * 3 * C + h * 16 + 4 * g;
+        qf[t] = *reinterpret_cast<const float4*>(base);
+        kf[t] = *reinterpret_cast<const float4*>(base + C);
+        qf[t].x *= scale2; qf[t].y *= scale2; qf[t].z *= scale2; qf[t].w *= scale2;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (G > 0 && t == T - 1 && r > 0) { vf[t][r] = 0.f; continue; }   // only the relay key lives there
+        const int rv = s_row[t * 16 + 4 * g + r];
+        vf[t][r] = rv >= 0 ? p.qkv[(int64_t)rv * 3 * C + 2 * C + h * 16 + c] : 0.f;
+      }
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < T; ++qt) {
+      int4 q = s_qry[qt * 16 + c];
+      const bool q_rpe = rpe && !(G > 0 && qt == T - 1);   // relay query: no RPE (static per qt)
+      q.x += tabx; q.y += taby; q.z += tabz;
+
+      f32x4 s[T];
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf[qt].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf[qt].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf[qt].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf[qt].w, acc, 0, 0, 0);
+        s[kt] = acc;
+      }
+
+      float mx = kDeadValue;
+#pragma unroll
+      for (int kt = 0; kt < TW; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int4 k = s_key[kt * 16 + 4 * g + r];
+          float v = s[kt][r];
+          if (q_rpe) {
+            int ox = q.x + k.x, oy = q.y + k.y, oz = q.z + k.z;
+            if (CLAMP) {     // |delta| can exceed pos_bnd only when 2^depth - 1 > pos_bnd
+              ox = min(max(ox, tabx), tabx + hi4);
+              oy = min(max(oy, taby), taby + hi4);
+              oz = min(max(oz, tabz), tabz + hi4);
+            }
+            typedef __attribute__((address_space(3))) const float lds_f32;
+            v += (*reinterpret_cast<lds_f32*>(ox) + *reinterpret_cast<lds_f32*>(oy)) +
+                 *reinterpret_cast<lds_f32*>(oz);
+          }
+          if (k.w != q.w) v += mask2;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      if (G > 0) {   // relay key: position K = tile T-1, k-slot group 0, register 0
+        const int kb = s_key[K].w;
+        float v = s[T - 1][0];
+        if (g != 0 || kb != q.w) v += mask2;
+        s[T - 1][0] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < TW; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+          s[kt][r] = e;
+          sum += e;
+        }
+      }
+      if (G > 0) {
+        const float e = __builtin_amdgcn_exp2f(s[T - 1][0] - mx);
+        s[T - 1][0] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < TW; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r] * inv, vf[kt][r], o, 0, 0, 0);
+      }
+      if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[T - 1][0] * inv, vf[T - 1][0], o, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = s_row[qt * 16 + 4 * g + r];
+        if (orow >= 0) p.out[(int64_t)orow * C + h * 16 + c] = o[r];
+      }
+    }
+  }
+}
+
+static int g_window_variant = 2;
+static int g_window_heads_per_wg = 4;
+
 template <int T, int G>
 static int launch_window(const WinParams& p, hipStream_t s) {
   constexpr int LP = T * 16;
   const int nrpe = 2 * p.bnd + 1;
-  const size_t lds = (p.table ? (size_t)p.H * 3 * nrpe * 4 : 0) + (size_t)LP * (4 + 4 + 8);
   int blocks = p.n_windows;
   const int cap = hfl_num_cus() * 4;
   if (blocks > cap) blocks = cap;
-  window_attn_kernel<T, G><<<blocks, p.H * 64, lds, s>>>(p);
+  if (g_window_variant == 1) {
+    const size_t lds = (p.table ? (size_t)p.H * 3 * nrpe * 4 : 0) + (size_t)LP * (4 + 4 + 8);
+    window_attn_kernel<T, G><<<blocks, p.H * 64, lds, s>>>(p);
+  } else {
+    int hpw = g_window_heads_per_wg;             // heads (= waves) per workgroup
+    if (hpw < 1 || hpw > p.H || p.H % hpw != 0) hpw = p.H;
+    const size_t lds = (p.table ? (size_t)hpw * 3 * nrpe * 4 : 0) + (size_t)LP * (16 + 16 + 4);
+    const int groups = p.H / hpw;
+    int bx = p.n_windows;
+    const int capx = hfl_num_cus() * 16 / groups;
+    if (bx > capx) bx = capx;
+    dim3 grid((unsigned)bx, (unsigned)groups);
+    if (p.clamp)
+      window_attn_kernel_v2<T, G, true><<<grid, hpw * 64, lds, s>>>(p);
+    else
+      window_attn_kernel_v2<T, G, false><<<grid, hpw * 64, lds, s>>>(p);
+  }
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -286,6 +490,26 @@ relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
 
 extern "C" {
 
+/* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
+int hfl_set_variant(const char* key, int value) {
+  if (key == nullptr) return HFL_EINVAL;
+  const char* k = "window_attention";
+  int i = 0;
+  while (k[i] != 0 && key[i] == k[i]) ++i;
+  if (k[i] == 0 && key[i] == 0) {
+    g_window_variant = value;
+    return HFL_OK;
+  }
+  const char* k2 = "window_heads_per_wg";
+  i = 0;
+  while (k2[i] != 0 && key[i] == k2[i]) ++i;
+  if (k2[i] == 0 && key[i] == 0) {
+    g_window_heads_per_wg = value;
+    return HFL_OK;
+  }
+  return HFL_EINVAL;
+}
+
 int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_meta,
                              const float* rpe_table, const hfl_window_attn_desc* d,
                              hfl_stream_t stream) {
@@ -298,6 +522,8 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
   p.n_tokens = d->n_tokens; p.rt_row0 = d->rt_row0; p.n_windows = d->n_windows;
   p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd;
   p.batch = d->batch_size; p.scale = d->scale;
+  // coordinates at octree depth `depth` are < 2^depth; 0 (unknown) keeps the clamp
+  p.clamp = (d->depth <= 0 || d->depth > 10 || ((1 << d->depth) - 1) > d->pos_bnd) ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int T = d->patch_size / 16 + d->n_relay;
   if (d->n_relay == 0) {
@@ -320,9 +546,11 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
 
 int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_rows,
                             const int32_t* seq_off, int batch, int n_heads, float scale,
-                            hfl_stream_t stream) {
-  if (batch <= 0 || n_heads <= 0) return HFL_EINVAL;
-  dim3 grid((unsigned)batch, 4);
+                            int max_seq_len, hfl_stream_t stream) {
+  if (batch <= 0 || n_heads <= 0 || max_seq_len < 0) return HFL_EINVAL;
+  // one wave per (head, 16-query tile) of the longest sequence; shorter clouds leave waves idle
+  const int items = n_heads * ((max_seq_len + 15) / 16);
+  dim3 grid((unsigned)batch, (unsigned)(items > 4 ? (items + 3) / 4 : 1));
   relay_attn_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(out, qkv, seq_rows, seq_off,
                                                                         n_heads, scale);
   HFL_RETURN_LAST_ERROR();

@@ -150,6 +150,98 @@ segment_softmax_kernel(float* __restrict__ scores, const int64_t* __restrict__ r
   }
 }
 
+
+// ------------------------------------------------------------------ LayerNorm
+// One row = TPR lanes x VPL float4 (C = 4*TPR*VPL); 256-thread blocks, grid-stride over rows.
+// Optional fused residual: xo = x + y (+ bias), h = LN(xo).  Pure streaming (HBM-bound).
+template <int TPR, int VPL, bool ADD>
+__global__ void __launch_bounds__(256)
+layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const float* __restrict__ y,
+                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                  const float* __restrict__ beta, int64_t n_rows, float eps) {
+  constexpr int C = TPR * VPL * 4;
+  constexpr int RPB = 256 / TPR;
+  const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
+  float4 gm[VPL], bt[VPL], bs[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    gm[v] = reinterpret_cast<const float4*>(gamma)[v * TPR + tx];
+    bt[v] = reinterpret_cast<const float4*>(beta)[v * TPR + tx];
+    bs[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ADD && bias != nullptr) bs[v] = reinterpret_cast<const float4*>(bias)[v * TPR + tx];
+  }
+  const float inv_c = 1.0f / (float)C;
+  for (int64_t base = (int64_t)blockIdx.x * RPB; base < n_rows; base += (int64_t)gridDim.x * RPB) {
+    const int64_t r = base + ty;
+    const bool live = r < n_rows;
+    float4 a[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      a[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        a[v] = reinterpret_cast<const float4*>(x + r * C)[v * TPR + tx];
+        if (ADD) {
+          const float4 b = reinterpret_cast<const float4*>(y + r * C)[v * TPR + tx];
+          a[v].x += b.x + bs[v].x; a[v].y += b.y + bs[v].y;
+          a[v].z += b.z + bs[v].z; a[v].w += b.w + bs[v].w;
+          reinterpret_cast<float4*>(x_out + r * C)[v * TPR + tx] = a[v];
+        }
+      }
+      sum += (a[v].x + a[v].y) + (a[v].z + a[v].w);
+    }
+    const float mean = hfl_group_sum<TPR>(sum) * inv_c;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      a[v].x -= mean; a[v].y -= mean; a[v].z -= mean; a[v].w -= mean;
+      sq += (a[v].x * a[v].x + a[v].y * a[v].y) + (a[v].z * a[v].z + a[v].w * a[v].w);
+    }
+    const float rstd = 1.0f / sqrtf(hfl_group_sum<TPR>(sq) * inv_c + eps);
+    if (live) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        float4 o;
+        o.x = fmaf(a[v].x * rstd, gm[v].x, bt[v].x);
+        o.y = fmaf(a[v].y * rstd, gm[v].y, bt[v].y);
+        o.z = fmaf(a[v].z * rstd, gm[v].z, bt[v].z);
+        o.w = fmaf(a[v].w * rstd, gm[v].w, bt[v].w);
+        reinterpret_cast<float4*>(h_out + r * C)[v * TPR + tx] = o;
+      }
+    }
+  }
+}
+
+template <int TPR, int VPL>
+static int launch_ln(float* h_out, float* x_out, const float* x, const float* y, const float* bias,
+                     const float* gamma, const float* beta, int64_t n, float eps, hipStream_t s) {
+  constexpr int RPB = 256 / TPR;
+  const int64_t need = hfl_cdiv(n, RPB);
+  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  const int blocks = (int)(need < cap ? need : cap);
+  if (y != nullptr)
+    layer_norm_kernel<TPR, VPL, true><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+  else
+    layer_norm_kernel<TPR, VPL, false><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+  HFL_RETURN_LAST_ERROR();
+}
+
+static int dispatch_ln(float* h_out, float* x_out, const float* x, const float* y, const float* bias,
+                       const float* gamma, const float* beta, int64_t n, int64_t C, float eps,
+                       hipStream_t s) {
+  if (n == 0) return HFL_OK;
+  switch (C) {
+    case 16:   return launch_ln<4, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 32:   return launch_ln<8, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 64:   return launch_ln<16, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 128:  return launch_ln<32, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 256:  return launch_ln<64, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 512:  return launch_ln<64, 2>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 1024: return launch_ln<64, 4>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    default:   return HFL_EINVAL;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -201,6 +293,21 @@ int hfl_segment_softmax(float* scores, const int64_t* row_off, int batch, int n_
   segment_softmax_kernel<<<grid, 1024, 0, static_cast<hipStream_t>(stream)>>>(scores, row_off,
                                                                               n_queries, scale);
   HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_layer_norm(float* out, const float* x, const float* gamma, const float* beta, int64_t n_rows,
+                   int64_t channels, float eps, hfl_stream_t stream) {
+  if (n_rows < 0) return HFL_EINVAL;
+  return dispatch_ln(out, nullptr, x, nullptr, nullptr, gamma, beta, n_rows, channels, eps,
+                     static_cast<hipStream_t>(stream));
+}
+
+int hfl_add_layer_norm(float* x_out, float* h_out, const float* x, const float* y, const float* bias,
+                       const float* gamma, const float* beta, int64_t n_rows, int64_t channels,
+                       float eps, hfl_stream_t stream) {
+  if (n_rows < 0 || y == nullptr || x_out == nullptr) return HFL_EINVAL;
+  return dispatch_ln(h_out, x_out, x, y, bias, gamma, beta, n_rows, channels, eps,
+                     static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -33,7 +33,19 @@ from .plan import WindowPlan
 
 
 def _ln(x, m: nn.LayerNorm):
+    """LayerNorm over channels: HIP kernel in inference, torch (autograd) when grads are needed."""
+    if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad)):
+        return ops.layer_norm(x, m.weight, m.bias, m.eps)
     return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+
+
+def _add_ln(x, y, m: nn.LayerNorm):
+    """(x + y, LN(x + y)): one fused pass in inference."""
+    if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad
+                                                       or m.weight.requires_grad)):
+        return ops.add_layer_norm(x, y, m.weight, m.bias, m.eps)
+    x = x + y
+    return x, F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
 
 
 def _require_layernorm(conv_norm: str):
@@ -146,9 +158,9 @@ class CPE(nn.Module):
         self.conv = OctreeDWConvParams(dim)
         self.norm = nn.LayerNorm(dim)
 
-    def forward(self, data, plan: WindowPlan, depth: int, residual: bool):
+    def forward(self, data, plan: WindowPlan, depth: int, residual: bool, out=None):
         return ops.cpe_forward(data, self.conv.weights, self.norm.weight, self.norm.bias,
-                               plan.neigh(depth), residual, self.norm.eps)
+                               plan.neigh(depth), residual, self.norm.eps, out=out)
 
 
 class RPE(nn.Module):
@@ -185,7 +197,7 @@ class OctreeAttention(nn.Module):
                                    n_tokens=nt, n_windows=plan.n_windows[depth],
                                    patch_size=self.patch_size, dilation=self.dilation,
                                    n_relay=self.rt_per_window, n_heads=self.num_heads,
-                                   batch_size=plan.B, rt_row0=nt)
+                                   batch_size=plan.B, rt_row0=nt, depth=depth)
         return self.proj(out)
 
 
@@ -202,8 +214,8 @@ class OctFormerBlock(nn.Module):
 
     def forward(self, x, plan: WindowPlan, depth: int):
         x = self.cpe(x, plan, depth, residual=True)
-        x = x + self.attention(_ln(x, self.norm1), plan, depth)
-        return x + self.mlp(_ln(x, self.norm2))
+        x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
+        return x + self.mlp(h)
 
 
 class OctFormerStage(nn.Module):
@@ -236,10 +248,15 @@ class HOTFormerBlock(nn.Module):
 
     def forward(self, buf, plan: WindowPlan, depth: int):
         nt = plan.n_tokens[depth]
-        tok = self.cpe(buf[:nt], plan, depth, residual=True)
-        buf = torch.cat([tok, buf[nt:]], 0)
-        buf = buf + self.attention(_ln(buf, self.norm1), plan, depth)
-        return buf + self.mlp(_ln(buf, self.norm2))
+        if torch.is_grad_enabled() and buf.requires_grad:
+            buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:]], 0)
+        else:                                   # CPE writes straight into the new buffer's token rows
+            new = torch.empty_like(buf)
+            self.cpe(buf[:nt], plan, depth, residual=True, out=new[:nt])
+            new[nt:].copy_(buf[nt:])
+            buf = new
+        buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
+        return buf + self.mlp(h)
 
 
 class RTAttention(nn.Module):
@@ -252,7 +269,8 @@ class RTAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
 
     def forward(self, rt, plan: WindowPlan):
-        out = ops.relay_attention(self.qkv(rt), plan.seq_rows, plan.seq_off, plan.B, self.num_heads)
+        out = ops.relay_attention(self.qkv(rt), plan.seq_rows, plan.seq_off, plan.B, self.num_heads,
+                                  plan.max_seq_len)
         return self.proj(out)
 
 
@@ -267,8 +285,8 @@ class RelayTokenTransformerBlock(nn.Module):
         self.mlp = MLP(dim, int(dim * 4.0), dim)
 
     def forward(self, rt, plan):
-        rt = rt + self.rt_attention(_ln(rt, self.norm1), plan)
-        return rt + self.mlp(_ln(rt, self.norm2))
+        rt, h = _add_ln(rt, self.rt_attention(_ln(rt, self.norm1), plan), self.norm2)
+        return rt + self.mlp(h)
 
 
 class RelayTokenInitialiser(nn.Module):
@@ -345,7 +363,11 @@ class HOTFormerStage(nn.Module):
             rt_all = self.rtsa_blocks[i](rt_all, plan)
             for d, nt in zip(depths, nts):
                 off = plan.rt_offset[d]
-                bufs[d] = torch.cat([bufs[d][:nt], rt_all[off:off + plan.n_windows[d]]], 0)
+                new_rt = rt_all[off:off + plan.n_windows[d]]
+                if torch.is_grad_enabled() and bufs[d].requires_grad:
+                    bufs[d] = torch.cat([bufs[d][:nt], new_rt], 0)
+                else:                              # only the relay rows move; tokens stay in place
+                    bufs[d][nt:].copy_(new_rt)
             for j, d in enumerate(depths):
                 bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
         local = {d: bufs[d][:nt] for d, nt in zip(depths, nts)}

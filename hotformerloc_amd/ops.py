@@ -123,12 +123,17 @@ def inverse_neigh(neigh: torch.Tensor):
     return out
 
 
-def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5):
-    """out = [x +] LayerNorm(dwconv(x, weight, neigh)) * gamma + beta (fused)."""
+def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5, out=None):
+    """out = [x +] LayerNorm(dwconv(x, weight, neigh)) * gamma + beta (fused).  `out` may be a
+    preallocated contiguous (n, C) view (e.g. the token rows of a larger buffer)."""
     _dev(x, weight, gamma, beta, neigh)
     x = _f32c(x)
     assert neigh.dtype == torch.int32 and neigh.is_contiguous()
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        assert out.shape == x.shape and out.is_contiguous() and out.dtype == torch.float32
+        assert out.data_ptr() != x.data_ptr(), 'CPE gathers neighbours: cannot run in place'
     n, c = x.shape
     # algorithmic bytes: read x once, write out once, read the int32 neighbour rows
     with _timed('hfl_cpe_forward', n * c * 8 + n * neigh.shape[1] * 4, 2 * neigh.shape[1] * n * c):
@@ -137,6 +142,38 @@ def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5
             _f32c(beta).data_ptr(), neigh.data_ptr(), n, c, neigh.shape[1],
             float(eps), int(bool(residual)), _stream()), 'hfl_cpe_forward')
     return out
+
+
+# ---------------------------------------------------------------------- layer norm
+_LN_CHANNELS = (16, 32, 64, 128, 256, 512, 1024)
+
+
+def layer_norm(x, weight, bias, eps: float = 1e-5):
+    """LayerNorm over the last axis of a (..., C) fp32 tensor (HIP kernel, one pass)."""
+    _dev(x, weight, bias)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    out = torch.empty_like(x2)
+    with _timed('hfl_layer_norm', x2.numel() * 8):
+        check(_native.load().hfl_layer_norm(out.data_ptr(), x2.data_ptr(), weight.data_ptr(),
+                                            bias.data_ptr(), x2.shape[0], c, float(eps), _stream()),
+              'hfl_layer_norm')
+    return out.view(x.shape)
+
+
+def add_layer_norm(x, y, weight, bias, eps: float = 1e-5, add_bias=None, inplace: bool = False):
+    """(x + y [+ add_bias], LN(x + y [+ add_bias])) in one pass over the rows."""
+    _dev(x, y, weight, bias, add_bias)
+    c = x.shape[-1]
+    x2, y2 = _f32c(x).view(-1, c), _f32c(y).view(-1, c)
+    xo = x2 if inplace else torch.empty_like(x2)
+    h = torch.empty_like(x2)
+    with _timed('hfl_add_layer_norm', x2.numel() * 16):
+        check(_native.load().hfl_add_layer_norm(
+            xo.data_ptr(), h.data_ptr(), x2.data_ptr(), y2.data_ptr(),
+            None if add_bias is None else add_bias.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+            x2.shape[0], c, float(eps), _stream()), 'hfl_add_layer_norm')
+    return xo.view(x.shape), h.view(x.shape)
 
 
 # ------------------------------------------------------------------------- gather
@@ -156,7 +193,8 @@ def octree_gather(data, neigh):
 
 # ---------------------------------------------------------------------- attention
 def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, patch_size: int,
-                     dilation: int, n_relay: int, n_heads: int, batch_size: int, rt_row0: int = 0):
+                     dilation: int, n_relay: int, n_heads: int, batch_size: int, rt_row0: int = 0,
+                     depth: int = 0):
     """qkv (rows, 3*H*16) -> out (rows, H*16); see hfl_window_attention_fwd."""
     _dev(qkv, tok_meta, rpe_table)
     qkv = _f32c(qkv)
@@ -167,7 +205,7 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=rt_row0, n_windows=n_windows,
                           patch_size=patch_size, dilation=dilation, n_relay=n_relay,
                           n_heads=n_heads, pos_bnd=int(0.8 * patch_size * dilation ** 0.5),
-                          batch_size=batch_size, scale=16 ** -0.5)
+                          batch_size=batch_size, scale=16 ** -0.5, depth=depth)
     table_ptr = None
     if rpe_table is not None:
         rpe_table = _f32c(rpe_table)
@@ -185,7 +223,7 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     return out
 
 
-def relay_attention(qkv, seq_rows, seq_off, batch: int, n_heads: int):
+def relay_attention(qkv, seq_rows, seq_off, batch: int, n_heads: int, max_seq_len: int):
     """Ragged per-cloud attention over relay-token rows; rows in no sequence -> 0."""
     _dev(qkv, seq_rows, seq_off)
     qkv = _f32c(qkv)
@@ -194,7 +232,7 @@ def relay_attention(qkv, seq_rows, seq_off, batch: int, n_heads: int):
     with _timed('hfl_relay_attention_fwd', qkv.shape[0] * c * 16):
         check(_native.load().hfl_relay_attention_fwd(out.data_ptr(), qkv.data_ptr(),
                                                      seq_rows.data_ptr(), seq_off.data_ptr(), batch,
-                                                     n_heads, 16 ** -0.5, _stream()),
+                                                     n_heads, 16 ** -0.5, int(max_seq_len), _stream()),
               'hfl_relay_attention_fwd')
     return out
 

@@ -106,6 +106,7 @@ class WindowPlan:
         self.meta = {d: ops.token_meta(octree.nkeys[d], d) for d in range(start_depth, max_depth + 1)}
         self.seq_rows = torch.from_numpy(lay['seq_rows']).to(dev, non_blocking=True)
         self.seq_off = torch.from_numpy(lay['seq_off']).to(dev, non_blocking=True)
+        self.max_seq_len = int(np.diff(lay['seq_off']).max()) if self.B > 0 else 0
         # per-cloud row offsets of the token stream (attentional pooling segments)
         self.cloud_off = {}
         self.pad_index = {}

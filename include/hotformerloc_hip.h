@@ -161,6 +161,7 @@ typedef struct {
   int32_t pos_bnd;      /* int(0.8*K*sqrt(D)), rpe table has 3*(2*pos_bnd+1) rows        */
   int32_t batch_size;   /* B: batch id given to padding                                  */
   float scale;          /* 16^-0.5                                                       */
+  int32_t depth;        /* octree depth of the tokens (coords < 2^depth); 0 = unknown    */
 } hfl_window_attn_desc;
 
 /* qkv (rows, 3*H*16): per row [q(H,16) | k(H,16) | v(H,16)], the layout produced by
@@ -174,6 +175,11 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
                              const float* rpe_table, const hfl_window_attn_desc* desc,
                              hfl_stream_t stream);
 
+/* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (1 = first
+ * version, 2 = default), "window_heads_per_wg" (waves per workgroup of the window kernel,
+ * default 4).  Returns HFL_EINVAL for an unknown key. */
+int hfl_set_variant(const char* key, int value);
+
 /* ------------------------------------------------------------------------
  * 5. Relay-token self-attention, ragged per cloud
  *    (replaces concat_and_pad_rt + RTAttention SDPA + unpad_and_split_rt,
@@ -183,10 +189,11 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
 /* qkv (rows, 3*H*16), out (rows, H*16).  Cloud b attends over the rows
  * seq_rows[seq_off[b] .. seq_off[b+1]) (its relay tokens of all pyramid depths,
  * fine to coarse; relay tokens of pure-padding windows are in no sequence).  Rows not
- * listed in seq_rows are left untouched (the caller zero-fills `out`). */
+ * listed in seq_rows are left untouched (the caller zero-fills `out`).  max_seq_len = the
+ * longest per-cloud sequence (host copy; sizes the grid). */
 int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_rows,
                             const int32_t* seq_off, int batch, int n_heads, float scale,
-                            hfl_stream_t stream);
+                            int max_seq_len, hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 6. Relay-token initialisation and window statistics
@@ -213,6 +220,19 @@ int hfl_window_stats(float* stats, const uint32_t* tok_meta, int64_t n_tokens,
  * scores (rows, n_queries). */
 int hfl_segment_softmax(float* scores, const int64_t* row_off, int batch, int n_queries,
                         float scale, hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 8. LayerNorm over the channel axis, optionally fused with the residual add that precedes it
+ *    (torch.nn.LayerNorm call sites: models/octformer_backbone.py:275-278,
+ *     models/hotformerloc_backbone.py:213-216,288-291; eps 1e-5, two-pass statistics)
+ * ---------------------------------------------------------------------- */
+/* out = LN(x) * gamma + beta ;  channels in {16,32,64,128,256,512,1024} */
+int hfl_layer_norm(float* out, const float* x, const float* gamma, const float* beta, int64_t n_rows,
+                   int64_t channels, float eps, hfl_stream_t stream);
+/* x_out = x + y (+ bias, may be NULL) ; h_out = LN(x_out) * gamma + beta.  x_out may alias x. */
+int hfl_add_layer_norm(float* x_out, float* h_out, const float* x, const float* y, const float* bias,
+                       const float* gamma, const float* beta, int64_t n_rows, int64_t channels,
+                       float eps, hfl_stream_t stream);
 
 #ifdef __cplusplus
 }

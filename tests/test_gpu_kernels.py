@@ -266,6 +266,10 @@ def test_window_attention_matches_oracle(cfg, sizes):
                                    table.to(DEV), nt, W, K, dil, G, H, B, rt_row0=nt).cpu()
         err = (got[:nt] - want_tok).abs().max().item()
         assert err < 2e-5, (cfg, depth, G, dil, err)
+        # depth given: the kernel may drop the RPE clamp (coordinates < 2^depth <= pos_bnd)
+        got_d = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth],
+                                     table.to(DEV), nt, W, K, dil, G, H, B, rt_row0=nt, depth=depth).cpu()
+        assert torch.equal(got_d[:nt], got[:nt])
         if G:
             real = -(-nt // K)                       # windows that hold at least one token
             err = (got[nt:nt + real] - want[:real, 0]).abs().max().item()
@@ -303,7 +307,7 @@ def test_relay_attention_init_and_stats(cfg, sizes, depth):
     q, k, v = x.reshape(B, -1, 3, H, 16).permute(2, 0, 3, 1, 4)
     want = hotformer_ref._sdpa(q, k, v, oplan.rt_attn_mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(B, -1, C)
     got = ops.relay_attention(torch.cat([rts[d] for d in depths]).to(DEV), plan.seq_rows, plan.seq_off,
-                              B, H).cpu()
+                              B, H, plan.max_seq_len).cpu()
     lay = plan.layout
     for b in range(B):
         rows = lay['seq_rows'][lay['seq_off'][b]:lay['seq_off'][b + 1]]
@@ -331,3 +335,25 @@ def test_segment_softmax():
         want = torch.cat([torch.softmax(s[off[b]:off[b + 1]] * 0.0625, dim=0) for b in range(4)])
         got = ops.segment_softmax_(s.clone().to(DEV), off.to(DEV), 4, 0.0625).cpu()
         assert torch.allclose(got, want, atol=1e-6, rtol=1e-5)
+
+
+def test_layer_norm_and_fused_add():
+    g = torch.Generator().manual_seed(6)
+    for n, C in ((1000, 128), (777, 256), (50, 32), (300, 64), (9, 1024), (33, 512), (5, 16)):
+        x = torch.randn(n, C, generator=g) * 3 + 0.5
+        y = torch.randn(n, C, generator=g)
+        w = 1 + 0.1 * torch.randn(C, generator=g)
+        b = 0.1 * torch.randn(C, generator=g)
+        ab = 0.2 * torch.randn(C, generator=g)
+        want = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5)
+        got = ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+        assert torch.allclose(got, want, atol=2e-6, rtol=1e-5), (n, C)
+        xs = x + y + ab
+        xo, h = ops.add_layer_norm(x.to(DEV), y.to(DEV), w.to(DEV), b.to(DEV), add_bias=ab.to(DEV))
+        assert torch.allclose(xo.cpu(), xs, atol=1e-6)
+        assert torch.allclose(h.cpu(), torch.nn.functional.layer_norm(xs, (C,), w, b, 1e-5), atol=3e-6, rtol=1e-5)
+        xo2, h2 = ops.add_layer_norm(x.to(DEV), y.to(DEV), w.to(DEV), b.to(DEV))
+        assert torch.allclose(xo2.cpu(), x + y, atol=1e-6)
+    x3 = torch.randn(4, 37, 256, generator=g)
+    got = ops.layer_norm(x3.to(DEV), torch.ones(256, device=DEV), torch.zeros(256, device=DEV)).cpu()
+    assert torch.allclose(got, torch.nn.functional.layer_norm(x3, (256,)), atol=2e-6, rtol=1e-5)
