@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--config', default='wild-places')
     ap.add_argument('--batch', type=int, default=32, help='clouds per GPU')
     ap.add_argument('--points', type=int, default=4096)
+    ap.add_argument('--gemm', default='bf16x3', choices=['bf16x3', 'fp32'],
+                    help="Linear layers: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) operands, fp32 "
+                         "accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='clouds in the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=16,
@@ -89,6 +92,8 @@ def main():
     import torch.distributed as dist
     from hotformerloc_amd import build_batch_octree, load_config, model_factory, ops
     from hotformerloc_amd import synthetic as syn
+    from hotformerloc_amd.model import set_gemm_mode
+    set_gemm_mode(args.gemm)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -171,10 +176,12 @@ def main():
             'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)', 'value': round(total_clouds / elapsed, 2),
             'unit': 'clouds/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.gemm == 'fp32' else 'f32 (Linear products as 3-term bf16 split, f32 accumulate)',
+            'data': 'synthetic',
             'config': {'workload': '%s cfg, batch=%d clouds/GPU x %d pts, octree depth %d, forward-only, '
                                    'octree+neighbours resident' % (args.config, args.batch, args.points, depth),
-                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
                        'collective': 'rccl all_gather (B_local,256) f32' if world > 1 else 'none'},
             'roofline': roof, 'kernels': others,
         }

@@ -52,6 +52,15 @@ SIGNATURES = {
     'hfl_octree_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
+    'hfl_window_attention_fwd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            ctypes.POINTER(WindowAttnDesc), c_int, c_void_p]),
+    'hfl_layer_norm_split3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                      c_float, c_void_p]),
+    'hfl_add_layer_norm_split3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_int64, c_float, c_void_p]),
+    'hfl_add_bias': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'hfl_bias_gelu_split3': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'hfl_split3': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),

@@ -43,7 +43,15 @@ struct WinParams {
   int batch;
   int clamp;      // 1 when a coordinate difference can exceed pos_bnd
   float scale;
+  const float* qkv_bias;   // (3*H*16) added to q,k,v on load (bias-free GEMM upstream), or null
+  int out_split;           // 1: out is bf16 [hi|hi|lo] rows of 3*H*16 (A operand of the split GEMM)
 };
+
+__device__ __forceinline__ uint16_t att_bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
 
 // T = number of 16-wide tiles of the padded sequence (K/16 + G), G = relay tokens
 template <int T, int G>
@@ -251,6 +259,14 @@ window_attn_kernel_v2(const WinParams p) {
   const float scale2 = p.scale * kLog2e;
   const float mask2 = kMaskValue * kLog2e;
 
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bk = bq;
+  float bv = 0.f;
+  if (p.qkv_bias != nullptr) {
+    bq = *reinterpret_cast<const float4*>(p.qkv_bias + h * 16 + 4 * g);
+    bk = *reinterpret_cast<const float4*>(p.qkv_bias + C + h * 16 + 4 * g);
+    bv = p.qkv_bias[2 * C + h * 16 + c];
+  }
+
   for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
     __syncthreads();
     for (int j = tid; j < LP; j += blockDim.x) {
@@ -288,13 +304,15 @@ window_attn_kernel_v2(const WinParams p) {
         const float* base = p.qkv + (int64_t)row * 3 * C + h * 16 + 4 * g;
         qf[t] = *reinterpret_cast<const float4*>(base);
         kf[t] = *reinterpret_cast<const float4*>(base + C);
-        qf[t].x *= scale2; qf[t].y *= scale2; qf[t].z *= scale2; qf[t].w *= scale2;
+        qf[t].x = (qf[t].x + bq.x) * scale2; qf[t].y = (qf[t].y + bq.y) * scale2;
+        qf[t].z = (qf[t].z + bq.z) * scale2; qf[t].w = (qf[t].w + bq.w) * scale2;
+        kf[t].x += bk.x; kf[t].y += bk.y; kf[t].z += bk.z; kf[t].w += bk.w;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (G > 0 && t == T - 1 && r > 0) { vf[t][r] = 0.f; continue; }   // only the relay key lives there
         const int rv = s_row[t * 16 + 4 * g + r];
-        vf[t][r] = rv >= 0 ? p.qkv[(int64_t)rv * 3 * C + 2 * C + h * 16 + c] : 0.f;
+        vf[t][r] = rv >= 0 ? p.qkv[(int64_t)rv * 3 * C + 2 * C + h * 16 + c] + bv : 0.f;
       }
     }
 
@@ -377,7 +395,17 @@ window_attn_kernel_v2(const WinParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = s_row[qt * 16 + 4 * g + r];
-        if (orow >= 0) p.out[(int64_t)orow * C + h * 16 + c] = o[r];
+        if (orow >= 0) {
+          if (p.out_split) {
+            uint16_t* orow16 = reinterpret_cast<uint16_t*>(p.out) + (int64_t)orow * 3 * C + h * 16 + c;
+            const uint16_t hi = att_bf16_rne(o[r]);
+            orow16[0] = hi;
+            orow16[C] = hi;
+            orow16[2 * C] = att_bf16_rne(o[r] - __uint_as_float((uint32_t)hi << 16));
+          } else {
+            p.out[(int64_t)orow * C + h * 16 + c] = o[r];
+          }
+        }
       }
     }
   }
@@ -513,12 +541,20 @@ int hfl_set_variant(const char* key, int value) {
 int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_meta,
                              const float* rpe_table, const hfl_window_attn_desc* d,
                              hfl_stream_t stream) {
+  return hfl_window_attention_fwd_ex(out, qkv, nullptr, tok_meta, rpe_table, d, 0, stream);
+}
+
+int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
+                                const uint32_t* tok_meta, const float* rpe_table,
+                                const hfl_window_attn_desc* d, int out_split3, hfl_stream_t stream) {
   if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
+  if ((qkv_bias != nullptr || out_split3) && g_window_variant != 2) return HFL_EINVAL;
   if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
   if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
   if (d->n_windows == 0) return HFL_OK;
   WinParams p;
-  p.out = out; p.qkv = qkv; p.meta = tok_meta; p.table = rpe_table;
+  p.out = static_cast<float*>(out); p.qkv = qkv; p.meta = tok_meta; p.table = rpe_table;
+  p.qkv_bias = qkv_bias; p.out_split = out_split3;
   p.n_tokens = d->n_tokens; p.rt_row0 = d->rt_row0; p.n_windows = d->n_windows;
   p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd;
   p.batch = d->batch_size; p.scale = d->scale;

@@ -154,7 +154,32 @@ segment_softmax_kernel(float* __restrict__ scores, const int64_t* __restrict__ r
 // ------------------------------------------------------------------ LayerNorm
 // One row = TPR lanes x VPL float4 (C = 4*TPR*VPL); 256-thread blocks, grid-stride over rows.
 // Optional fused residual: xo = x + y (+ bias), h = LN(xo).  Pure streaming (HBM-bound).
-template <int TPR, int VPL, bool ADD>
+// fp32 -> (hi, lo) bf16 with hi = RNE(v), lo = RNE(v - hi): v ~= hi + lo to 2^-17 relative.
+__device__ __forceinline__ uint16_t hfl_bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void hfl_split4(const float4 v, uint2& hi, uint2& lo) {
+  const uint16_t h0 = hfl_bf16_rne(v.x), h1 = hfl_bf16_rne(v.y), h2 = hfl_bf16_rne(v.z), h3 = hfl_bf16_rne(v.w);
+  const uint16_t l0 = hfl_bf16_rne(v.x - __uint_as_float((uint32_t)h0 << 16));
+  const uint16_t l1 = hfl_bf16_rne(v.y - __uint_as_float((uint32_t)h1 << 16));
+  const uint16_t l2 = hfl_bf16_rne(v.z - __uint_as_float((uint32_t)h2 << 16));
+  const uint16_t l3 = hfl_bf16_rne(v.w - __uint_as_float((uint32_t)h3 << 16));
+  hi = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+  lo = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+}
+// row of the split-GEMM A operand: [hi (C) | hi (C) | lo (C)] bf16, so that one bf16 GEMM against
+// [w_hi | w_lo | w_hi] accumulates hi*hi + hi*lo + lo*hi in fp32
+__device__ __forceinline__ void hfl_store_split3(uint16_t* row, int C, int c4, const float4 v) {
+  uint2 hi, lo;
+  hfl_split4(v, hi, lo);
+  reinterpret_cast<uint2*>(row)[c4] = hi;
+  reinterpret_cast<uint2*>(row + C)[c4] = hi;
+  reinterpret_cast<uint2*>(row + 2 * C)[c4] = lo;
+}
+
+template <int TPR, int VPL, bool ADD, bool SPLIT>
 __global__ void __launch_bounds__(256)
 layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const float* __restrict__ y,
                   const float* __restrict__ bias, const float* __restrict__ gamma,
@@ -206,7 +231,10 @@ layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const
         o.y = fmaf(a[v].y * rstd, gm[v].y, bt[v].y);
         o.z = fmaf(a[v].z * rstd, gm[v].z, bt[v].z);
         o.w = fmaf(a[v].w * rstd, gm[v].w, bt[v].w);
-        reinterpret_cast<float4*>(h_out + r * C)[v * TPR + tx] = o;
+        if (SPLIT)
+          hfl_store_split3(reinterpret_cast<uint16_t*>(h_out) + r * 3 * C, C, v * TPR + tx, o);
+        else
+          reinterpret_cast<float4*>(h_out + r * C)[v * TPR + tx] = o;
       }
     }
   }
@@ -214,32 +242,87 @@ layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const
 
 template <int TPR, int VPL>
 static int launch_ln(float* h_out, float* x_out, const float* x, const float* y, const float* bias,
-                     const float* gamma, const float* beta, int64_t n, float eps, hipStream_t s) {
+                     const float* gamma, const float* beta, int64_t n, float eps, int split,
+                     hipStream_t s) {
   constexpr int RPB = 256 / TPR;
   const int64_t need = hfl_cdiv(n, RPB);
   const int64_t cap = (int64_t)hfl_num_cus() * 16;
   const int blocks = (int)(need < cap ? need : cap);
-  if (y != nullptr)
-    layer_norm_kernel<TPR, VPL, true><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
-  else
-    layer_norm_kernel<TPR, VPL, false><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+  if (y != nullptr) {
+    if (split)
+      layer_norm_kernel<TPR, VPL, true, true><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+    else
+      layer_norm_kernel<TPR, VPL, true, false><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+  } else {
+    if (split)
+      layer_norm_kernel<TPR, VPL, false, true><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+    else
+      layer_norm_kernel<TPR, VPL, false, false><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+  }
   HFL_RETURN_LAST_ERROR();
 }
 
 static int dispatch_ln(float* h_out, float* x_out, const float* x, const float* y, const float* bias,
                        const float* gamma, const float* beta, int64_t n, int64_t C, float eps,
-                       hipStream_t s) {
+                       int split, hipStream_t s) {
   if (n == 0) return HFL_OK;
   switch (C) {
-    case 16:   return launch_ln<4, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
-    case 32:   return launch_ln<8, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
-    case 64:   return launch_ln<16, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
-    case 128:  return launch_ln<32, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
-    case 256:  return launch_ln<64, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
-    case 512:  return launch_ln<64, 2>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
-    case 1024: return launch_ln<64, 4>(h_out, x_out, x, y, bias, gamma, beta, n, eps, s);
+    case 16:   return launch_ln<4, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
+    case 32:   return launch_ln<8, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
+    case 64:   return launch_ln<16, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
+    case 128:  return launch_ln<32, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
+    case 256:  return launch_ln<64, 1>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
+    case 512:  return launch_ln<64, 2>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
+    case 1024: return launch_ln<64, 4>(h_out, x_out, x, y, bias, gamma, beta, n, eps, split, s);
     default:   return HFL_EINVAL;
   }
+}
+
+// ---------------------------------------------------------- elementwise producers
+// MODE 0: out_f32 = a + b + bias            (residual add with the fc2 bias folded in)
+// MODE 1: out_bf16x3 = split3(gelu(a + bias))   (exact erf GELU, models/layers/octformer_layers.py:49,55)
+// MODE 2: out_bf16x3 = split3(a)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+eltwise_kernel(void* __restrict__ out, const float* a, const float* b,
+               const float* __restrict__ bias, int64_t n_rows, int C) {
+  const int cv = C / 4;
+  const int64_t total = n_rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c4 = (int)(i % cv);
+    float4 v = reinterpret_cast<const float4*>(a)[i];
+    if (bias != nullptr) {
+      const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    if (MODE == 0) {
+      const float4 w = reinterpret_cast<const float4*>(b)[i];
+      v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      reinterpret_cast<float4*>(out)[i] = v;
+    } else {
+      if (MODE == 1) {
+        const float k = 0.70710678118654752440f;
+        v.x = 0.5f * v.x * (1.0f + erff(v.x * k));
+        v.y = 0.5f * v.y * (1.0f + erff(v.y * k));
+        v.z = 0.5f * v.z * (1.0f + erff(v.z * k));
+        v.w = 0.5f * v.w * (1.0f + erff(v.w * k));
+      }
+      hfl_store_split3(reinterpret_cast<uint16_t*>(out) + r * 3 * C, C, c4, v);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_eltwise(void* out, const float* a, const float* b, const float* bias, int64_t n,
+                          int64_t C, hipStream_t s) {
+  if (n < 0 || C <= 0 || C % 4 != 0) return HFL_EINVAL;
+  if (n == 0) return HFL_OK;
+  const int64_t need = hfl_cdiv(n * (C / 4), 256);
+  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  eltwise_kernel<MODE><<<(int)(need < cap ? need : cap), 256, 0, s>>>(out, a, b, bias, n, (int)C);
+  HFL_RETURN_LAST_ERROR();
 }
 
 }  // namespace
@@ -298,7 +381,7 @@ int hfl_segment_softmax(float* scores, const int64_t* row_off, int batch, int n_
 int hfl_layer_norm(float* out, const float* x, const float* gamma, const float* beta, int64_t n_rows,
                    int64_t channels, float eps, hfl_stream_t stream) {
   if (n_rows < 0) return HFL_EINVAL;
-  return dispatch_ln(out, nullptr, x, nullptr, nullptr, gamma, beta, n_rows, channels, eps,
+  return dispatch_ln(out, nullptr, x, nullptr, nullptr, gamma, beta, n_rows, channels, eps, 0,
                      static_cast<hipStream_t>(stream));
 }
 
@@ -306,8 +389,37 @@ int hfl_add_layer_norm(float* x_out, float* h_out, const float* x, const float* 
                        const float* gamma, const float* beta, int64_t n_rows, int64_t channels,
                        float eps, hfl_stream_t stream) {
   if (n_rows < 0 || y == nullptr || x_out == nullptr) return HFL_EINVAL;
-  return dispatch_ln(h_out, x_out, x, y, bias, gamma, beta, n_rows, channels, eps,
+  return dispatch_ln(h_out, x_out, x, y, bias, gamma, beta, n_rows, channels, eps, 0,
                      static_cast<hipStream_t>(stream));
+}
+
+int hfl_layer_norm_split3(uint16_t* out, const float* x, const float* gamma, const float* beta,
+                          int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream) {
+  if (n_rows < 0) return HFL_EINVAL;
+  return dispatch_ln(reinterpret_cast<float*>(out), nullptr, x, nullptr, nullptr, gamma, beta, n_rows,
+                     channels, eps, 1, static_cast<hipStream_t>(stream));
+}
+
+int hfl_add_layer_norm_split3(float* x_out, uint16_t* h_out, const float* x, const float* y,
+                              const float* bias, const float* gamma, const float* beta, int64_t n_rows,
+                              int64_t channels, float eps, hfl_stream_t stream) {
+  if (n_rows < 0 || y == nullptr || x_out == nullptr) return HFL_EINVAL;
+  return dispatch_ln(reinterpret_cast<float*>(h_out), x_out, x, y, bias, gamma, beta, n_rows, channels,
+                     eps, 1, static_cast<hipStream_t>(stream));
+}
+
+int hfl_add_bias(float* out, const float* x, const float* y, const float* bias, int64_t n_rows,
+                 int64_t channels, hfl_stream_t stream) {
+  return launch_eltwise<0>(out, x, y, bias, n_rows, channels, static_cast<hipStream_t>(stream));
+}
+
+int hfl_bias_gelu_split3(uint16_t* out, const float* x, const float* bias, int64_t n_rows,
+                         int64_t channels, hfl_stream_t stream) {
+  return launch_eltwise<1>(out, x, nullptr, bias, n_rows, channels, static_cast<hipStream_t>(stream));
+}
+
+int hfl_split3(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream) {
+  return launch_eltwise<2>(out, x, nullptr, nullptr, n_rows, channels, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

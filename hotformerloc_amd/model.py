@@ -22,6 +22,8 @@ Only the options the shipped configs use are implemented; anything else raises.
 """
 
 import contextlib
+import os
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -46,6 +48,47 @@ def _add_ln(x, y, m: nn.LayerNorm):
         return ops.add_layer_norm(x, y, m.weight, m.bias, m.eps)
     x = x + y
     return x, F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+
+
+# ---- Linear layers: 'fp32' = hipBLASLt fp32 GEMM; 'bf16x3' = one bf16 GEMM over K-concatenated
+# (hi|hi|lo) x (hi|lo|hi) operands with fp32 accumulation/output (include/hotformerloc_hip.h section 9).
+_GEMM_MODE = os.environ.get('HFL_GEMM', 'bf16x3')
+_W3_CACHE = {}          # id(weight) -> (weakref to weight, version, W3)
+
+
+def set_gemm_mode(mode: str):
+    global _GEMM_MODE
+    assert mode in ('fp32', 'bf16x3')
+    _GEMM_MODE = mode
+
+
+def get_gemm_mode() -> str:
+    return _GEMM_MODE
+
+
+def _split_path(x) -> bool:
+    return _GEMM_MODE == 'bf16x3' and x.is_cuda and not torch.is_grad_enabled()
+
+
+def _w3(lin: nn.Linear):
+    w = lin.weight
+    hit = _W3_CACHE.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        if len(_W3_CACHE) > 4096:                     # drop entries whose weight is gone
+            for k in [k for k, v in _W3_CACHE.items() if v[0]() is None]:
+                del _W3_CACHE[k]
+        hit = (weakref.ref(w), w._version, ops.split_weight(w))
+        _W3_CACHE[id(w)] = hit
+    return hit[2]
+
+
+def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
+    """proj -> +residual -> LN2 -> fc1 -> GELU -> fc2 -> +residual with every bias folded into
+    the element-wise kernel that follows its GEMM."""
+    p = ops.split_mm(attn_out3, _w3(attn.proj))
+    x, h3 = ops.add_layer_norm_split3(x, p, norm2.weight, norm2.bias, norm2.eps, add_bias=attn.proj.bias)
+    g3 = ops.bias_gelu_split3(ops.split_mm(h3, _w3(mlp.fc1)), mlp.fc1.bias)
+    return ops.add_bias(x, ops.split_mm(g3, _w3(mlp.fc2)), mlp.fc2.bias)
 
 
 def _require_layernorm(conv_norm: str):
@@ -188,17 +231,25 @@ class OctreeAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.rpe = RPE(patch_size, num_heads, dilation) if use_rpe else None
 
+    def core(self, qkv, plan: WindowPlan, depth: int, qkv_bias=None, out_split=False):
+        nt = plan.n_tokens[depth]
+        return ops.window_attention(qkv, plan.meta[depth],
+                                    None if self.rpe is None else self.rpe.rpe_table,
+                                    n_tokens=nt, n_windows=plan.n_windows[depth],
+                                    patch_size=self.patch_size, dilation=self.dilation,
+                                    n_relay=self.rt_per_window, n_heads=self.num_heads,
+                                    batch_size=plan.B, rt_row0=nt, depth=depth,
+                                    qkv_bias=qkv_bias, out_split=out_split)
+
     def forward(self, x, plan: WindowPlan, depth: int):
         """x: (N_t [+ W], C) token rows [followed by the relay-token rows]."""
-        nt = plan.n_tokens[depth]
-        qkv = self.qkv(x)
-        out = ops.window_attention(qkv, plan.meta[depth],
-                                   None if self.rpe is None else self.rpe.rpe_table,
-                                   n_tokens=nt, n_windows=plan.n_windows[depth],
-                                   patch_size=self.patch_size, dilation=self.dilation,
-                                   n_relay=self.rt_per_window, n_heads=self.num_heads,
-                                   batch_size=plan.B, rt_row0=nt, depth=depth)
-        return self.proj(out)
+        return self.proj(self.core(self.qkv(x), plan, depth))
+
+    def forward_split(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
+        """LN1 -> qkv -> attention, split-precision path; returns the bf16 operand of `proj`."""
+        a3 = ops.layer_norm_split3(x, norm1.weight, norm1.bias, norm1.eps)
+        return self.core(ops.split_mm(a3, _w3(self.qkv)), plan, depth, qkv_bias=self.qkv.bias,
+                         out_split=True)
 
 
 class OctFormerBlock(nn.Module):
@@ -214,6 +265,9 @@ class OctFormerBlock(nn.Module):
 
     def forward(self, x, plan: WindowPlan, depth: int):
         x = self.cpe(x, plan, depth, residual=True)
+        if _split_path(x):
+            o3 = self.attention.forward_split(x, self.norm1, plan, depth)
+            return _block_tail_split(x, o3, self.attention, self.norm2, self.mlp)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
         return x + self.mlp(h)
 
@@ -255,6 +309,9 @@ class HOTFormerBlock(nn.Module):
             self.cpe(buf[:nt], plan, depth, residual=True, out=new[:nt])
             new[nt:].copy_(buf[nt:])
             buf = new
+        if _split_path(buf):
+            o3 = self.attention.forward_split(buf, self.norm1, plan, depth)
+            return _block_tail_split(buf, o3, self.attention, self.norm2, self.mlp)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
         return buf + self.mlp(h)
 

@@ -176,6 +176,89 @@ def add_layer_norm(x, y, weight, bias, eps: float = 1e-5, add_bias=None, inplace
     return xo.view(x.shape), h.view(x.shape)
 
 
+# ------------------------------------------------------- split-precision Linear path
+def _a3(rows, c, device):
+    return torch.empty((rows, 3 * c), dtype=torch.bfloat16, device=device)
+
+
+def layer_norm_split3(x, weight, bias, eps: float = 1e-5):
+    """A3 = [hi | hi | lo] bf16 of LN(x): the A operand of `split_mm` (header section 9)."""
+    _dev(x, weight, bias)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    out = _a3(x2.shape[0], c, x.device)
+    with _timed('hfl_layer_norm_split3', x2.numel() * 10):
+        check(_native.load().hfl_layer_norm_split3(out.data_ptr(), x2.data_ptr(), weight.data_ptr(),
+                                                   bias.data_ptr(), x2.shape[0], c, float(eps),
+                                                   _stream()), 'hfl_layer_norm_split3')
+    return out
+
+
+def add_layer_norm_split3(x, y, weight, bias, eps: float = 1e-5, add_bias=None):
+    """(x + y [+ add_bias] as fp32, split3(LN(that)))."""
+    _dev(x, y, weight, bias, add_bias)
+    c = x.shape[-1]
+    x2, y2 = _f32c(x).view(-1, c), _f32c(y).view(-1, c)
+    xo = torch.empty_like(x2)
+    h = _a3(x2.shape[0], c, x.device)
+    with _timed('hfl_add_layer_norm_split3', x2.numel() * 18):
+        check(_native.load().hfl_add_layer_norm_split3(
+            xo.data_ptr(), h.data_ptr(), x2.data_ptr(), y2.data_ptr(),
+            None if add_bias is None else add_bias.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+            x2.shape[0], c, float(eps), _stream()), 'hfl_add_layer_norm_split3')
+    return xo.view(x.shape), h
+
+
+def add_bias(x, y, bias=None):
+    """x + y + bias (fp32), one pass."""
+    _dev(x, y, bias)
+    c = x.shape[-1]
+    x2, y2 = _f32c(x).view(-1, c), _f32c(y).view(-1, c)
+    out = torch.empty_like(x2)
+    with _timed('hfl_add_bias', x2.numel() * 12):
+        check(_native.load().hfl_add_bias(out.data_ptr(), x2.data_ptr(), y2.data_ptr(),
+                                          None if bias is None else bias.data_ptr(), x2.shape[0], c,
+                                          _stream()), 'hfl_add_bias')
+    return out.view(x.shape)
+
+
+def bias_gelu_split3(x, bias=None):
+    """split3(gelu(x + bias)) with the exact (erf) GELU."""
+    _dev(x, bias)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    out = _a3(x2.shape[0], c, x.device)
+    with _timed('hfl_bias_gelu_split3', x2.numel() * 10):
+        check(_native.load().hfl_bias_gelu_split3(out.data_ptr(), x2.data_ptr(),
+                                                  None if bias is None else bias.data_ptr(),
+                                                  x2.shape[0], c, _stream()), 'hfl_bias_gelu_split3')
+    return out
+
+
+def split3(x):
+    _dev(x)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    out = _a3(x2.shape[0], c, x.device)
+    check(_native.load().hfl_split3(out.data_ptr(), x2.data_ptr(), x2.shape[0], c, _stream()),
+          'hfl_split3')
+    return out
+
+
+def split_weight(w: torch.Tensor) -> torch.Tensor:
+    """(N, K) fp32 Linear weight -> W3 = [w_hi | w_lo | w_hi] bf16 (N, 3K)."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+def split_mm(a3: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """fp32 (rows, N) = A3 @ W3^T: one hipBLASLt bf16 GEMM, fp32 accumulate and output,
+    computing x_hi w_hi + x_hi w_lo + x_lo w_hi."""
+    return torch.mm(a3, w3.t(), out_dtype=torch.float32)
+
+
 # ------------------------------------------------------------------------- gather
 def octree_gather(data, neigh):
     """(N,C),(M,K) int32 -> (M, K*C): ocnn octree2col with zero fill."""
@@ -194,14 +277,21 @@ def octree_gather(data, neigh):
 # ---------------------------------------------------------------------- attention
 def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, patch_size: int,
                      dilation: int, n_relay: int, n_heads: int, batch_size: int, rt_row0: int = 0,
-                     depth: int = 0):
-    """qkv (rows, 3*H*16) -> out (rows, H*16); see hfl_window_attention_fwd."""
-    _dev(qkv, tok_meta, rpe_table)
+                     depth: int = 0, qkv_bias=None, out_split: bool = False):
+    """qkv (rows, 3*H*16) -> out (rows, H*16) fp32, or with out_split the bf16 [hi|hi|lo]
+    (rows, 3*H*16) operand of the projection GEMM; qkv_bias is added to q,k,v on load.
+    See hfl_window_attention_fwd(_ex)."""
+    _dev(qkv, tok_meta, rpe_table, qkv_bias)
     qkv = _f32c(qkv)
     rows = qkv.shape[0]
     c = n_heads * 16
     assert qkv.shape[1] == 3 * c
-    out = torch.empty((rows, c), dtype=torch.float32, device=qkv.device)
+    if out_split:
+        # rows the kernel does not own (none today) must not hold NaN bit patterns
+        out = torch.zeros((rows, 3 * c), dtype=torch.bfloat16, device=qkv.device) if rows > n_tokens + \
+            (n_windows if n_relay else 0) else torch.empty((rows, 3 * c), dtype=torch.bfloat16, device=qkv.device)
+    else:
+        out = torch.empty((rows, c), dtype=torch.float32, device=qkv.device)
     desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=rt_row0, n_windows=n_windows,
                           patch_size=patch_size, dilation=dilation, n_relay=n_relay,
                           n_heads=n_heads, pos_bnd=int(0.8 * patch_size * dilation ** 0.5),
@@ -216,10 +306,10 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     real_windows = -(-n_tokens // patch_size)
     # algorithmic work: read q,k,v + write out, 16 B per (row, channel); QK^T + PV = 4 L^2 C per window
     with _timed('hfl_window_attention_fwd', used * c * 16 + n_tokens * 8, 4 * seq * seq * c * real_windows):
-        check(_native.load().hfl_window_attention_fwd(out.data_ptr(), qkv.data_ptr(),
-                                                      tok_meta.data_ptr(), table_ptr,
-                                                      ctypes.byref(desc), _stream()),
-              'hfl_window_attention_fwd')
+        check(_native.load().hfl_window_attention_fwd_ex(
+            out.data_ptr(), qkv.data_ptr(), None if qkv_bias is None else _f32c(qkv_bias).data_ptr(),
+            tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), int(bool(out_split)), _stream()),
+            'hfl_window_attention_fwd')
     return out
 
 

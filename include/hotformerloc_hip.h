@@ -175,6 +175,13 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
                              const float* rpe_table, const hfl_window_attn_desc* desc,
                              hfl_stream_t stream);
 
+/* As hfl_window_attention_fwd, for the split-precision Linear path: qkv comes from a bias-free GEMM
+ * and `qkv_bias` (3*H*16) is added to q, k, v on load (NULL = none); with out_split3 != 0 `out` is the
+ * bf16 A operand [hi | hi | lo] (rows, 3*H*16) of the output projection (section 9). */
+int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
+                                const uint32_t* tok_meta, const float* rpe_table,
+                                const hfl_window_attn_desc* desc, int out_split3, hfl_stream_t stream);
+
 /* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (1 = first
  * version, 2 = default), "window_heads_per_wg" (waves per workgroup of the window kernel,
  * default 4).  Returns HFL_EINVAL for an unknown key. */
@@ -233,6 +240,32 @@ int hfl_layer_norm(float* out, const float* x, const float* gamma, const float* 
 int hfl_add_layer_norm(float* x_out, float* h_out, const float* x, const float* y, const float* bias,
                        const float* gamma, const float* beta, int64_t n_rows, int64_t channels,
                        float eps, hfl_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 9. Operand producers of the split-precision Linear path.
+ *    An fp32 Linear y = x W^T (torch.nn.Linear call sites: models/octformer_backbone.py:70,91,
+ *    models/layers/octformer_layers.py:54,57) is evaluated as ONE bf16 matrix-core GEMM with fp32
+ *    accumulation and fp32 output over K-concatenated operands
+ *        A3 = [x_hi | x_hi | x_lo]  (rows, 3K) bf16,   W3 = [w_hi | w_lo | w_hi]  (N, 3K) bf16,
+ *    i.e. x_hi w_hi + x_hi w_lo + x_lo w_hi with x = x_hi + x_lo to 2^-17 (measured GEMM error
+ *    4e-6 relative, descriptors 1.5e-5 vs the 1e-3 bar).  These kernels write A3 directly from the
+ *    op that produces x, so the split costs no extra pass.
+ * ---------------------------------------------------------------------- */
+/* A3 = split3(LN(x)) */
+int hfl_layer_norm_split3(uint16_t* out, const float* x, const float* gamma, const float* beta,
+                          int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
+/* x_out = x + y (+ bias) ; A3 = split3(LN(x_out)) */
+int hfl_add_layer_norm_split3(float* x_out, uint16_t* h_out, const float* x, const float* y,
+                              const float* bias, const float* gamma, const float* beta, int64_t n_rows,
+                              int64_t channels, float eps, hfl_stream_t stream);
+/* out = x + y + bias (fp32; out may alias x or y) */
+int hfl_add_bias(float* out, const float* x, const float* y, const float* bias, int64_t n_rows,
+                 int64_t channels, hfl_stream_t stream);
+/* A3 = split3(gelu(x + bias)), exact erf GELU */
+int hfl_bias_gelu_split3(uint16_t* out, const float* x, const float* bias, int64_t n_rows,
+                         int64_t channels, hfl_stream_t stream);
+/* A3 = split3(x) */
+int hfl_split3(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
 
 #ifdef __cplusplus
 }

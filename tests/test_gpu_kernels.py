@@ -357,3 +357,60 @@ def test_layer_norm_and_fused_add():
     x3 = torch.randn(4, 37, 256, generator=g)
     got = ops.layer_norm(x3.to(DEV), torch.ones(256, device=DEV), torch.zeros(256, device=DEV)).cpu()
     assert torch.allclose(got, torch.nn.functional.layer_norm(x3, (256,)), atol=2e-6, rtol=1e-5)
+
+
+def test_split_precision_linear_path():
+    """bf16 [hi|hi|lo] x [hi|lo|hi] GEMM == fp32 Linear to ~4e-6; producers agree with their fp32 ops."""
+    g = torch.Generator().manual_seed(7)
+
+    def unsplit(a3, c):
+        a3 = a3.float().cpu()
+        assert torch.equal(a3[:, :c], a3[:, c:2 * c])
+        return a3[:, :c] + a3[:, 2 * c:]
+
+    for n, cin, cout in ((3000, 256, 768), (1234, 128, 512), (500, 1024, 256)):
+        x = torch.randn(n, cin, generator=g)
+        w = torch.randn(cout, cin, generator=g) * 0.05
+        a3 = ops.split3(x.to(DEV))
+        assert (unsplit(a3, cin) - x).abs().max() <= x.abs().max() * 2 ** -15
+        y = ops.split_mm(a3, ops.split_weight(w.to(DEV))).cpu().double()
+        ref = x.double() @ w.double().t()
+        assert ((y - ref).norm() / ref.norm()).item() < 2e-5
+    for n, C in ((700, 256), (900, 128)):
+        x = torch.randn(n, C, generator=g) * 2
+        y = torch.randn(n, C, generator=g)
+        w = 1 + 0.1 * torch.randn(C, generator=g)
+        b = 0.1 * torch.randn(C, generator=g)
+        ab = 0.3 * torch.randn(C, generator=g)
+        ln = torch.nn.functional.layer_norm(x, (C,), w, b)
+        got = unsplit(ops.layer_norm_split3(x.to(DEV), w.to(DEV), b.to(DEV)), C)
+        assert (got - ln).abs().max() < 2e-4 * ln.abs().max()
+        xo, h3 = ops.add_layer_norm_split3(x.to(DEV), y.to(DEV), w.to(DEV), b.to(DEV), add_bias=ab.to(DEV))
+        xs = x + y + ab
+        assert torch.allclose(xo.cpu(), xs, atol=1e-6)
+        ln2 = torch.nn.functional.layer_norm(xs, (C,), w, b)
+        assert (unsplit(h3, C) - ln2).abs().max() < 2e-4 * ln2.abs().max()
+        gl = torch.nn.functional.gelu(x + ab)
+        assert (unsplit(ops.bias_gelu_split3(x.to(DEV), ab.to(DEV)), C) - gl).abs().max() < 2e-4 * gl.abs().max()
+        assert torch.allclose(ops.add_bias(x.to(DEV), y.to(DEV), ab.to(DEV)).cpu(), xs, atol=1e-6)
+
+
+def test_window_attention_fused_bias_and_split_output():
+    clouds = [syn.unit_ball_cloud(900 + i, n) for i, n in enumerate([3000, 2000])]
+    params, ref, dev, oplan, plan = _plans(clouds, 'wild-places', 7)
+    K = params.patch_size
+    g = torch.Generator().manual_seed(8)
+    for depth, H, G in ((5, 8, 0), (4, 16, 1)):
+        C = H * 16
+        nt, W = plan.n_tokens[depth], plan.n_windows[depth]
+        rows = nt + (W if G else 0)
+        qkv = torch.randn(rows, 3 * C, generator=g).to(DEV)
+        bias = torch.randn(3 * C, generator=g).to(DEV)
+        table = (torch.randn(3 * (2 * int(0.8 * K) + 1), H, generator=g) * 0.3).to(DEV)
+        want = ops.window_attention(qkv + bias, plan.meta[depth], table, nt, W, K, 1, G, H, 2, rt_row0=nt,
+                                    depth=depth)
+        got3 = ops.window_attention(qkv, plan.meta[depth], table, nt, W, K, 1, G, H, 2, rt_row0=nt,
+                                    depth=depth, qkv_bias=bias, out_split=True).float()
+        assert torch.equal(got3[:, :C], got3[:, C:2 * C])
+        got = got3[:, :C] + got3[:, 2 * C:]
+        assert (got - want).abs().max() < 1e-4 * want.abs().max() + 1e-6

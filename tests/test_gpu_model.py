@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 from hotformerloc_amd import (Octree, Points, merge_octrees, build_batch_octree, load_config,
                               model_factory)
 from hotformerloc_amd import synthetic as syn
+from hotformerloc_amd.model import set_gemm_mode
 from oracle import hotformer_ref
 from oracle.testing import load_case, oracle_octree, synthetic_state_dict
 
@@ -44,8 +45,16 @@ def _rel(a, b):
     return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-12)
 
 
+@pytest.fixture(params=['bf16x3', 'fp32'])
+def gemm_mode(request):
+    """Linear layers as one split-bf16 GEMM (default) or as hipBLASLt fp32 GEMMs."""
+    set_gemm_mode(request.param)
+    yield request.param
+    set_gemm_mode('bf16x3')
+
+
 @pytest.mark.parametrize('case', CASES)
-def test_descriptors_match_reference_golden(golden_dir, case):
+def test_descriptors_match_reference_golden(golden_dir, case, gemm_mode):
     g = load_case(golden_dir, case)
     params, depth = load_config(g['cfg'])
     model = _device_model(params)
@@ -74,14 +83,14 @@ def test_descriptors_match_reference_golden(golden_dir, case):
         head = g['rt_final_%d_head' % d]
         nreal = min(head.shape[0], -(-feats[d].shape[0] // params.patch_size))   # skip padding windows
         report['rt_final_%d' % d] = float(np.abs(rts[d][:nreal].cpu().numpy() - head[:nreal]).max())
-    print(case, report)
+    print(case, gemm_mode, report)
     assert report['descriptor'] <= REL_TOL, report
     assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
 
 
 @pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 4096, 1500, 4096]),
                                                     ('cs-wild-places', 7, [7000, 4096])])
-def test_stage_by_stage_against_oracle(cfg, octree_depth, sizes):
+def test_stage_by_stage_against_oracle(cfg, octree_depth, sizes, gemm_mode):
     """Fresh inputs (not in the fixtures), both weight profiles; oracle run live on the CPU."""
     params, _ = load_config(cfg)
     clouds = syn.make_clouds(77, len(sizes), 4096, params.coordinates)
@@ -104,7 +113,7 @@ def test_stage_by_stage_against_oracle(cfg, octree_depth, sizes):
             nreal = -(-feats[d].shape[0] // params.patch_size)                  # skip padding windows
             errs['rt_final.%d' % d] = (rts[d].cpu()[:nreal] - ocap['rt_final.%d' % d][:nreal]).abs().max().item()
         errs['descriptor'] = float(_rel(y.cpu().numpy(), want).max())
-        print(cfg, profile, errs)
+        print(cfg, profile, gemm_mode, errs)
         assert errs['descriptor'] <= REL_TOL, errs
 
 
