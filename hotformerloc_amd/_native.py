@@ -61,6 +61,12 @@ SIGNATURES = {
     'hfl_add_bias': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_bias_gelu_split3': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_split3': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'hfl_window_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         ctypes.POINTER(WindowAttnDesc), c_void_p]),
+    'hfl_inverse_table': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    'hfl_octree_gather_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    'hfl_relay_token_init_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                         c_int64, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),

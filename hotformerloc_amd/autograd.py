@@ -1,0 +1,143 @@
+"""Autograd glue of the training path: `torch.autograd.Function`s whose forward AND backward are
+HIP kernels (window attention, octree-conv gather, relay-token init; the depth-wise conv lives in
+`hotformerloc_amd.dwconv`), plus differentiable torch formulations of the two tiny ragged ops
+whose backward kernels are not written yet (relay-token attention, attentional pooling).
+
+The reference gets all of this from PyTorch autograd over its materialised masks
+(`models/octformer_backbone.py:59-93`) and from `libs/dwconv/dwconv/nn.py:17-43`."""
+
+import ctypes
+
+import torch
+
+from . import _native, ops
+from ._native import WindowAttnDesc, check
+
+
+def _desc(n_tokens, n_windows, patch_size, dilation, n_relay, n_heads, batch_size, rt_row0, depth):
+    return WindowAttnDesc(n_tokens=n_tokens, rt_row0=rt_row0, n_windows=n_windows,
+                          patch_size=patch_size, dilation=dilation, n_relay=n_relay, n_heads=n_heads,
+                          pos_bnd=int(0.8 * patch_size * dilation ** 0.5), batch_size=batch_size,
+                          scale=16 ** -0.5, depth=depth)
+
+
+class WindowAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, rpe_table, tok_meta, cfg):
+        qkv = qkv.contiguous()
+        out = ops.window_attention(qkv, tok_meta, rpe_table, **cfg)
+        ctx.save_for_backward(qkv, rpe_table if rpe_table is not None else qkv.new_empty(0), tok_meta)
+        ctx.cfg = cfg
+        ctx.has_table = rpe_table is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, table, tok_meta = ctx.saved_tensors
+        cfg = ctx.cfg
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.zeros_like(table) if ctx.has_table else None
+        d = _desc(cfg['n_tokens'], cfg['n_windows'], cfg['patch_size'], cfg['dilation'], cfg['n_relay'],
+                  cfg['n_heads'], cfg['batch_size'], cfg.get('rt_row0', 0), cfg.get('depth', 0))
+        check(_native.load().hfl_window_attention_bwd(
+            dqkv.data_ptr(), dtable.data_ptr() if ctx.has_table else None, qkv.data_ptr(),
+            dout.data_ptr(), tok_meta.data_ptr(), table.data_ptr() if ctx.has_table else None,
+            ctypes.byref(d), ops._stream()), 'hfl_window_attention_bwd')
+        return dqkv, dtable, None, None
+
+
+def window_attention(qkv, rpe_table, tok_meta, **cfg):
+    return WindowAttentionFn.apply(qkv, rpe_table, tok_meta, cfg)
+
+
+_INV_CACHE = {}
+
+
+def _inverse_table(neigh, n_src):
+    key = (neigh.data_ptr(), neigh.shape[0], neigh.shape[1], n_src)
+    hit = _INV_CACHE.get(key)
+    if hit is not None and hit[0]() is neigh:
+        return hit[1]
+    import weakref
+    inv = torch.empty((n_src, neigh.shape[1]), dtype=torch.int32, device=neigh.device)
+    check(_native.load().hfl_inverse_table(inv.data_ptr(), n_src, neigh.data_ptr(), neigh.shape[0],
+                                           neigh.shape[1], ops._stream()), 'hfl_inverse_table')
+    if len(_INV_CACHE) > 64:
+        _INV_CACHE.clear()
+    _INV_CACHE[key] = (weakref.ref(neigh), inv)
+    return inv
+
+
+class OctreeGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, neigh):
+        ctx.save_for_backward(neigh)
+        ctx.n_src, ctx.c = data.shape
+        return ops.octree_gather(data, neigh)
+
+    @staticmethod
+    def backward(ctx, dcol):
+        (neigh,) = ctx.saved_tensors
+        inv = _inverse_table(neigh, ctx.n_src)
+        dcol = dcol.contiguous()
+        ddata = torch.empty((ctx.n_src, ctx.c), dtype=torch.float32, device=dcol.device)
+        check(_native.load().hfl_octree_gather_bwd(ddata.data_ptr(), dcol.data_ptr(), inv.data_ptr(),
+                                                   ctx.n_src, neigh.shape[1], ctx.c, ops._stream()),
+              'hfl_octree_gather_bwd')
+        return ddata, None
+
+
+def octree_gather(data, neigh):
+    return OctreeGatherFn.apply(data, neigh)
+
+
+class RelayTokenInitFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tok_meta, n_windows, patch_size):
+        ctx.save_for_backward(tok_meta)
+        ctx.shape = x.shape
+        ctx.n_windows, ctx.patch_size = n_windows, patch_size
+        return ops.relay_token_init(x, tok_meta, n_windows, patch_size)
+
+    @staticmethod
+    def backward(ctx, drt):
+        (tok_meta,) = ctx.saved_tensors
+        n, c = ctx.shape
+        drt = drt.contiguous()
+        dx = torch.empty((n, c), dtype=torch.float32, device=drt.device)
+        check(_native.load().hfl_relay_token_init_bwd(dx.data_ptr(), drt.data_ptr(), tok_meta.data_ptr(),
+                                                      n, ctx.n_windows, ctx.patch_size, c, ops._stream()),
+              'hfl_relay_token_init_bwd')
+        return dx, None, None, None
+
+
+def relay_token_init(x, tok_meta, n_windows, patch_size):
+    return RelayTokenInitFn.apply(x, tok_meta, n_windows, patch_size)
+
+
+# ------------------------------------------------ differentiable torch forms (GPU, tiny ops)
+def relay_attention_torch(qkv, plan, n_heads: int):
+    """Ragged relay-token attention as padded dense math (training path only): rows of cloud b
+    are gathered to (B, Rmax, ...), masked softmax over the real entries, scattered back."""
+    B, C = plan.B, n_heads * 16
+    idx, valid = plan.relay_pad_index()                       # (B, Rmax) row ids / bool
+    x = qkv[idx.clamp(min=0)]                                 # (B, R, 3C)
+    q, k, v = x.reshape(B, -1, 3, n_heads, 16).permute(2, 0, 3, 1, 4)
+    s = torch.matmul(q, k.transpose(-2, -1)) * (16 ** -0.5)
+    s = s.masked_fill(~valid[:, None, None, :], float('-inf'))
+    s = s.masked_fill(~valid.any(1)[:, None, None, None], 0.0)     # clouds without relay tokens
+    o = torch.matmul(torch.softmax(s, dim=-1), v).transpose(1, 2).reshape(B, -1, C)
+    out = qkv.new_zeros((qkv.shape[0], C))
+    return out.index_put((idx[valid],), o[valid])
+
+
+def attentional_pooling_torch(x, query, plan, depth: int, scale: float):
+    """learned-query pooling over each cloud's tokens (training path): padded dense math."""
+    idx = plan.pad_index[depth]
+    B = plan.B
+    xp = torch.cat([x, x.new_zeros(1, x.shape[1])], 0).index_select(0, idx).view(B, -1, x.shape[1])
+    valid = (idx != x.shape[0]).view(B, -1)
+    s = torch.matmul(query.unsqueeze(0), xp.transpose(1, 2)) * scale          # (B, k, Nmax)
+    s = s.masked_fill(~valid[:, None, :], float('-inf'))
+    return torch.matmul(torch.softmax(s, dim=-1), xp)

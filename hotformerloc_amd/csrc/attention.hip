@@ -593,3 +593,342 @@ int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_row
 }
 
 }  // extern "C"
+
+// ======================================================================================
+// Backward of the windowed attention (training path, SURVEY section 7 "backward obligations").
+// Given dO it recomputes the softmax per (window, head) -- everything of a window lives in one
+// workgroup -- and produces dQ, dK, dV for every token / relay row plus the RPE-table gradient.
+//   P = softmax(S), S = scale q k^T + bias ;  dP = dO V^T ;  D_i = sum_j P_ij dP_ij
+//   dS = P o (dP - D) ;  dQ = scale dS K ;  dK = scale dS^T Q ;  dV = P^T dO ;  dTable[idx] += dS
+// Two register orientations of the same 16x16 score tile are used so that every contraction is
+// an MFMA whose operands already sit in lanes: "A" (key rows, query columns: a lane owns a query;
+// softmax statistics, dQ, table gradient) and "B" (query rows, key columns: dK, dV).
+// Q, K, V, dO of the wave's head are staged once in LDS; the table gradient is accumulated in LDS
+// by the persistent workgroup and flushed with one global atomic pass.
+namespace {
+
+struct WinBwdParams {
+  float* dqkv;            // (rows, 3*H*16)
+  float* dtable;          // (3*nrpe, H), accumulated (zero it before the launch)
+  const float* qkv;       // (rows, 3*H*16), bias included
+  const float* dout;      // (rows, H*16)
+  const uint32_t* meta;
+  const float* table;
+  int64_t n_tokens;
+  int64_t rt_row0;
+  int n_windows, K, D, H, bnd, batch;
+  float scale;
+};
+
+template <int T, int G>
+__global__ void __launch_bounds__(128)
+window_attn_bwd_kernel(const WinBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LP = T * 16;
+  constexpr int TW = T - G;
+  constexpr int NHW = 2;                          // heads (waves) per workgroup
+  constexpr float kLog2e = 1.4426950408889634f;
+  const int H = p.H, K = p.K;
+  const int C = H * 16;
+  const int nrpe = 2 * p.bnd + 1;
+  // LDS carve (per workgroup)
+  int4* s_key = reinterpret_cast<int4*>(smem);                          // [LP]
+  int4* s_qry = s_key + LP;                                             // [LP]
+  int* s_row = reinterpret_cast<int*>(s_qry + LP);                      // [LP]
+  float* s_tile = reinterpret_cast<float*>(s_row + LP);                 // [NHW][4][LP][16]  Q,K,V,dO
+  float* s_stat = s_tile + NHW * 4 * LP * 16;                           // [NHW][3][LP]      m, 1/l, D
+  float* s_tab = s_stat + NHW * 3 * LP;                                 // [NHW][3*nrpe] * log2e
+  float* s_dtab = s_tab + NHW * 3 * nrpe;                               // [NHW][3*nrpe]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, hw = tid >> 6;
+  const int h = blockIdx.y * NHW + hw;
+  const int c = lane & 15, g = lane >> 4;
+  const bool rpe = p.table != nullptr;
+
+  if (rpe)
+    for (int i = tid; i < 3 * nrpe * NHW; i += blockDim.x) {
+      const int r = i / NHW, hh = i % NHW;
+      s_tab[hh * 3 * nrpe + r] = p.table[r * H + blockIdx.y * NHW + hh] * kLog2e;
+      s_dtab[hh * 3 * nrpe + r] = 0.f;
+    }
+  float* tq = s_tile + (hw * 4 + 0) * LP * 16;
+  float* tk = s_tile + (hw * 4 + 1) * LP * 16;
+  float* tv = s_tile + (hw * 4 + 2) * LP * 16;
+  float* td = s_tile + (hw * 4 + 3) * LP * 16;
+  float* st_m = s_stat + (hw * 3 + 0) * LP;
+  float* st_il = s_stat + (hw * 3 + 1) * LP;
+  float* st_d = s_stat + (hw * 3 + 2) * LP;
+  const float* tabx = s_tab + hw * 3 * nrpe;
+  float* dtabx = s_dtab + hw * 3 * nrpe;
+  const int hi4 = 8 * p.bnd;
+  const float scale2 = p.scale * kLog2e;
+  const float mask2 = kMaskValue * kLog2e;
+
+  // bias of score (key position kj, query position qi) in the exp2 domain; returns table offsets
+  auto bias_of = [&](const int4 k, const int4 q, bool use_rpe, int& ox, int& oy, int& oz) -> float {
+    float b = 0.f;
+    ox = oy = oz = -1;
+    if (use_rpe) {
+      ox = min(max(q.x + k.x, 0), hi4) >> 2;
+      oy = (min(max(q.y + k.y, 0), hi4) >> 2) + nrpe;
+      oz = (min(max(q.z + k.z, 0), hi4) >> 2) + 2 * nrpe;
+      b = (tabx[ox] + tabx[oy]) + tabx[oz];
+    }
+    if (k.w != q.w) b += mask2;
+    return b;
+  };
+
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
+    __syncthreads();
+    for (int j = tid; j < LP; j += blockDim.x) {
+      int bid = -1, row = -1, x = 0, y = 0, z = 0;
+      if (j < K) {
+        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
+                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
+        if (t < p.n_tokens) {
+          const uint32_t xyz = p.meta[2 * t];
+          x = (int)(xyz & 1023u); y = (int)((xyz >> 10) & 1023u); z = (int)(xyz >> 20);
+          bid = (int)p.meta[2 * t + 1];
+          row = (int)t;
+        }
+      } else if (G > 0 && j == K) {
+        const int64_t t0 = (int64_t)w * K;
+        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
+        row = (int)(p.rt_row0 + w);
+      }
+      s_key[j] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), bid);
+      s_qry[j] = make_int4(4 * x, 4 * y, 4 * z, row >= 0 ? bid : -2);
+      s_row[j] = row;
+    }
+    __syncthreads();
+    // stage Q, K, V, dO of this head: LP rows x 4 float4 each, one wave
+    for (int i = lane; i < LP * 4; i += 64) {
+      const int j = i >> 2, f = i & 3;
+      const int row = s_row[j];
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, v4 = q4, d4 = q4;
+      if (row >= 0) {
+        const float* base = p.qkv + (int64_t)row * 3 * C + h * 16 + 4 * f;
+        q4 = *reinterpret_cast<const float4*>(base);
+        k4 = *reinterpret_cast<const float4*>(base + C);
+        v4 = *reinterpret_cast<const float4*>(base + 2 * C);
+        d4 = *reinterpret_cast<const float4*>(p.dout + (int64_t)row * C + h * 16 + 4 * f);
+      }
+      reinterpret_cast<float4*>(tq)[i] = q4;
+      reinterpret_cast<float4*>(tk)[i] = k4;
+      reinterpret_cast<float4*>(tv)[i] = v4;
+      reinterpret_cast<float4*>(td)[i] = d4;
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before it reads them
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------- pass 1, orientation A: statistics, dQ, table gradient ----------------
+#pragma unroll 1
+    for (int qt = 0; qt < T; ++qt) {
+      const int qi = qt * 16 + c;
+      const int4 q = s_qry[qi];
+      const bool q_rpe = rpe && !(G > 0 && qt == T - 1);
+      const float4 qf = reinterpret_cast<const float4*>(tq)[qi * 4 + g];
+      const float4 df = reinterpret_cast<const float4*>(td)[qi * 4 + g];
+      f32x4 s[T], dp[T];
+      int off[T][4][3];
+      float mx = kDeadValue;
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+        const float4 kf = reinterpret_cast<const float4*>(tk)[(kt * 16 + c) * 4 + g];
+        const float4 vf4 = reinterpret_cast<const float4*>(tv)[(kt * 16 + c) * 4 + g];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, acc, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4.x, df.x, acd, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4.y, df.y, acd, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4.z, df.z, acd, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(vf4.w, df.w, acd, 0, 0, 0);
+        dp[kt] = acd;
+        const bool t_rpe = q_rpe && kt < TW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int4 k = s_key[kt * 16 + 4 * g + r];
+          const float v = acc[r] * scale2 + bias_of(k, q, t_rpe, off[kt][r][0], off[kt][r][1], off[kt][r][2]);
+          acc[r] = v;
+          mx = fmaxf(mx, v);
+        }
+        s[kt] = acc;
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+          s[kt][r] = e;
+          sum += e;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.0f / sum;
+      float dsum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[kt][r] *= inv;                        // P
+          dsum += s[kt][r] * dp[kt][r];
+        }
+      dsum += __shfl_xor(dsum, 16, 64);
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (g == 0) {
+        st_m[qi] = mx;
+        st_il[qi] = inv;
+        st_d[qi] = dsum;
+      }
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = s[kt][r] * (dp[kt][r] - dsum);
+          if (off[kt][r][0] >= 0 && q.w >= 0) {
+            atomicAdd(dtabx + off[kt][r][0], ds);
+            atomicAdd(dtabx + off[kt][r][1], ds);
+            atomicAdd(dtabx + off[kt][r][2], ds);
+          }
+          // dQ^T[d][query] += K[key][d] * dS[key][query]  (A = K in (k-slot g, d = c) layout)
+          dq = __builtin_amdgcn_mfma_f32_16x16x4f32(tk[(kt * 16 + 4 * g + r) * 16 + c], ds, dq, 0, 0, 0);
+        }
+      const int qrow = s_row[qi];
+      if (qrow >= 0)
+        *reinterpret_cast<float4*>(p.dqkv + (int64_t)qrow * 3 * C + h * 16 + 4 * g) =
+            make_float4(dq[0] * p.scale, dq[1] * p.scale, dq[2] * p.scale, dq[3] * p.scale);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---------------- pass 2, orientation B: dK, dV -----------------------------------------
+    f32x4 dk[T], dv[T];
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      dk[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < T; ++qt) {
+      const float4 qf = reinterpret_cast<const float4*>(tq)[(qt * 16 + c) * 4 + g];
+      const float4 df = reinterpret_cast<const float4*>(td)[(qt * 16 + c) * 4 + g];
+      const bool q_rpe = rpe && !(G > 0 && qt == T - 1);
+      int4 qm[4];
+      float m_i[4], il_i[4], d_i[4], qv[4], dov[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qt * 16 + 4 * g + r;
+        qm[r] = s_qry[qi];
+        m_i[r] = st_m[qi];
+        il_i[r] = st_il[qi];
+        d_i[r] = st_d[qi];
+        qv[r] = tq[qi * 16 + c];        // Q[query 4g+r][d = c]
+        dov[r] = td[qi * 16 + c];       // dO[query 4g+r][d = c]
+      }
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+        const float4 kf = reinterpret_cast<const float4*>(tk)[(kt * 16 + c) * 4 + g];
+        const float4 vf4 = reinterpret_cast<const float4*>(tv)[(kt * 16 + c) * 4 + g];
+        const int4 k = s_key[kt * 16 + c];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.x, kf.x, acc, 0, 0, 0);   // (query 4g+r, key c)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.y, kf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.z, kf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf.w, kf.w, acc, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(df.x, vf4.x, acd, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(df.y, vf4.y, acd, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(df.z, vf4.z, acd, 0, 0, 0);
+        acd = __builtin_amdgcn_mfma_f32_16x16x4f32(df.w, vf4.w, acd, 0, 0, 0);
+        const bool t_rpe = q_rpe && kt < TW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int o0, o1, o2;
+          const float v = acc[r] * scale2 + bias_of(k, qm[r], t_rpe, o0, o1, o2);
+          const float pb = __builtin_amdgcn_exp2f(v - m_i[r]) * il_i[r];
+          const float ds = pb * (acd[r] - d_i[r]);
+          // dV^T[d][key c] += dO[query][d] * P[query][key] ; dK^T[d][key c] += Q[query][d] * dS[query][key]
+          dv[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dov[r], pb, dv[kt], 0, 0, 0);
+          dk[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[r], ds, dk[kt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      const int krow = s_row[kt * 16 + c];
+      if (krow >= 0) {
+        float* base = p.dqkv + (int64_t)krow * 3 * C + h * 16 + 4 * g;
+        *reinterpret_cast<float4*>(base + C) =
+            make_float4(dk[kt][0] * p.scale, dk[kt][1] * p.scale, dk[kt][2] * p.scale, dk[kt][3] * p.scale);
+        *reinterpret_cast<float4*>(base + 2 * C) = make_float4(dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3]);
+      }
+    }
+  }
+  __syncthreads();
+  if (rpe && p.dtable != nullptr)
+    for (int i = tid; i < 3 * nrpe * NHW; i += blockDim.x) {
+      const int r = i / NHW, hh = i % NHW;
+      const float v = s_dtab[hh * 3 * nrpe + r];
+      if (v != 0.f) atomicAdd(p.dtable + r * H + blockIdx.y * NHW + hh, v);
+    }
+}
+
+template <int T, int G>
+static int launch_window_bwd(const WinBwdParams& p, hipStream_t s) {
+  constexpr int LP = T * 16;
+  constexpr int NHW = 2;
+  const int nrpe = 2 * p.bnd + 1;
+  const size_t lds = (size_t)LP * (16 + 16 + 4) + (size_t)NHW * 4 * LP * 16 * 4 + (size_t)NHW * 3 * LP * 4 +
+                     (p.table ? (size_t)2 * NHW * 3 * nrpe * 4 : 0);
+  if (p.H % NHW != 0) return HFL_EINVAL;
+  int bx = p.n_windows;
+  const int capx = hfl_num_cus() * 8 / (p.H / NHW) + 1;
+  if (bx > capx) bx = capx;
+  dim3 grid((unsigned)bx, (unsigned)(p.H / NHW));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel<T, G>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  window_attn_bwd_kernel<T, G><<<grid, NHW * 64, lds, s>>>(p);
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // namespace
+
+extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv,
+                                        const float* dout, const uint32_t* tok_meta,
+                                        const float* rpe_table, const hfl_window_attn_desc* d,
+                                        hfl_stream_t stream) {
+  if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
+  if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
+  if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
+  if (d->n_windows == 0) return HFL_OK;
+  WinBwdParams p;
+  p.dqkv = dqkv; p.dtable = drpe_table; p.qkv = qkv; p.dout = dout; p.meta = tok_meta; p.table = rpe_table;
+  p.n_tokens = d->n_tokens; p.rt_row0 = d->rt_row0; p.n_windows = d->n_windows;
+  p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd; p.batch = d->batch_size;
+  p.scale = d->scale;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int T = d->patch_size / 16 + d->n_relay;
+  if (d->n_relay == 0) {
+    switch (T) {
+      case 1: return launch_window_bwd<1, 0>(p, s);
+      case 2: return launch_window_bwd<2, 0>(p, s);
+      case 3: return launch_window_bwd<3, 0>(p, s);
+      case 4: return launch_window_bwd<4, 0>(p, s);
+      default: return HFL_EINVAL;
+    }
+  }
+  switch (T) {
+    case 2: return launch_window_bwd<2, 1>(p, s);
+    case 3: return launch_window_bwd<3, 1>(p, s);
+    case 4: return launch_window_bwd<4, 1>(p, s);
+    case 5: return launch_window_bwd<5, 1>(p, s);
+    default: return HFL_EINVAL;
+  }
+}

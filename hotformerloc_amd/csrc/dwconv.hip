@@ -371,4 +371,17 @@ int hfl_cpe_forward(float* out, const float* x, const float* weight, const float
   }
 }
 
+int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table, int64_t n_dst_rows,
+                      int kngh, hfl_stream_t stream) {
+  if (n_src_rows < 0 || n_dst_rows < 0 || kngh <= 0) return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(inverse, 0xFF, (size_t)n_src_rows * kngh * sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  if (n_dst_rows == 0) return HFL_OK;
+  const int64_t need = hfl_cdiv(n_dst_rows * kngh, 256);
+  const int blocks = (int)(need < 4096 ? need : 4096);
+  inverse_neigh_kernel<int32_t><<<blocks, 256, 0, s>>>(inverse, table, n_dst_rows, kngh);
+  HFL_RETURN_LAST_ERROR();
+}
+
 }  // extern "C"

@@ -28,6 +28,78 @@ __global__ void gather_kernel(float* __restrict__ out, const float* __restrict__
   }
 }
 
+
+// ------------------------------------------------- backward of the octree-conv gather
+// dcol (M, K*C) -> ddata (N, C):  ddata[n, c] = sum_k [ineigh[n,k] >= 0] dcol[ineigh[n,k], k*C + c]
+// (the scatter-add of octree2col turned into a gather through the inverse table, which is
+//  injective per column: no atomics, bitwise reproducible)
+__global__ void gather_bwd_kernel(float* __restrict__ ddata, const float* __restrict__ dcol,
+                                  const int32_t* __restrict__ ineigh, int64_t n_rows, int K, int C) {
+  const int cv = C / 4;
+  const int64_t total = n_rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / cv;
+    const int c = (int)(i % cv);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      const int32_t m = ineigh[n * K + k];
+      if (m >= 0) {
+        const float4 v = reinterpret_cast<const float4*>(dcol + ((int64_t)m * K + k) * C)[c];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    reinterpret_cast<float4*>(ddata + n * C)[c] = acc;
+  }
+}
+
+__global__ void gather_bwd_scalar_kernel(float* __restrict__ ddata, const float* __restrict__ dcol,
+                                         const int32_t* __restrict__ ineigh, int64_t n_rows, int K, int C) {
+  const int64_t total = n_rows * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / C;
+    const int c = (int)(i % C);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int32_t m = ineigh[n * K + k];
+      if (m >= 0) acc += dcol[((int64_t)m * K + k) * C + c];
+    }
+    ddata[i] = acc;
+  }
+}
+
+// backward of relay-token init: dx[t] = drt[window(t)] / count(window) for the owner's tokens, else 0
+__global__ void relay_init_bwd_kernel(float* __restrict__ dx, const float* __restrict__ drt,
+                                      const uint32_t* __restrict__ meta, int64_t n_tokens,
+                                      int32_t n_windows, int K, int C) {
+  const int cv = C / 4;
+  const int c = threadIdx.x;
+  for (int w = blockIdx.x; w < n_windows; w += gridDim.x) {
+    const int64_t t0 = (int64_t)w * K;
+    if (t0 >= n_tokens) continue;
+    const uint32_t owner = meta[2 * t0 + 1];
+    int cnt = 0;
+    for (int k = 0; k < K; ++k) {
+      const int64_t t = t0 + k;
+      if (t >= n_tokens || meta[2 * t + 1] != owner) break;
+      ++cnt;
+    }
+    float4 gsc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cv) {
+      const float4 gr = reinterpret_cast<const float4*>(drt + (int64_t)w * C)[c];
+      const float n = (float)cnt;
+      gsc = make_float4(gr.x / n, gr.y / n, gr.z / n, gr.w / n);
+    }
+    for (int k = 0; k < K; ++k) {
+      const int64_t t = t0 + k;
+      if (t >= n_tokens) break;
+      if (c < cv)
+        reinterpret_cast<float4*>(dx + t * C)[c] = k < cnt ? gsc : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
 // --------------------------------------------------------------- relay tokens
 // one block per window; thread c4 owns 4 channels; owner = batch id of first token
 __global__ void relay_init_kernel(float* __restrict__ rt, const float* __restrict__ x,
@@ -420,6 +492,37 @@ int hfl_bias_gelu_split3(uint16_t* out, const float* x, const float* bias, int64
 
 int hfl_split3(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream) {
   return launch_eltwise<2>(out, x, nullptr, nullptr, n_rows, channels, static_cast<hipStream_t>(stream));
+}
+
+int hfl_octree_gather_bwd(float* ddata, const float* dcol, const int32_t* ineigh, int64_t n_rows,
+                          int kngh, int64_t channels, hfl_stream_t stream) {
+  if (n_rows < 0 || kngh <= 0 || channels <= 0) return HFL_EINVAL;
+  if (n_rows == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  if (channels % 4 == 0) {
+    const int64_t need = hfl_cdiv(n_rows * (channels / 4), 256);
+    gather_bwd_kernel<<<(int)(need < cap ? need : cap), 256, 0, s>>>(ddata, dcol, ineigh, n_rows, kngh,
+                                                                     (int)channels);
+  } else {
+    const int64_t need = hfl_cdiv(n_rows * channels, 256);
+    gather_bwd_scalar_kernel<<<(int)(need < cap ? need : cap), 256, 0, s>>>(ddata, dcol, ineigh, n_rows,
+                                                                            kngh, (int)channels);
+  }
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_relay_token_init_bwd(float* dx, const float* drt, const uint32_t* tok_meta, int64_t n_tokens,
+                             int32_t n_windows, int32_t patch_size, int64_t channels,
+                             hfl_stream_t stream) {
+  if (n_windows < 0 || patch_size <= 0 || channels <= 0 || channels % 4 != 0 || channels > 4096)
+    return HFL_EINVAL;
+  if (n_windows == 0) return HFL_OK;
+  int threads = (int)(channels / 4);
+  threads = ((threads + 63) / 64) * 64;
+  relay_init_bwd_kernel<<<n_windows, threads, 0, static_cast<hipStream_t>(stream)>>>(
+      dx, drt, tok_meta, n_tokens, n_windows, patch_size, (int)channels);
+  HFL_RETURN_LAST_ERROR();
 }
 
 }  // extern "C"

@@ -30,21 +30,28 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import autograd as ag
+from . import dwconv as hdw
 from . import ops
 from .plan import WindowPlan
 
 
+def _grad_path(x) -> bool:
+    """True when autograd must see the op (training / fine-tuning): route through the
+    autograd Functions instead of the fused inference kernels."""
+    return torch.is_grad_enabled()
+
+
 def _ln(x, m: nn.LayerNorm):
     """LayerNorm over channels: HIP kernel in inference, torch (autograd) when grads are needed."""
-    if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad)):
+    if x.is_cuda and not _grad_path(x):
         return ops.layer_norm(x, m.weight, m.bias, m.eps)
     return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
 
 
 def _add_ln(x, y, m: nn.LayerNorm):
     """(x + y, LN(x + y)): one fused pass in inference."""
-    if x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad
-                                                       or m.weight.requires_grad)):
+    if x.is_cuda and not _grad_path(x):
         return ops.add_layer_norm(x, y, m.weight, m.bias, m.eps)
     x = x + y
     return x, F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
@@ -116,7 +123,7 @@ class OctreeConv(nn.Module):
 
     def forward(self, data: torch.Tensor, octree, depth: int):
         neigh = octree.get_neigh(depth, self.kernel, self.stride, nempty=True)
-        col = ops.octree_gather(data, neigh)
+        col = ag.octree_gather(data, neigh) if _grad_path(data) else ops.octree_gather(data, neigh)
         w = self.weights.reshape(self.kdim * self.in_channels, self.out_channels)
         if self.bias is not None:
             return torch.addmm(self.bias, col, w)
@@ -202,6 +209,10 @@ class CPE(nn.Module):
         self.norm = nn.LayerNorm(dim)
 
     def forward(self, data, plan: WindowPlan, depth: int, residual: bool, out=None):
+        if _grad_path(data):      # dwconv (HIP fwd/bwd, libs/dwconv semantics) -> LayerNorm -> residual
+            y = hdw.octree_dwconv(data, self.conv.weights, plan.neigh(depth))
+            y = F.layer_norm(y, self.norm.normalized_shape, self.norm.weight, self.norm.bias, self.norm.eps)
+            return data + y if residual else y
         return ops.cpe_forward(data, self.conv.weights, self.norm.weight, self.norm.bias,
                                plan.neigh(depth), residual, self.norm.eps, out=out)
 
@@ -233,13 +244,14 @@ class OctreeAttention(nn.Module):
 
     def core(self, qkv, plan: WindowPlan, depth: int, qkv_bias=None, out_split=False):
         nt = plan.n_tokens[depth]
-        return ops.window_attention(qkv, plan.meta[depth],
-                                    None if self.rpe is None else self.rpe.rpe_table,
-                                    n_tokens=nt, n_windows=plan.n_windows[depth],
-                                    patch_size=self.patch_size, dilation=self.dilation,
-                                    n_relay=self.rt_per_window, n_heads=self.num_heads,
-                                    batch_size=plan.B, rt_row0=nt, depth=depth,
-                                    qkv_bias=qkv_bias, out_split=out_split)
+        cfg = dict(n_tokens=nt, n_windows=plan.n_windows[depth], patch_size=self.patch_size,
+                   dilation=self.dilation, n_relay=self.rt_per_window, n_heads=self.num_heads,
+                   batch_size=plan.B, rt_row0=nt, depth=depth)
+        table = None if self.rpe is None else self.rpe.rpe_table
+        if _grad_path(qkv):
+            return ag.window_attention(qkv, table, plan.meta[depth], **cfg)
+        return ops.window_attention(qkv, plan.meta[depth], table, qkv_bias=qkv_bias,
+                                    out_split=out_split, **cfg)
 
     def forward(self, x, plan: WindowPlan, depth: int):
         """x: (N_t [+ W], C) token rows [followed by the relay-token rows]."""
@@ -302,7 +314,7 @@ class HOTFormerBlock(nn.Module):
 
     def forward(self, buf, plan: WindowPlan, depth: int):
         nt = plan.n_tokens[depth]
-        if torch.is_grad_enabled() and buf.requires_grad:
+        if _grad_path(buf):
             buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:]], 0)
         else:                                   # CPE writes straight into the new buffer's token rows
             new = torch.empty_like(buf)
@@ -326,7 +338,10 @@ class RTAttention(nn.Module):
         self.proj = nn.Linear(dim, dim)
 
     def forward(self, rt, plan: WindowPlan):
-        out = ops.relay_attention(self.qkv(rt), plan.seq_rows, plan.seq_off, plan.B, self.num_heads,
+        qkv = self.qkv(rt)
+        if _grad_path(qkv):
+            return self.proj(ag.relay_attention_torch(qkv, plan, self.num_heads))
+        out = ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, self.num_heads,
                                   plan.max_seq_len)
         return self.proj(out)
 
@@ -359,6 +374,8 @@ class RelayTokenInitialiser(nn.Module):
     def forward(self, x, plan: WindowPlan, depth: int):
         if self.use_cpe:
             x = self.cpe(x, plan, depth, residual=False)
+        if _grad_path(x):
+            return ag.relay_token_init(x, plan.meta[depth], plan.n_windows[depth], self.patch_size)
         return ops.relay_token_init(x, plan.meta[depth], plan.n_windows[depth], self.patch_size)
 
 
@@ -421,7 +438,7 @@ class HOTFormerStage(nn.Module):
             for d, nt in zip(depths, nts):
                 off = plan.rt_offset[d]
                 new_rt = rt_all[off:off + plan.n_windows[d]]
-                if torch.is_grad_enabled() and bufs[d].requires_grad:
+                if _grad_path(new_rt):
                     bufs[d] = torch.cat([bufs[d][:nt], new_rt], 0)
                 else:                              # only the relay rows move; tokens stay in place
                     bufs[d][nt:].copy_(new_rt)
@@ -507,6 +524,8 @@ class AdaptivePooling(nn.Module):
 
     def forward(self, x, plan: WindowPlan, depth: int):
         """x (N_t, C) ragged over clouds -> (B, k, C)."""
+        if _grad_path(x):
+            return ag.attentional_pooling_torch(x, self.query, plan, depth, self.scale)
         scores = torch.mm(x, self.query.t())                              # (N_t, k)
         ops.segment_softmax_(scores, plan.cloud_off[depth], plan.B, self.scale)
         idx = plan.pad_index[depth]

@@ -127,5 +127,19 @@ class WindowPlan:
                 self.window_stats[d] = ops.window_stats(self.meta[d], self.n_tokens[d],
                                                         self.n_windows[d], self.K, d)
 
+    def relay_pad_index(self):
+        """(B, Rmax) row index of each cloud's relay-token sequence (-1 = padding) and its validity
+        mask, for the dense training-path formulation of relay attention."""
+        if getattr(self, '_relay_pad', None) is None:
+            off = self.layout['seq_off']
+            rmax = max(int(np.diff(off).max()), 1)
+            idx = np.full((self.B, rmax), -1, dtype=np.int64)
+            for b in range(self.B):
+                rows = self.layout['seq_rows'][off[b]:off[b + 1]]
+                idx[b, :len(rows)] = rows
+            t = torch.from_numpy(idx).to(self.device)
+            self._relay_pad = (t, t >= 0)
+        return self._relay_pad
+
     def neigh(self, depth: int):
         return self.octree.get_neigh(depth, '333', 1, nempty=True)

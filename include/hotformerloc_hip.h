@@ -267,6 +267,30 @@ int hfl_bias_gelu_split3(uint16_t* out, const float* x, const float* bias, int64
 /* A3 = split3(x) */
 int hfl_split3(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * 10. Backward kernels (training path; autograd glue in hotformerloc_amd/autograd.py).
+ *     The reference gets these from PyTorch autograd over its materialised formulation and from
+ *     dwconv.cu for the depth-wise conv (section 1 already covers dwconv's two gradients).
+ * ---------------------------------------------------------------------- */
+/* Gradient of hfl_window_attention_fwd.  dout (rows, H*16) -> dqkv (rows, 3*H*16), fully written for
+ * every token and relay row; drpe_table (3*(2*pos_bnd+1), H) is ACCUMULATED into (zero it first; float
+ * atomics, so its low bits are not run-to-run reproducible) and may be NULL when rpe_table is NULL. */
+int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
+                             const uint32_t* tok_meta, const float* rpe_table,
+                             const hfl_window_attn_desc* desc, hfl_stream_t stream);
+/* Inverse of a gather table whose source and destination row counts differ (stride-2 conv:
+ * table (n_dst, K) with entries in [0, n_src)): inverse (n_src, K), inverse[table[m,k], k] = m, -1 else. */
+int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table, int64_t n_dst_rows,
+                      int kngh, hfl_stream_t stream);
+/* Gradient of hfl_octree_gather w.r.t. data through the INVERSE table (hfl_inverse_neigh of the
+ * forward table, int32): ddata[n,c] = sum_k dcol[ineigh[n,k], k*C + c]. */
+int hfl_octree_gather_bwd(float* ddata, const float* dcol, const int32_t* ineigh, int64_t n_rows,
+                          int kngh, int64_t channels, hfl_stream_t stream);
+/* Gradient of hfl_relay_token_init: dx (N_t,C) fully written. */
+int hfl_relay_token_init_bwd(float* dx, const float* drt, const uint32_t* tok_meta, int64_t n_tokens,
+                             int32_t n_windows, int32_t patch_size, int64_t channels,
+                             hfl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -324,8 +324,7 @@ def pyramid_attn_pool_mixer(feats: Dict[int, torch.Tensor], sd, p, plan, k_token
 
 
 # ---------------------------------------------------------------------- forward
-@torch.no_grad()
-def forward(sd: Dict[str, torch.Tensor], params, octree, capture: Optional[dict] = None):
+def forward_with_grad(sd: Dict[str, torch.Tensor], params, octree, capture: Optional[dict] = None):
     """models/hotformerloc.py:33-59 -> hotformerloc_backbone.py:702-723,574-635.
 
     sd:      state_dict (CPU fp32) with the reference's key names
@@ -403,3 +402,9 @@ def forward(sd: Dict[str, torch.Tensor], params, octree, capture: Optional[dict]
     if params.normalize_embeddings:
         y = F.normalize(y, dim=1)
     return y
+
+
+@torch.no_grad()
+def forward(sd: Dict[str, torch.Tensor], params, octree, capture: Optional[dict] = None):
+    """Inference forward (no autograd graph); see :func:`forward_with_grad` for the body."""
+    return forward_with_grad(sd, params, octree, capture)

@@ -414,3 +414,90 @@ def test_window_attention_fused_bias_and_split_output():
         assert torch.equal(got3[:, :C], got3[:, C:2 * C])
         got = got3[:, :C] + got3[:, 2 * C:]
         assert (got - want).abs().max() < 1e-4 * want.abs().max() + 1e-6
+
+
+def test_window_attention_backward_matches_autograd():
+    """dQ, dK, dV and the RPE-table gradient of the HIP backward against torch autograd over the
+    oracle's materialised formulation (both window kinds, dilation, relay token)."""
+    from hotformerloc_amd import autograd as ag
+    clouds = [syn.unit_ball_cloud(1200 + i, n) for i, n in enumerate([3000, 40, 2200])]
+    for cfg in ('wild-places', 'cs-wild-places'):
+        params, ref, dev, oplan, plan = _plans(clouds, cfg, 7)
+        K, D = params.patch_size, params.dilation
+        g = torch.Generator().manual_seed(9)
+        B = len(clouds)
+        for depth, H, G, dil in ((5, 8, 0, 1), (5, 8, 0, D), (4, 16, 1, 1), (2, 16, 1, 1)):
+            C = H * 16
+            nt, W = plan.n_tokens[depth], plan.n_windows[depth]
+            qkv_tok = torch.randn(nt, 3 * C, generator=g, requires_grad=True)
+            qkv_rt = torch.randn(W, 3 * C, generator=g, requires_grad=True)
+            bnd = int(0.8 * K * dil ** 0.5)
+            table = (torch.randn(3 * (2 * bnd + 1), H, generator=g) * 0.5).requires_grad_()
+            xw = oplan.to_windows(qkv_tok, depth, dil > 1)
+            if G:
+                xw = torch.cat([qkv_rt.unsqueeze(1), xw], 1)
+            q, k, v = xw.reshape(-1, K + G, 3, H, 16).permute(2, 0, 3, 1, 4)
+            if dil > 1:
+                mask, pos = oplan.dilate_mask[depth], oplan.dilate_pos[depth]
+            else:
+                mask, pos = (oplan.hat_mask[depth] if G else oplan.patch_mask[depth]), oplan.rel_pos[depth]
+            rpe = hotformer_ref.rpe_bias(table, pos, K, dil)
+            if G:
+                rpe = torch.nn.functional.pad(rpe, (G, 0, G, 0))
+            o = hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1) + rpe, 0.25).transpose(1, 2).reshape(-1, K + G, C)
+            o_tok = oplan.from_windows(o[:, G:], depth, dil > 1)
+            real = -(-nt // K)
+            wt = torch.randn(nt, C, generator=g)
+            wr = torch.randn(W, C, generator=g)
+            loss = (o_tok * wt).sum()
+            if G:
+                loss = loss + (o[:real, 0] * wr[:real]).sum()
+            loss.backward()
+            # HIP path
+            qd = torch.cat([qkv_tok.detach(), qkv_rt.detach()]).to(DEV).requires_grad_()
+            td = table.detach().to(DEV).requires_grad_()
+            od = ag.window_attention(qd, td, plan.meta[depth], n_tokens=nt, n_windows=W, patch_size=K,
+                                     dilation=dil, n_relay=G, n_heads=H, batch_size=B, rt_row0=nt, depth=depth)
+            wd = torch.cat([wt, wr]).to(DEV)
+            if G:
+                wd[nt + real:] = 0
+                ld = (od * wd).sum()
+            else:
+                ld = (od[:nt] * wd[:nt]).sum()
+            ld.backward()
+            gq = qd.grad.cpu()
+            scale = qkv_tok.grad.abs().max().item()
+            assert (gq[:nt] - qkv_tok.grad).abs().max().item() < 3e-5 * max(scale, 1), (cfg, depth, G, dil)
+            if G:
+                assert (gq[nt:nt + real] - qkv_rt.grad[:real]).abs().max().item() < 3e-5 * max(scale, 1)
+            tscale = table.grad.abs().max().item()
+            assert (td.grad.cpu() - table.grad).abs().max().item() < 1e-4 * max(tscale, 1), (cfg, depth, G, dil)
+
+
+def test_gather_and_relay_init_backward():
+    from hotformerloc_amd import autograd as ag
+    clouds = [syn.unit_ball_cloud(1300, 2500), syn.forest_cloud(1301, 1800)]
+    ref = oracle_octree(clouds, 7)
+    dev = build_batch_octree(clouds, 7, 2, DEV)
+    g = torch.Generator().manual_seed(10)
+    for depth, C, kernel, stride in ((6, 64, '333', 1), (6, 32, '222', 2), (7, 3, '333', 1)):
+        n = int(ref.nnum_nempty[depth])
+        x = torch.randn(n, C, generator=g, requires_grad=True)
+        col = onn.octree_gather(x, ref.get_neigh(depth, kernel, stride, True)).flatten(1)
+        wgt = torch.randn(col.shape, generator=g)
+        (col * wgt).sum().backward()
+        xd = x.detach().to(DEV).requires_grad_()
+        cd = ag.octree_gather(xd, dev.get_neigh(depth, kernel, stride, True).contiguous())
+        (cd * wgt.to(DEV)).sum().backward()
+        assert torch.allclose(xd.grad.cpu(), x.grad, atol=1e-5, rtol=1e-5), (depth, C, kernel)
+    params, ref, dev, oplan, plan = _plans(clouds, 'wild-places', 7)
+    for d in oplan.pyramid_depths:
+        x = torch.randn(plan.n_tokens[d], 256, generator=g, requires_grad=True)
+        xw = oplan.pad(x, d).view(-1, 48, 256).masked_fill(oplan.rt_init_mask[d].unsqueeze(-1), float('nan'))
+        rt = torch.nanmean(xw, 1)
+        wgt = torch.randn(rt.shape, generator=g)
+        (rt * wgt).sum().backward()
+        xd = x.detach().to(DEV).requires_grad_()
+        rd = ag.relay_token_init(xd, plan.meta[d], plan.n_windows[d], 48)
+        (rd * wgt.to(DEV)).sum().backward()
+        assert torch.allclose(xd.grad.cpu(), x.grad, atol=1e-6, rtol=1e-5)

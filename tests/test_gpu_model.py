@@ -136,3 +136,34 @@ def test_batch_composition_semantics():
     with torch.inference_mode():
         again = model({'octree': build_batch_octree(clouds, depth, 2, 'cuda')})['global'].cpu().numpy()
     assert np.array_equal(full, again)
+
+
+@pytest.mark.parametrize('cfg,sizes', [('cs-wild-places', [2500, 1800]), ('wild-places', [1500, 900, 1200])])
+def test_forward_backward_matches_oracle_autograd(cfg, sizes):
+    """BASELINE config 3 (fwd+bwd): parameter gradients of the HIP training path against torch
+    autograd through the CPU oracle, drop_path = 0 (stochastic depth is RNG-dependent)."""
+    params, depth = load_config(cfg)
+    clouds = [syn.forest_cloud(1400 + i, n) if i % 2 else syn.unit_ball_cloud(1400 + i, n)
+              for i, n in enumerate(sizes)]
+    if params.coordinates == 'cylindrical':
+        clouds = [syn.cylindrical(c) for c in clouds]
+    sd = {k: v.clone().requires_grad_() for k, v in synthetic_state_dict(params, 'stress').items()}
+    proj = torch.from_numpy(syn.hash_uniform(4242, len(sizes) * 256).reshape(len(sizes), 256).astype(np.float32))
+    y_ref = hotformer_ref.forward_with_grad(sd, params, oracle_octree(clouds, depth))
+    (y_ref * proj).sum().backward()
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'stress')
+    model = model.cuda().train()
+    y = model({'octree': build_batch_octree(clouds, depth, 2, 'cuda')})['global']
+    (y * proj.cuda()).sum().backward()
+    rel = _rel(y.detach().cpu().numpy(), y_ref.detach().numpy()).max()
+    assert rel <= REL_TOL, rel
+    worst = {}
+    for name, p in model.named_parameters():
+        gref = sd[name].grad
+        assert p.grad is not None, name
+        err = (p.grad.cpu() - gref).norm().item() / max(gref.norm().item(), 1e-12)
+        kind = name.split('.')[-1] if 'rpe_table' not in name else 'rpe_table'
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        assert err < 2e-3 or gref.norm().item() < 1e-9, (name, err, gref.norm().item())
+    print(cfg, 'forward rel', rel, 'worst grad rel-L2 per kind', worst)
