@@ -103,8 +103,10 @@ def main():
                          % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ        # under torchrun the RCCL path runs even at N=1
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', device_id=dev)
 
     params, depth = load_config(args.config)
@@ -120,13 +122,12 @@ def main():
     batch = {'octree': octree}
     torch.cuda.synchronize()
     log('octree ready', octree.nnum_nempty.tolist())
-    gathered = [torch.empty((args.batch, params.output_dim), device=dev) for _ in range(world)] \
-        if world > 1 else None
+    from hotformerloc_amd.distributed import all_gather_descriptors
 
     def step():
         y = model(batch)['global']
-        if world > 1:
-            dist.all_gather(gathered, y.contiguous())
+        if use_dist:
+            all_gather_descriptors(y, args.batch * world, force=True)      # (B_total, 256) on every rank
         return y
 
     with torch.inference_mode():
@@ -134,14 +135,14 @@ def main():
             step()
             torch.cuda.synchronize()
             log('warmup step', i)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         with ops.KernelTimer() as timer:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 y = step()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
@@ -150,7 +151,7 @@ def main():
     assert torch.isfinite(y).all()
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -160,9 +161,17 @@ def main():
         roof = None
         if n:
             gbs = nbytes / (ms * 1e-3) / 1e9
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+                # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
+                rec = json.load(open(pmc)).get('window_attn_kernel_v2')
+                if rec:
+                    traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json'
             roof = {'kernel': 'hfl_window_attention_fwd', 'bound': 'hbm',
                     'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                     'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                     'algorithmic_bytes_per_launch': int(nbytes / n),
                     'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 2),
@@ -189,7 +198,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(params, depth, args)
             line['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -60,11 +60,14 @@ class _AllGatherDescriptors(torch.autograd.Function):
         return grad[ctx.lo:ctx.lo + ctx.n].contiguous(), None, None
 
 
-def all_gather_descriptors(local: torch.Tensor, n_total: Optional[int] = None, group=None) -> torch.Tensor:
+def all_gather_descriptors(local: torch.Tensor, n_total: Optional[int] = None, group=None,
+                           force: bool = False) -> torch.Tensor:
     """(B_local, D) on every rank -> (B_total, D) on every rank, rows in global batch order.
     One small latency-bound collective (32 KiB per rank at B_local=32): a single
     `all_gather_into_tensor` (uneven slices are padded to the largest block)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return local
+    if dist.get_world_size(group) == 1 and not force:     # force: still issue the collective (tests)
         return local
     world = dist.get_world_size(group)
     if n_total is None:

@@ -305,7 +305,9 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     seq = patch_size + n_relay
     real_windows = -(-n_tokens // patch_size)
     # algorithmic work: read q,k,v + write out, 16 B per (row, channel); QK^T + PV = 4 L^2 C per window
-    with _timed('hfl_window_attention_fwd', used * c * 16 + n_tokens * 8, 4 * seq * seq * c * real_windows):
+    # (bf16 [hi|hi|lo] output: 6 B instead of 4 B per written channel)
+    with _timed('hfl_window_attention_fwd', used * c * (18 if out_split else 16) + n_tokens * 8,
+                4 * seq * seq * c * real_windows):
         check(_native.load().hfl_window_attention_fwd_ex(
             out.data_ptr(), qkv.data_ptr(), None if qkv_bias is None else _f32c(qkv_bias).data_ptr(),
             tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), int(bool(out_split)), _stream()),
