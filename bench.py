@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--gemm', default='bf16x3', choices=['bf16x3', 'fp32'],
                     help="Linear layers: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) operands, fp32 "
                          "accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
+    ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='clouds in the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=16,
@@ -92,8 +93,9 @@ def main():
     import torch.distributed as dist
     from hotformerloc_amd import build_batch_octree, load_config, model_factory, ops
     from hotformerloc_amd import synthetic as syn
-    from hotformerloc_amd.model import set_gemm_mode
+    from hotformerloc_amd.model import set_gemm_mode, set_pyramid_streams
     set_gemm_mode(args.gemm)
+    set_pyramid_streams(not args.no_streams)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

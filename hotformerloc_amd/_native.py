@@ -67,6 +67,8 @@ SIGNATURES = {
     'hfl_octree_gather_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     'hfl_relay_token_init_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                          c_int64, c_void_p]),
+    'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int, c_int, c_int, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),

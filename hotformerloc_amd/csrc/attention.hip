@@ -518,6 +518,8 @@ relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
 
 extern "C" {
 
+extern "C" void hfl_internal_set_cpe_chunk(int rows);
+extern "C" void hfl_internal_set_linear_ablate(int v);
 /* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
@@ -526,6 +528,20 @@ int hfl_set_variant(const char* key, int value) {
   while (k[i] != 0 && key[i] == k[i]) ++i;
   if (k[i] == 0 && key[i] == 0) {
     g_window_variant = value;
+    return HFL_OK;
+  }
+  const char* k4 = "linear_ablate";
+  i = 0;
+  while (k4[i] != 0 && key[i] == k4[i]) ++i;
+  if (k4[i] == 0 && key[i] == 0) {
+    hfl_internal_set_linear_ablate(value);
+    return HFL_OK;
+  }
+  const char* k3 = "cpe_chunk_rows";
+  i = 0;
+  while (k3[i] != 0 && key[i] == k3[i]) ++i;
+  if (k3[i] == 0 && key[i] == 0) {
+    hfl_internal_set_cpe_chunk(value);
     return HFL_OK;
   }
   const char* k2 = "window_heads_per_wg";

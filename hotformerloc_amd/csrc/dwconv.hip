@@ -234,7 +234,7 @@ template <int TPR>
 __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, const float* __restrict__ x,
                                const float* __restrict__ weight, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const int32_t* __restrict__ neigh,
-                               int64_t n_rows, int K, float eps, int residual) {
+                               int64_t n_rows, int K, float eps, int residual, int chunk_rows) {
   constexpr int C = TPR * 4;
   constexpr int RPB = 256 / TPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -246,7 +246,22 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
   const float4 gm = reinterpret_cast<const float4*>(gamma)[tx];
   const float4 bt = reinterpret_cast<const float4*>(beta)[tx];
 
-  for (int64_t base = (int64_t)blockIdx.x * RPB; base < n_rows; base += (int64_t)gridDim.x * RPB) {
+  // iteration space: `it` enumerates groups of RPB rows.  chunk_rows == 0: group it of block b is
+  // b + it*gridDim (interleaved).  chunk_rows > 0: a block owns chunk_rows consecutive rows at a time
+  // (z-order neighbours -> its gathers revisit lines still in L1/L2), chunks dealt round-robin.
+  const int64_t groups = (n_rows + RPB - 1) / RPB;
+  const int64_t gpc = chunk_rows > 0 ? (chunk_rows + RPB - 1) / RPB : 1;     // groups per chunk
+  for (int64_t it = 0;; ++it) {
+    int64_t grp;
+    if (chunk_rows > 0) {
+      const int64_t chunk = (it / gpc) * gridDim.x + blockIdx.x;
+      grp = chunk * gpc + it % gpc;
+      if (chunk * gpc >= groups) break;
+    } else {
+      grp = (int64_t)blockIdx.x + it * gridDim.x;
+      if (grp >= groups) break;
+    }
+    const int64_t base = grp * RPB;
     const int64_t h = base + ty;
     const bool live = h < n_rows;
     __syncthreads();
@@ -291,6 +306,8 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
   }
 }
 
+static int g_cpe_chunk_rows = 0;   // 0: rows interleaved over blocks; >0: contiguous chunk per block
+
 template <int TPR>
 static int launch_cpe(float* out, const float* x, const float* w, const float* gamma,
                       const float* beta, const int32_t* neigh, int64_t n, int K, float eps,
@@ -299,7 +316,8 @@ static int launch_cpe(float* out, const float* x, const float* w, const float* g
   const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * sizeof(int32_t);
   const int64_t need = hfl_cdiv(n, RPB);
   const int blocks = (int)(need < (int64_t)hfl_num_cus() * 8 ? need : (int64_t)hfl_num_cus() * 8);
-  cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual);
+  cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual,
+                                               g_cpe_chunk_rows);
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -383,5 +401,8 @@ int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table
   inverse_neigh_kernel<int32_t><<<blocks, 256, 0, s>>>(inverse, table, n_dst_rows, kngh);
   HFL_RETURN_LAST_ERROR();
 }
+
+/* internal tuning hook used by hfl_set_variant("cpe_chunk_rows", n) */
+void hfl_internal_set_cpe_chunk(int rows) { g_cpe_chunk_rows = rows; }
 
 }  // extern "C"

@@ -60,6 +60,14 @@ def _add_ln(x, y, m: nn.LayerNorm):
 # ---- Linear layers: 'fp32' = hipBLASLt fp32 GEMM; 'bf16x3' = one bf16 GEMM over K-concatenated
 # (hi|hi|lo) x (hi|lo|hi) operands with fp32 accumulation/output (include/hotformerloc_hip.h section 9).
 _GEMM_MODE = os.environ.get('HFL_GEMM', 'bf16x3')
+_PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
+
+
+def set_pyramid_streams(enabled: bool):
+    """Run the pyramid depths of one H-OSA iteration on separate HIP streams (inference path)."""
+    global _PYRAMID_STREAMS
+    _PYRAMID_STREAMS = bool(enabled)
+
 _W3_CACHE = {}          # id(weight) -> (weakref to weight, version, W3)
 
 
@@ -442,8 +450,25 @@ class HOTFormerStage(nn.Module):
                     bufs[d] = torch.cat([bufs[d][:nt], new_rt], 0)
                 else:                              # only the relay rows move; tokens stay in place
                     bufs[d][nt:].copy_(new_rt)
-            for j, d in enumerate(depths):
-                bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+            if _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda:
+                # the three depths are independent inside an iteration (the reference runs them on
+                # three CUDA streams too, hotformerloc_backbone.py:604-633): the coarse depths'
+                # small GEMMs and kernels overlap the fine depth's.  Fork/join discipline: side
+                # streams wait for the main stream's event, the main stream waits for theirs.
+                main = torch.cuda.current_stream()
+                side = self._side_streams(data.device)
+                for j, d in enumerate(depths):
+                    if j == 0:
+                        continue
+                    side[j - 1].wait_stream(main)
+                    with torch.cuda.stream(side[j - 1]):
+                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+                bufs[depths[0]] = self.hosa_blocks[0][i](bufs[depths[0]], plan, depths[0])
+                for st in side:
+                    main.wait_stream(st)
+            else:
+                for j, d in enumerate(depths):
+                    bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
         local = {d: bufs[d][:nt] for d, nt in zip(depths, nts)}
         relay = {d: bufs[d][nt:] for d, nt in zip(depths, nts)}
         return local, relay

@@ -54,9 +54,12 @@ def main():
         w = torch.randn(27, 1, C, device='cuda', generator=g)
         gm = torch.ones(C, device='cuda'); bt = torch.zeros(C, device='cuda')
         neigh = plan.neigh(d)
-        med, mn = timeit(lambda: ops.cpe_forward(x, w, gm, bt, neigh, True))
         nb = n * C * 8 + n * 27 * 4
-        print('cpe d=%d C=%d n=%d  med %7.1f us  min %7.1f us  %6.0f GB/s' % (d, C, n, med, mn, nb / med / 1e3))
+        for chunk in (0, 32, 64, 128, 256, 1024):
+            lib.hfl_set_variant(b'cpe_chunk_rows', chunk)
+            med, mn = timeit(lambda: ops.cpe_forward(x, w, gm, bt, neigh, True))
+            print('cpe d=%d C=%d n=%d chunk=%4d med %7.1f us  min %7.1f us  %6.0f GB/s' % (d, C, n, chunk, med, mn, nb / med / 1e3))
+        lib.hfl_set_variant(b'cpe_chunk_rows', 0)
         med, mn = timeit(lambda: torch.nn.functional.layer_norm(x, (C,), gm, bt))
         print('   torch LN same shape   med %7.1f us  %6.0f GB/s' % (med, n * C * 8 / med / 1e3))
         y = torch.randn_like(x)
