@@ -63,6 +63,8 @@ SIGNATURES = {
     'hfl_split3': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_window_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
+    'hfl_relay_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_float, c_int, c_void_p]),
     'hfl_inverse_table': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     'hfl_octree_gather_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     'hfl_relay_token_init_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

@@ -116,6 +116,31 @@ def relay_token_init(x, tok_meta, n_windows, patch_size):
     return RelayTokenInitFn.apply(x, tok_meta, n_windows, patch_size)
 
 
+class RelayAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, seq_rows, seq_off, batch, n_heads, max_seq_len):
+        qkv = qkv.contiguous()
+        ctx.save_for_backward(qkv, seq_rows, seq_off)
+        ctx.cfg = (batch, n_heads, max_seq_len)
+        return ops.relay_attention(qkv, seq_rows, seq_off, batch, n_heads, max_seq_len)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, seq_rows, seq_off = ctx.saved_tensors
+        batch, n_heads, max_seq_len = ctx.cfg
+        dqkv = torch.zeros_like(qkv)
+        check(_native.load().hfl_relay_attention_bwd(
+            dqkv.data_ptr(), qkv.data_ptr(), dout.contiguous().data_ptr(), seq_rows.data_ptr(),
+            seq_off.data_ptr(), batch, n_heads, 16 ** -0.5, max_seq_len, ops._stream()),
+            'hfl_relay_attention_bwd')
+        return dqkv, None, None, None, None, None
+
+
+def relay_attention(qkv, plan, n_heads: int):
+    """Ragged relay-token attention, HIP forward and backward."""
+    return RelayAttentionFn.apply(qkv, plan.seq_rows, plan.seq_off, plan.B, n_heads, plan.max_seq_len)
+
+
 # ------------------------------------------------ differentiable torch forms (GPU, tiny ops)
 def relay_attention_torch(qkv, plan, n_heads: int):
     """Ragged relay-token attention as padded dense math (training path only): rows of cloud b

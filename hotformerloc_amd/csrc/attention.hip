@@ -948,3 +948,104 @@ extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const fl
     default: return HFL_EINVAL;
   }
 }
+
+// ======================================================================================
+// Backward of the ragged relay-token attention (training path).  One workgroup per (cloud, head):
+// the cloud's Q, K, V, dO rows of that head are staged in LDS (R x 16 floats each), one thread per
+// query row recomputes its softmax, accumulates dQ in registers and adds its contributions to
+// dK / dV in LDS (ds_add_f32); the sums are written once.  Work is tiny (R ~ 56..250).
+namespace {
+
+__global__ void __launch_bounds__(256)
+relay_attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ qkv,
+                      const float* __restrict__ dout, const int32_t* __restrict__ seq_rows,
+                      const int32_t* __restrict__ seq_off, int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int r0 = seq_off[b];
+  const int R = seq_off[b + 1] - r0;
+  if (R <= 0) return;
+  const int C = H * 16;
+  float* sq = reinterpret_cast<float*>(smem);      // [R][16]
+  float* sk = sq + R * 16;
+  float* sv = sk + R * 16;
+  float* sd = sv + R * 16;
+  float* dk = sd + R * 16;
+  float* dv = dk + R * 16;
+  for (int i = threadIdx.x; i < R * 4; i += blockDim.x) {
+    const int j = i >> 2, f = i & 3;
+    const int64_t row = seq_rows[r0 + j];
+    const float* base = qkv + row * 3 * C + h * 16 + 4 * f;
+    reinterpret_cast<float4*>(sq)[i] = *reinterpret_cast<const float4*>(base);
+    reinterpret_cast<float4*>(sk)[i] = *reinterpret_cast<const float4*>(base + C);
+    reinterpret_cast<float4*>(sv)[i] = *reinterpret_cast<const float4*>(base + 2 * C);
+    reinterpret_cast<float4*>(sd)[i] = *reinterpret_cast<const float4*>(dout + row * C + h * 16 + 4 * f);
+    reinterpret_cast<float4*>(dk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(dv)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R; i += blockDim.x) {
+    float q[16], g[16], dq[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { q[d] = sq[i * 16 + d]; g[d] = sd[i * 16 + d]; dq[d] = 0.f; }
+    float m = -INFINITY;
+    for (int j = 0; j < R; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s = fmaf(q[d], sk[j * 16 + d], s);
+      m = fmaxf(m, s * scale);
+    }
+    float l = 0.f, D = 0.f;
+    for (int j = 0; j < R; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], sk[j * 16 + d], s); dp = fmaf(g[d], sv[j * 16 + d], dp); }
+      const float e = __expf(s * scale - m);
+      l += e;
+      D += e * dp;
+    }
+    const float inv = 1.0f / l;
+    D *= inv;
+    for (int j = 0; j < R; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], sk[j * 16 + d], s); dp = fmaf(g[d], sv[j * 16 + d], dp); }
+      const float pj = __expf(s * scale - m) * inv;
+      const float ds = pj * (dp - D) * scale;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        dq[d] = fmaf(ds, sk[j * 16 + d], dq[d]);
+        atomicAdd(dk + j * 16 + d, ds * q[d]);
+        atomicAdd(dv + j * 16 + d, pj * g[d]);
+      }
+    }
+    float* o = dqkv + (int64_t)seq_rows[r0 + i] * 3 * C + h * 16;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = dq[d];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R * 4; i += blockDim.x) {
+    const int j = i >> 2, f = i & 3;
+    float* base = dqkv + (int64_t)seq_rows[r0 + j] * 3 * C + h * 16 + 4 * f;
+    *reinterpret_cast<float4*>(base + C) = reinterpret_cast<const float4*>(dk)[i];
+    *reinterpret_cast<float4*>(base + 2 * C) = reinterpret_cast<const float4*>(dv)[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int hfl_relay_attention_bwd(float* dqkv, const float* qkv, const float* dout,
+                                       const int32_t* seq_rows, const int32_t* seq_off, int batch,
+                                       int n_heads, float scale, int max_seq_len, hfl_stream_t stream) {
+  if (batch <= 0 || n_heads <= 0 || max_seq_len < 0) return HFL_EINVAL;
+  const size_t lds = (size_t)max_seq_len * 16 * 4 * 6;
+  if (lds > 160 * 1024) return HFL_ECAPACITY;
+  if (max_seq_len == 0) return HFL_OK;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(relay_attn_bwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((unsigned)batch, (unsigned)n_heads);
+  relay_attn_bwd_kernel<<<grid, 256, lds, static_cast<hipStream_t>(stream)>>>(dqkv, qkv, dout, seq_rows,
+                                                                            seq_off, n_heads, scale);
+  HFL_RETURN_LAST_ERROR();
+}

@@ -111,6 +111,29 @@ def _require_layernorm(conv_norm: str):
         raise NotImplementedError("conv_norm=%r: every shipped config uses 'layernorm'" % conv_norm)
 
 
+class OctreeDropPath(nn.Module):
+    """Per-cloud stochastic depth (models/layers/octformer_layers.py:213-289): in training every
+    cloud keeps (scaled by 1/keep) or drops a residual branch; identity in eval.  `bid` gives the
+    cloud of every row (relay rows carry their window owner, padding rows the last cloud)."""
+
+    def __init__(self, drop_prob: float = 0.0, scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+        self.scale_by_keep = scale_by_keep
+
+    def forward(self, data, bid, batch_size: int):
+        if self.drop_prob <= 0.0 or not self.training:
+            return data
+        keep = 1.0 - self.drop_prob
+        rnd = torch.floor(torch.rand(batch_size, 1, dtype=data.dtype, device=data.device) + keep)
+        if keep > 0.0 and self.scale_by_keep:
+            rnd = rnd / keep
+        return data * rnd[bid]
+
+    def extra_repr(self):
+        return 'drop_prob={:.4f}'.format(self.drop_prob)
+
+
 # --------------------------------------------------------------------------- convs
 class OctreeConv(nn.Module):
     """`ocnn.nn.OctreeConv` (nempty=True): parameter `weights` (kdim, Cin, Cout) [+ `bias`].
@@ -275,12 +298,14 @@ class OctreeAttention(nn.Module):
 class OctFormerBlock(nn.Module):
     """models/octformer_backbone.py:182-299 (use_rt=False)"""
 
-    def __init__(self, dim, num_heads, patch_size, dilation, disable_RPE=False, conv_norm='layernorm'):
+    def __init__(self, dim, num_heads, patch_size, dilation, disable_RPE=False, conv_norm='layernorm',
+                 drop_path=0.0):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.attention = OctreeAttention(dim, patch_size, num_heads, dilation, 0, not disable_RPE)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4.0), dim)
+        self.drop_path = OctreeDropPath(drop_path)
         self.cpe = CPE(dim, conv_norm)
 
     def forward(self, x, plan: WindowPlan, depth: int):
@@ -288,6 +313,10 @@ class OctFormerBlock(nn.Module):
         if _split_path(x):
             o3 = self.attention.forward_split(x, self.norm1, plan, depth)
             return _block_tail_split(x, o3, self.attention, self.norm2, self.mlp)
+        if self.training and self.drop_path.drop_prob > 0.0:
+            bid = plan.row_cloud(depth, with_relay=False)
+            x = x + self.drop_path(self.attention(_ln(x, self.norm1), plan, depth), bid, plan.B)
+            return x + self.drop_path(self.mlp(_ln(x, self.norm2)), bid, plan.B)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
         return x + self.mlp(h)
 
@@ -296,11 +325,12 @@ class OctFormerStage(nn.Module):
     """models/octformer_backbone.py:363-421"""
 
     def __init__(self, dim, num_heads, patch_size, dilation, num_blocks, disable_RPE=False,
-                 conv_norm='layernorm'):
+                 conv_norm='layernorm', drop_path=0.0):
         super().__init__()
+        dp = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * num_blocks
         self.blocks = nn.ModuleList([
             OctFormerBlock(dim, num_heads, patch_size, 1 if i % 2 == 0 else dilation, disable_RPE,
-                           conv_norm) for i in range(num_blocks)])
+                           conv_norm, dp[i]) for i in range(num_blocks)])
 
     def forward(self, x, plan, depth):
         for blk in self.blocks:
@@ -312,12 +342,14 @@ class HOTFormerBlock(nn.Module):
     """models/hotformerloc_backbone.py:130-236 (rt_propagation off): operates on the
     [tokens | relay tokens] buffer of one depth."""
 
-    def __init__(self, dim, num_heads, patch_size, disable_RPE=False, conv_norm='layernorm'):
+    def __init__(self, dim, num_heads, patch_size, disable_RPE=False, conv_norm='layernorm',
+                 drop_path=0.0):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.attention = OctreeAttention(dim, patch_size, num_heads, 1, 1, not disable_RPE)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4.0), dim)
+        self.drop_path = OctreeDropPath(drop_path)
         self.cpe = CPE(dim, conv_norm)
 
     def forward(self, buf, plan: WindowPlan, depth: int):
@@ -332,6 +364,10 @@ class HOTFormerBlock(nn.Module):
         if _split_path(buf):
             o3 = self.attention.forward_split(buf, self.norm1, plan, depth)
             return _block_tail_split(buf, o3, self.attention, self.norm2, self.mlp)
+        if self.training and self.drop_path.drop_prob > 0.0:
+            bid = plan.row_cloud(depth, with_relay=True)
+            buf = buf + self.drop_path(self.attention(_ln(buf, self.norm1), plan, depth), bid, plan.B)
+            return buf + self.drop_path(self.mlp(_ln(buf, self.norm2)), bid, plan.B)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
         return buf + self.mlp(h)
 
@@ -348,6 +384,8 @@ class RTAttention(nn.Module):
     def forward(self, rt, plan: WindowPlan):
         qkv = self.qkv(rt)
         if _grad_path(qkv):
+            if plan.max_seq_len <= 426:             # LDS capacity of the HIP backward
+                return self.proj(ag.relay_attention(qkv, plan, self.num_heads))
             return self.proj(ag.relay_attention_torch(qkv, plan, self.num_heads))
         out = ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, self.num_heads,
                                   plan.max_seq_len)
@@ -357,14 +395,19 @@ class RTAttention(nn.Module):
 class RelayTokenTransformerBlock(nn.Module):
     """models/hotformerloc_backbone.py:239-302 on the concatenated (sum W_d, C) relay rows."""
 
-    def __init__(self, dim, num_heads):
+    def __init__(self, dim, num_heads, drop_path=0.0):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.rt_attention = RTAttention(dim, num_heads)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4.0), dim)
+        self.drop_path = OctreeDropPath(drop_path)
 
     def forward(self, rt, plan):
+        if self.training and self.drop_path.drop_prob > 0.0:
+            bid = plan.relay_cloud()
+            rt = rt + self.drop_path(self.rt_attention(_ln(rt, self.norm1), plan), bid, plan.B)
+            return rt + self.drop_path(self.mlp(_ln(rt, self.norm2)), bid, plan.B)
         rt, h = _add_ln(rt, self.rt_attention(_ln(rt, self.norm1), plan), self.norm2)
         return rt + self.mlp(h)
 
@@ -402,7 +445,7 @@ class HOTFormerStage(nn.Module):
     """models/hotformerloc_backbone.py:366-635 (one channel width for all levels)."""
 
     def __init__(self, channels, num_heads, num_blocks, num_pyramid_levels, patch_size,
-                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm'):
+                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm', drop_path=0.0):
         super().__init__()
         if len(channels) != 1 or len(num_heads) != 1:
             raise NotImplementedError('per-level channel widths (projection layers) are not used '
@@ -410,10 +453,12 @@ class HOTFormerStage(nn.Module):
         C, H = channels[0], num_heads[0]
         self.num_pyramid_levels, self.num_blocks = num_pyramid_levels, num_blocks
         self.use_ADaPE = ADaPE_mode is not None
+        dp = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * num_blocks
         self.hosa_blocks = nn.ModuleList([
-            nn.ModuleList([HOTFormerBlock(C, H, patch_size, disable_RPE, conv_norm)
-                           for _ in range(num_blocks)]) for _ in range(num_pyramid_levels)])
-        self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(C, H) for _ in range(num_blocks)])
+            nn.ModuleList([HOTFormerBlock(C, H, patch_size, disable_RPE, conv_norm, dp[i])
+                           for i in range(num_blocks)]) for _ in range(num_pyramid_levels)])
+        self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(C, H, dp[i])
+                                          for i in range(num_blocks)])
         self.relay_tokeniser = RelayTokenInitialiser(C, patch_size, conv_norm,
                                                      use_cpe=not self.use_ADaPE)
         if self.use_ADaPE:
@@ -478,8 +523,11 @@ class HOTFormerBase(nn.Module):
     """models/hotformerloc_backbone.py:638-723"""
 
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels,
-                 num_octf_levels, patch_size, dilation, stem_down, ADaPE_mode, disable_RPE, conv_norm):
+                 num_octf_levels, patch_size, dilation, stem_down, ADaPE_mode, disable_RPE, conv_norm,
+                 drop_path=0.0):
         super().__init__()
+        # stochastic depth per block (hotformerloc_backbone.py:669-700)
+        drop_ratio = torch.linspace(0, drop_path, sum(num_blocks)).tolist()
         self.patch_size, self.dilation = patch_size, dilation
         self.num_pyramid_levels, self.num_octf_levels = num_pyramid_levels, num_octf_levels
         self.num_stages = num_octf_levels + num_pyramid_levels
@@ -490,13 +538,14 @@ class HOTFormerBase(nn.Module):
         self.patch_embed = PatchEmbed(in_channels, channels[0], stem_down, conv_norm)
         self.octf_stage = nn.ModuleList([
             OctFormerStage(channels[i], num_heads[i], patch_size, dilation, num_blocks[i], disable_RPE,
-                           conv_norm) for i in range(num_octf_levels)])
+                           conv_norm, drop_ratio[sum(num_blocks[:i]):sum(num_blocks[:i + 1])])
+            for i in range(num_octf_levels)])
         self.downsample = nn.ModuleList([Downsample(channels[i], channels[i + 1], conv_norm)
                                          for i in range(num_octf_levels)])
         self.hotf_stage = HOTFormerStage(list(channels[num_octf_levels:]),
                                          list(num_heads[num_octf_levels:]), num_blocks[-1],
                                          num_pyramid_levels, patch_size, disable_RPE, ADaPE_mode,
-                                         conv_norm)
+                                         conv_norm, drop_ratio[sum(num_blocks[:-1]):sum(num_blocks)])
 
     def forward(self, data, octree, depth):
         data = self.patch_embed(data, octree, depth)
@@ -517,13 +566,14 @@ class HOTFormer(nn.Module):
     """models/hotformerloc_backbone.py:726-849 (init: 817-843)"""
 
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels=3,
-                 num_octf_levels=1, patch_size=32, dilation=4, stem_down=2, ADaPE_mode=None,
-                 disable_RPE=False, conv_norm='layernorm', qkv_init=('trunc_normal', 0.02)):
+                 num_octf_levels=1, patch_size=32, dilation=4, drop_path=0.5, stem_down=2,
+                 ADaPE_mode=None, disable_RPE=False, conv_norm='layernorm',
+                 qkv_init=('trunc_normal', 0.02)):
         super().__init__()
         self.backbone = HOTFormerBase(in_channels, list(channels), list(num_blocks),
                                       None if num_heads is None else list(num_heads),
                                       num_pyramid_levels, num_octf_levels, patch_size, dilation,
-                                      stem_down, ADaPE_mode, disable_RPE, conv_norm)
+                                      stem_down, ADaPE_mode, disable_RPE, conv_norm, drop_path)
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=0.02)

@@ -50,6 +50,7 @@ def model_factory(model_params: ModelParams):
         num_octf_levels=model_params.num_octf_levels,
         patch_size=model_params.patch_size,
         dilation=model_params.dilation,
+        drop_path=model_params.drop_path,
         stem_down=model_params.num_input_downsamples,
         ADaPE_mode=model_params.ADaPE_mode,
         disable_RPE=model_params.disable_RPE,

@@ -127,6 +127,28 @@ class WindowPlan:
                 self.window_stats[d] = ops.window_stats(self.meta[d], self.n_tokens[d],
                                                         self.n_windows[d], self.K, d)
 
+    def row_cloud(self, depth: int, with_relay: bool):
+        """int64 cloud index of every row of a depth's buffer: tokens by their batch id, relay rows
+        (if any) by their window owner, padding windows -> last cloud (octformer_layers.py:262-281)."""
+        key = (depth, with_relay)
+        cache = self.__dict__.setdefault('_row_cloud', {})
+        if key not in cache:
+            tok = self.meta[depth][:, 1].long()
+            if with_relay:
+                first = torch.arange(self.n_windows[depth], device=self.device) * self.K
+                own = torch.where(first < tok.shape[0], tok[first.clamp(max=tok.shape[0] - 1)],
+                                  torch.full_like(first, self.B))
+                tok = torch.cat([tok, own.clamp(max=self.B - 1)])
+            cache[key] = tok
+        return cache[key]
+
+    def relay_cloud(self):
+        """cloud index of every row of the concatenated relay-token matrix (all pyramid depths)."""
+        if getattr(self, '_relay_cloud', None) is None:
+            parts = [self.row_cloud(d, True)[self.n_tokens[d]:] for d in self.pyramid_depths]
+            self._relay_cloud = torch.cat(parts)
+        return self._relay_cloud
+
     def relay_pad_index(self):
         """(B, Rmax) row index of each cloud's relay-token sequence (-1 = padding) and its validity
         mask, for the dense training-path formulation of relay attention."""

@@ -289,6 +289,12 @@ int hfl_linear_bf16x3(float* out, const float* x, const uint16_t* w_hi, const ui
 int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
                              const uint32_t* tok_meta, const float* rpe_table,
                              const hfl_window_attn_desc* desc, hfl_stream_t stream);
+/* Gradient of hfl_relay_attention_fwd.  dqkv (rows, 3*H*16): rows listed in seq_rows are written, the
+ * others left untouched (the caller zero-fills).  max_seq_len * 384 B of LDS per workgroup: returns
+ * HFL_ECAPACITY beyond 426 relay tokens per cloud. */
+int hfl_relay_attention_bwd(float* dqkv, const float* qkv, const float* dout, const int32_t* seq_rows,
+                            const int32_t* seq_off, int batch, int n_heads, float scale,
+                            int max_seq_len, hfl_stream_t stream);
 /* Inverse of a gather table whose source and destination row counts differ (stride-2 conv:
  * table (n_dst, K) with entries in [0, n_src)): inverse (n_src, K), inverse[table[m,k], k] = m, -1 else. */
 int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table, int64_t n_dst_rows,

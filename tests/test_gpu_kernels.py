@@ -521,3 +521,21 @@ def test_linear_bf16x3_kernel():
         y = ops.linear_bf16x3(x.to(DEV), wh, wl, bias=b.to(DEV), gelu=True).cpu().double()
         ref3 = torch.nn.functional.gelu(ref + b.double())
         assert ((y - ref3).norm() / ref3.norm()).item() < 1e-5
+
+
+def test_relay_attention_backward():
+    from hotformerloc_amd import autograd as ag
+    clouds = [syn.unit_ball_cloud(1500 + i, n) for i, n in enumerate([4096, 50, 3000])]
+    params, ref, dev, oplan, plan = _plans(clouds, 'wild-places', 7)
+    g = torch.Generator().manual_seed(12)
+    rows = sum(plan.n_windows[d] for d in plan.pyramid_depths)
+    qkv = torch.randn(rows, 768, generator=g)
+    wgt = torch.randn(rows, 256, generator=g)
+    a = qkv.clone().to(DEV).requires_grad_()
+    (ag.relay_attention_torch(a, plan, 16) * wgt.to(DEV)).sum().backward()
+    b = qkv.clone().to(DEV).requires_grad_()
+    out = ag.relay_attention(b, plan, 16)
+    (out * wgt.to(DEV)).sum().backward()
+    assert torch.allclose(out.detach(), ag.relay_attention_torch(a.detach(), plan, 16), atol=2e-5)
+    scale = a.grad.abs().max().item()
+    assert (a.grad - b.grad).abs().max().item() < 3e-5 * max(scale, 1.0)

@@ -151,6 +151,7 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes):
     proj = torch.from_numpy(syn.hash_uniform(4242, len(sizes) * 256).reshape(len(sizes), 256).astype(np.float32))
     y_ref = hotformer_ref.forward_with_grad(sd, params, oracle_octree(clouds, depth))
     (y_ref * proj).sum().backward()
+    params.drop_path = 0.0                       # stochastic depth off: RNG parity is impossible
     model = model_factory(params)
     syn.fill_synthetic_weights(model, 'stress')
     model = model.cuda().train()
@@ -167,3 +168,34 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes):
         worst[kind] = max(worst.get(kind, 0.0), err)
         assert err < 2e-3 or gref.norm().item() < 1e-9, (name, err, gref.norm().item())
     print(cfg, 'forward rel', rel, 'worst grad rel-L2 per kind', worst)
+
+
+def test_drop_path_is_per_cloud_and_off_in_eval():
+    """Stochastic depth (models/layers/octformer_layers.py:213-289): train-mode outputs differ from
+    eval, a dropped branch is dropped for a whole cloud, eval ignores it."""
+    params, depth = load_config('wild-places')
+    assert params.drop_path == 0.5
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'stress')
+    model = model.cuda()
+    clouds = syn.make_clouds(55, 3, 1200, params.coordinates)
+    octree = build_batch_octree(clouds, depth, 2, 'cuda')
+    model.eval()
+    with torch.no_grad():
+        e1 = model({'octree': octree})['global']
+        e2 = model({'octree': octree})['global']
+    assert torch.equal(e1, e2)
+    model.train()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        t1 = model({'octree': octree})['global']
+    assert torch.isfinite(t1).all() and not torch.allclose(t1, e1, atol=1e-4)
+    from hotformerloc_amd.model import OctreeDropPath
+    dp = OctreeDropPath(0.5).train()
+    bid = torch.tensor([0] * 5 + [1] * 7 + [2] * 3, device='cuda')
+    x = torch.ones(15, 4, device='cuda')
+    torch.manual_seed(3)
+    y = dp(x, bid, 3)
+    for b in range(3):
+        rows = y[bid == b]
+        assert torch.all(rows == rows[0, 0]) and rows[0, 0].item() in (0.0, 2.0)
