@@ -5,10 +5,7 @@ import csv, sys, re, collections
 def group(name):
     if name.startswith('Cijk_'): return 'hipBLASLt fp32 GEMM (torch Linear/mm/bmm)'
     m = re.search(r'\(anonymous namespace\)::(\w+)', name)
-    if m and m.group(1) in ('window_attn_kernel','cpe_fwd_kernel','gather_kernel','relay_attn_kernel',
-        'segment_softmax_kernel','relay_init_kernel','token_meta_kernel','build_cloud_kernel','neigh_walk_kernel',
-        'neigh_full_kernel','merge_sparse_kernel','merge_full_kernel','window_stats_kernel','dwconv_fwd_vec4',
-        'fused_ln_kernel','bias_act_kernel'):
+    if m and not name.startswith('void at::') and 'at::native' not in name:
         t = re.search(r'<([^>]*)>', name)
         return 'hfl:' + m.group(1) + (('<%s>' % t.group(1)) if t else '')
     if 'layer_norm' in name: return 'torch LayerNorm'
