@@ -46,6 +46,7 @@ def parse():
                     help="Linear layers: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) operands, fp32 "
                          "accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
+    ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='clouds in the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=16,
@@ -126,13 +127,26 @@ def main():
     log('octree ready', octree.nnum_nempty.tolist())
     from hotformerloc_amd.distributed import all_gather_descriptors
 
+    if args.train:
+        model.train()
+        for m in model.modules():
+            if hasattr(m, 'drop_prob'):
+                m.drop_prob = 0.0
+        proj = torch.from_numpy(syn.hash_uniform(99, args.batch * params.output_dim).reshape(
+            args.batch, params.output_dim).astype('float32')).to(dev)
+
     def step():
+        if args.train:
+            model.zero_grad(set_to_none=True)
+            y = model(batch)['global']
+            (y * proj).sum().backward()
+            return y.detach()
         y = model(batch)['global']
         if use_dist:
             all_gather_descriptors(y, args.batch * world, force=True)      # (B_total, 256) on every rank
         return y
 
-    with torch.inference_mode():
+    with (torch.enable_grad() if args.train else torch.inference_mode()):
         for i in range(args.warmup):
             step()
             torch.cuda.synchronize()
@@ -190,8 +204,9 @@ def main():
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.gemm == 'fp32' else 'f32 (Linear products as 3-term bf16 split, f32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': '%s cfg, batch=%d clouds/GPU x %d pts, octree depth %d, forward-only, '
-                                   'octree+neighbours resident' % (args.config, args.batch, args.points, depth),
+            'config': {'workload': '%s cfg, batch=%d clouds/GPU x %d pts, octree depth %d, %s, '
+                                   'octree+neighbours resident' % (args.config, args.batch, args.points, depth,
+                                                                   'forward+backward' if args.train else 'forward-only'),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
                        'collective': 'rccl all_gather (B_local,256) f32' if world > 1 else 'none'},
             'roofline': roof, 'kernels': others,

@@ -37,9 +37,11 @@ def main():
         nbytes = rows * C * 16
         flops = 4 * (K + G) ** 2 * C * (-(-nt // K))
         res = {}
-        for name, var, hpw in (('v1', 1, 0), ('v2/hpw=H', 2, H), ('v2/hpw=8', 2, 8), ('v2/hpw=4', 2, 4), ('v2/hpw=2', 2, 2)):
+        for name, var, hpw, wgs in (('v2/cap16', 2, 4, 16), ('v2/cap8', 2, 4, 8), ('v2/cap6', 2, 4, 6), ('v2/cap4', 2, 4, 4),
+                                    ('v2/cap3', 2, 4, 3), ('v2/hpw2/cap6', 2, 2, 6), ('v2/hpw1/cap12', 2, 1, 12)):
             lib.hfl_set_variant(b'window_attention', var)
             lib.hfl_set_variant(b'window_heads_per_wg', hpw if hpw else H)
+            lib.hfl_set_variant(b'window_v2_wgs_per_cu', wgs)
             f = lambda: ops.window_attention(qkv, plan.meta[d], table, nt, W, K, dil, G, H, B, rt_row0=nt, depth=d)
             med, mn = timeit(f)
             res[name] = med
@@ -47,6 +49,7 @@ def main():
                   (d, H, G, dil, name, med, mn, nbytes / med / 1e3, flops / med / 1e6))
     lib.hfl_set_variant(b'window_attention', 2)
     lib.hfl_set_variant(b'window_heads_per_wg', 4)
+    lib.hfl_set_variant(b'window_v2_wgs_per_cu', 16)
     # CPE
     for d, C in ((md, 128), (md - 1, 256), (md - 2, 256)):
         n = plan.n_tokens[d]
@@ -55,7 +58,7 @@ def main():
         gm = torch.ones(C, device='cuda'); bt = torch.zeros(C, device='cuda')
         neigh = plan.neigh(d)
         nb = n * C * 8 + n * 27 * 4
-        for chunk in (0, 32, 64, 128, 256, 1024):
+        for chunk in (0,):
             lib.hfl_set_variant(b'cpe_chunk_rows', chunk)
             med, mn = timeit(lambda: ops.cpe_forward(x, w, gm, bt, neigh, True))
             print('cpe d=%d C=%d n=%d chunk=%4d med %7.1f us  min %7.1f us  %6.0f GB/s' % (d, C, n, chunk, med, mn, nb / med / 1e3))
