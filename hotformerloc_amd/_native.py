@@ -25,7 +25,7 @@ class WindowAttnDesc(ctypes.Structure):
     _fields_ = [('n_tokens', c_int64), ('rt_row0', c_int64), ('n_windows', c_int32),
                 ('patch_size', c_int32), ('dilation', c_int32), ('n_relay', c_int32),
                 ('n_heads', c_int32), ('pos_bnd', c_int32), ('batch_size', c_int32),
-                ('scale', c_float), ('depth', c_int32)]
+                ('scale', c_float), ('depth', c_int32), ('rpe_expanded', c_void_p)]
 
 
 # name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
@@ -72,6 +72,8 @@ SIGNATURES = {
     'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
+    'hfl_window_rpe_expand_size': (c_int64, [c_int, c_int, c_int]),
+    'hfl_window_rpe_expand': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),
     'hfl_relay_token_init': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

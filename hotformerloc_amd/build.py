@@ -19,6 +19,9 @@ ARCH = 'gfx950'
 SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'window_misc.hip', 'attention.hip', 'linear.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
+# per-file extras.  attention.hip: MFMA results feed VALU softmax code directly, so keep the MFMA
+# destination in arch VGPRs (the default heuristic parks it in AGPRs and pays a v_accvgpr_read per score)
+EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'] + os.environ.get('HFL_ATTENTION_FLAGS', '').split()}
 
 
 def _hipcc() -> str:
@@ -51,7 +54,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (s, r.stderr))

@@ -21,6 +21,8 @@
 //     token rows: window (un)packing, dilation and padding are pure index arithmetic.
 #include "hfl_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +47,17 @@ struct WinParams {
   float scale;
   const float* qkv_bias;   // (3*H*16) added to q,k,v on load (bias-free GEMM upstream), or null
   int out_split;           // 1: out is bf16 [hi|hi|lo] rows of 3*H*16 (A operand of the split GEMM)
+  const float* rpe2;       // (H, TS) expanded table of hfl_window_rpe_expand (v4), or null
+  int depth;               // octree depth of the tokens (0 = unknown)
+  int dbg;                 // ablation bits (tools/kbench.py): 1 no softmax/MFMA, 2 no stores, 4 cached rows
 };
+
+// v_max3_f32 without the canonicalising v_max(x,x) that fmaxf() costs under IEEE mode
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 __device__ __forceinline__ uint16_t att_bf16_rne(float v) {
   uint32_t u = __float_as_uint(v);
@@ -715,7 +727,416 @@ window_attn_kernel_v3(const WinParams p) {
   }
 }
 
-static int g_window_variant = 2;
+
+// ----------------------------------------------------------------------------------
+// v4: v2 after a second instruction diet.  The ISA of v2<5,1> is 3250 instructions per (window,
+// head) for 148 MFMAs -- ~50 issue slots per score against a floor of ~8 -- so the kernel is
+// VALU/issue bound, not memory bound (SQ counters: profiles/r01_b_summary.md).  What changes:
+//   * RPE bias = X[dx] + YZ[dy,dz]: the y and z axis tables are pre-added into a (2R+1)^2 table
+//     (R = 2^depth - 1, no clamp needed when R <= pos_bnd), built once per table by
+//     hfl_window_rpe_expand and copied to LDS per workgroup: two lookups and one add per score
+//     instead of three lookups, two adds and six clamps;
+//   * a lane's 16 keys are the same for every query tile: their LDS table offsets live in
+//     registers for the whole window instead of being re-read per query tile;
+//   * windows that lie inside one cloud and have no padding (all but ~B of them) take a path
+//     with no mask arithmetic at all; tokens are sorted by cloud, so comparing the batch id of the
+//     first and last token of the window decides it (wave-uniform, two scalar loads);
+//   * P stays un-normalised into the P V MFMAs; the 1/sum lands on the 4 output registers;
+//   * v_rcp_f32 instead of an IEEE divide, 32-bit byte offsets from the qkv / out base pointers
+//     (saddr + voffset addressing; the caller falls back to v2 when a buffer exceeds 4 GiB).
+#ifndef HFL_V4_PF
+#define HFL_V4_PF 1
+#endif
+#ifndef HFL_V4_WAVES
+#define HFL_V4_WAVES 2
+#endif
+template <int T, int G, bool RPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFL_V4_WAVES, HFL_V4_WAVES)))
+window_attn_kernel_v4(const WinParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LP = T * 16;
+  constexpr int TW = T - G;
+  constexpr float kLog2e = 1.4426950408889634f;
+  typedef __attribute__((address_space(3))) const float lds_f32;
+  const int H = p.H, K = p.K;
+  const int C = H * 16;
+  const int R = (1 << p.depth) - 1, W = 2 * R + 1;
+  const int TS = RPE ? ((W + W * W + 3) & ~3) : 0;
+  // metadata is double-buffered: window i+1's is written while window i's is still being read
+  int4* s_qry0 = reinterpret_cast<int4*>(smem);                        // [2][LP] {4x, 4(yW+z), id, row}
+  int2* s_key0 = reinterpret_cast<int2*>(s_qry0 + 2 * LP);             // [2][LP] {4(R-x), 4(W+(R-y)W+R-z)}
+  int* s_kbid0 = reinterpret_cast<int*>(s_key0 + 2 * LP);              // [2][LP] batch id, -1 dead
+  float* s_tab = reinterpret_cast<float*>(s_kbid0 + 2 * LP);           // [nhw][TS] * log2e
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int hw = tid >> 6;
+  const int nhw = blockDim.x >> 6;
+  const int h = blockIdx.y * nhw + hw;
+  const int c = lane & 15, g = lane >> 4;
+
+  if (RPE) {
+    const float4* src = reinterpret_cast<const float4*>(p.rpe2 + (size_t)blockIdx.y * nhw * TS);
+    float4* dst = reinterpret_cast<float4*>(s_tab);
+    for (int i = tid; i < nhw * TS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  const int hu = __builtin_amdgcn_readfirstlane(hw);
+  const int tabb = (int)(size_t)(s_tab + hu * TS);
+  const float scale2 = p.scale * kLog2e;
+  const float mask2 = kMaskValue * kLog2e;
+  const float rt_add = (g == 0) ? 0.f : kDeadValue;   // the relay key lives in the g == 0 lanes only
+  const uint32_t row_q = (uint32_t)(3 * C) * 4u;       // bytes per qkv row
+  const uint32_t row_o = p.out_split ? (uint32_t)(3 * C) * 2u : (uint32_t)C * 4u;
+  const char* qkv_b = reinterpret_cast<const char*>(p.qkv);
+  char* out_b = reinterpret_cast<char*>(p.out);
+
+  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bk = bq;
+  float bv = 0.f;
+  if (p.qkv_bias != nullptr) {
+    bq = *reinterpret_cast<const float4*>(p.qkv_bias + h * 16 + 4 * g);
+    bk = *reinterpret_cast<const float4*>(p.qkv_bias + C + h * 16 + 4 * g);
+    bv = p.qkv_bias[2 * C + h * 16 + c];
+  }
+  const uint32_t col_qk = (uint32_t)(h * 16 + 4 * g) * 4u;
+  const uint32_t col_v = (uint32_t)(2 * C + h * 16 + c) * 4u;
+
+  const int n_tok = (int)p.n_tokens;
+  const bool owns = tid < LP;                          // the launcher guarantees blockDim.x >= LP
+
+  // Request one window: its metadata word and every Q/K/V fragment of this wave's head.  Rows are
+  // index arithmetic (token of window slot j = tok0 + j * D), so nothing here waits on anything.
+  auto request = [&](float4 (&kf)[T], float4 (&qf)[T], float (&vf)[T][4], uint2& mt, int w) {
+    const int tstep = p.D;
+    const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
+    const int rt_row = (int)p.rt_row0 + w;
+    mt = make_uint2(0u, 0xFFFFFFFFu);                  // dead slot
+    if (owns && tid < K) {
+      const int t = tok0 + tid * tstep;
+      if (t < n_tok) mt = *reinterpret_cast<const uint2*>(p.meta + 2 * (int64_t)t);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      kf[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      qf[t] = kf[t];
+      int row;
+      bool ok;
+      if (G > 0 && t == T - 1) {
+        row = rt_row;
+        ok = (c == 0);
+      } else {
+        row = tok0 + (t * 16 + c) * tstep;
+        ok = row < n_tok;
+      }
+      if ((p.dbg & 4) && ok) row &= 63;
+      if (ok) {
+        const char* base = qkv_b + ((uint32_t)row * row_q + col_qk);
+        qf[t] = *reinterpret_cast<const float4*>(base);
+        kf[t] = *reinterpret_cast<const float4*>(base + (uint32_t)C * 4u);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vf[t][r] = 0.f;
+        int rv;
+        bool okv;
+        if (G > 0 && t == T - 1) {
+          if (r > 0) continue;                         // only the relay key lives in that tile
+          rv = rt_row;
+          okv = (g == 0);
+        } else {
+          rv = tok0 + (t * 16 + 4 * g + r) * tstep;
+          okv = rv < n_tok;
+        }
+        if ((p.dbg & 4) && okv) rv &= 63;
+        if (okv) vf[t][r] = *reinterpret_cast<const float*>(qkv_b + ((uint32_t)rv * row_q + col_v));
+      }
+    }
+  };
+
+  float4 kf[T], qf[T], kf_n[T], qf_n[T];
+  float vf[T][4], vf_n[T][4];
+  uint2 mt, mt_n;
+  if ((int)blockIdx.x < p.n_windows) request(kf, qf, vf, mt, blockIdx.x);
+  int it = 0;
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
+    // the next window of this workgroup is requested before this one is touched: its round trip
+    // to HBM hides behind the softmax/MFMA work below (the last request repeats a window: the
+    // instruction stream stays static, so the waits the compiler places stay partial)
+    const int wn = min(w + (int)gridDim.x, p.n_windows - 1);
+    if (HFL_V4_PF)
+      request(kf_n, qf_n, vf_n, mt_n, wn);
+    else if (it > 0)
+      request(kf, qf, vf, mt, w);
+
+    const int tstep = p.D;
+    const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
+    const int rt_row = (int)p.rt_row0 + w;
+    int4* s_qry = s_qry0 + (it & 1) * LP;
+    int2* s_key = s_key0 + (it & 1) * LP;
+    int* s_kbid = s_kbid0 + (it & 1) * LP;
+    if (owns) {
+      const int j = tid;
+      int bid = -1, row = -1;
+      int x = 0, y = 0, z = 0;
+      if (j < K) {
+        if (mt.y != 0xFFFFFFFFu) {
+          x = (int)(mt.x & 1023u); y = (int)((mt.x >> 10) & 1023u); z = (int)(mt.x >> 20);
+          bid = (int)mt.y;
+          row = tok0 + j * tstep;
+        }
+      } else if (G > 0 && j == K) {
+        row = rt_row;
+      }
+      s_key[j] = make_int2(4 * (R - x), 4 * (W + (R - y) * W + (R - z)));
+      s_kbid[j] = bid;
+      s_qry[j] = make_int4(4 * x, 4 * (y * W + z), bid, row);
+    }
+    __syncthreads();
+    // the relay token carries the batch id of the window's first token (pad window: B)
+    const int bid0 = s_kbid[0], bidl = s_kbid[K - 1];
+    const int rt_bid = bid0 >= 0 ? bid0 : p.batch;
+    const bool homog = __builtin_amdgcn_readfirstlane((bidl >= 0 && bid0 == bidl) ? 1 : 0) != 0;
+
+    // q/k bias + softmax scale (after the loads so that nothing waits between their issue)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      qf[t].x = (qf[t].x + bq.x) * scale2; qf[t].y = (qf[t].y + bq.y) * scale2;
+      qf[t].z = (qf[t].z + bq.z) * scale2; qf[t].w = (qf[t].w + bq.w) * scale2;
+      kf[t].x += bk.x; kf[t].y += bk.y; kf[t].z += bk.z; kf[t].w += bk.w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vf[t][r] += bv;
+    }
+
+    int kxa[TW][4], kyza[TW][4];
+    if (RPE) {
+#pragma unroll
+      for (int kt = 0; kt < TW; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int2 km = s_key[kt * 16 + 4 * g + r];
+          kxa[kt][r] = km.x;
+          kyza[kt][r] = km.y;
+        }
+    }
+
+    auto body = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+      for (int qt = 0; qt < TW; ++qt) {          // token queries; the relay query is handled below
+        const int4 qm = s_qry[qt * 16 + c];
+        const int qxa = qm.x + tabb, qyza = qm.y + tabb;
+
+        f32x4 s[T];
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf[qt].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf[qt].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf[qt].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf[qt].w, acc, 0, 0, 0);
+          s[kt] = acc;
+        }
+        if (RPE) {
+#pragma unroll
+          for (int kt = 0; kt < TW; ++kt) {
+            f32x4 bx, byz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bx[r] = *reinterpret_cast<lds_f32*>(kxa[kt][r] + qxa);
+              byz[r] = *reinterpret_cast<lds_f32*>(kyza[kt][r] + qyza);
+            }
+            s[kt] += bx + byz;
+          }
+        }
+        if (MASKED) {
+#pragma unroll
+          for (int kt = 0; kt < TW; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (s_kbid[kt * 16 + 4 * g + r] != qm.z) s[kt][r] += mask2;
+        }
+        float mx = kDeadValue;
+        float srt = kDeadValue;
+        if (G > 0) {   // relay key: position K = tile T-1, k-slot group 0, register 0; no RPE
+          srt = s[T - 1][0] + rt_add;
+          if (MASKED && rt_bid != qm.z) srt += mask2;
+          mx = srt;
+        }
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+          mx = att_max3(mx, s[kt][0], s[kt][1]);
+          mx = att_max3(mx, s[kt][2], s[kt][3]);
+        }
+        mx = att_max3(mx, __shfl_xor(mx, 16, 64), mx);
+        mx = att_max3(mx, __shfl_xor(mx, 32, 64), mx);
+        const f32x4 nmx4 = {-mx, -mx, -mx, -mx};
+        f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+          f32x4 e = s[kt] + nmx4;
+          e[0] = __builtin_amdgcn_exp2f(e[0]); e[1] = __builtin_amdgcn_exp2f(e[1]);
+          e[2] = __builtin_amdgcn_exp2f(e[2]); e[3] = __builtin_amdgcn_exp2f(e[3]);
+          s[kt] = e;
+          sum4 += e;
+        }
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+        float ert = 0.f;
+        if (G > 0) {
+          ert = __builtin_amdgcn_exp2f(srt - mx);
+          sum += ert;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r], vf[kt][r], o, 0, 0, 0);
+        }
+        if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(ert, vf[T - 1][0], o, 0, 0, 0);
+        // O rows are queries 4g+r of this tile; their 1/sum sits in lane (any group, c = 4g+r)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] *= __shfl(inv, (lane & 48) + 4 * g + r, 64);
+          const int orow = s_qry[qt * 16 + 4 * g + r].w;
+          if ((!MASKED || orow >= 0) && (!(p.dbg & 2) || o[r] == 1234.5f)) {
+            char* ob = out_b + ((uint32_t)orow * row_o);
+            if (p.out_split) {
+              uint16_t* o16 = reinterpret_cast<uint16_t*>(ob) + h * 16 + c;
+              const uint16_t hi = att_bf16_rne(o[r]);
+              o16[0] = hi;
+              o16[C] = hi;
+              o16[2 * C] = att_bf16_rne(o[r] - __uint_as_float((uint32_t)hi << 16));
+            } else {
+              reinterpret_cast<float*>(ob)[h * 16 + c] = o[r];
+            }
+          }
+        }
+      }
+
+      if (G > 0) {
+        // ---- the relay token as a QUERY: one row, done on the VALU instead of padding a 16-row
+        // MFMA tile with 15 dead queries.  No RPE for the relay row (octformer_backbone.py:78-80).
+        const int rbid = rt_bid;
+        const float4 qr = qf[T - 1];                  // lanes c == 0 hold row K = the relay query ...
+        float4 qrt;                                   // ... broadcast its 4g..4g+3 slice to the 16 lanes
+        qrt.x = __shfl(qr.x, lane & 48, 64); qrt.y = __shfl(qr.y, lane & 48, 64);
+        qrt.z = __shfl(qr.z, lane & 48, 64); qrt.w = __shfl(qr.w, lane & 48, 64);
+        float sr[TW];
+        float m = kDeadValue;
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+          float part = (qrt.x * kf[kt].x + qrt.y * kf[kt].y) + (qrt.z * kf[kt].z + qrt.w * kf[kt].w);
+          part += __shfl_xor(part, 16, 64);
+          part += __shfl_xor(part, 32, 64);           // score of key kt*16+c (replicated over g)
+          if (MASKED && s_kbid[kt * 16 + c] != rbid) part += mask2;
+          sr[kt] = part;
+          m = fmaxf(m, part);
+        }
+        const float4 kr = kf[T - 1];                  // row K of K, held by lanes c == 0
+        float srr = (qrt.x * __shfl(kr.x, lane & 48, 64) + qrt.y * __shfl(kr.y, lane & 48, 64)) +
+                    (qrt.z * __shfl(kr.z, lane & 48, 64) + qrt.w * __shfl(kr.w, lane & 48, 64));
+        srr += __shfl_xor(srr, 16, 64);
+        srr += __shfl_xor(srr, 32, 64);
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        m = fmaxf(m, srr);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+          sr[kt] = __builtin_amdgcn_exp2f(sr[kt] - m);
+          sum += sr[kt];
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 64);
+        const float err = __builtin_amdgcn_exp2f(srr - m);
+        const float inv = __builtin_amdgcn_rcpf(sum + err);
+        float acc = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc += __shfl(sr[kt], (lane & 48) | (4 * g + r), 64) * vf[kt][r];
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        const float vrt = __shfl(vf[T - 1][0], c, 64);     // V[relay][d = c] lives in the g == 0 lanes
+        acc = (acc + err * vrt) * inv;
+        const int orow = s_qry[K].w;
+        if (g == 0 && orow >= 0) {
+          char* ob = out_b + ((uint32_t)orow * row_o);
+          if (p.out_split) {
+            uint16_t* o16 = reinterpret_cast<uint16_t*>(ob) + h * 16 + c;
+            const uint16_t hi = att_bf16_rne(acc);
+            o16[0] = hi;
+            o16[C] = hi;
+            o16[2 * C] = att_bf16_rne(acc - __uint_as_float((uint32_t)hi << 16));
+          } else {
+            reinterpret_cast<float*>(ob)[h * 16 + c] = acc;
+          }
+        }
+      }
+    };
+    if (p.dbg & 1) {            // ablation: memory pattern only
+#pragma unroll
+      for (int qt = 0; qt < TW; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = s_qry[qt * 16 + 4 * g + r].w;
+          if (orow >= 0 && !(p.dbg & 2)) {
+            const float v = qf[qt].x + kf[qt].y + vf[qt][r];
+            char* ob = out_b + ((uint32_t)orow * row_o);
+            if (p.out_split) {
+              uint16_t* o16 = reinterpret_cast<uint16_t*>(ob) + h * 16 + c;
+              o16[0] = att_bf16_rne(v); o16[C] = o16[0]; o16[2 * C] = 0;
+            } else {
+              reinterpret_cast<float*>(ob)[h * 16 + c] = v;
+            }
+          }
+        }
+      if ((p.dbg & 2) && qf[0].x + kf[T - 1].y + vf[0][1] == 1234.5f) p.out[0] = 1.f;
+    } else if (homog)
+      body(std::false_type{});
+    else
+      body(std::true_type{});
+    if (HFL_V4_PF) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        kf[t] = kf_n[t];
+        qf[t] = qf_n[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[t][r] = vf_n[t][r];
+      }
+      mt = mt_n;
+    }
+  }
+}
+
+// expanded RPE table of v4: out (H, TS), TS = (W + W*W + 3) & ~3, W = 2R+1, R = 2^depth - 1 <= pos_bnd:
+//   out[h][i]             = table[(i - R + bnd), h] * log2e                       i in [0, W)   (x axis)
+//   out[h][W + iy*W + iz] = (table[nrpe + iy - R + bnd, h] + table[2 nrpe + iz - R + bnd, h]) * log2e
+__global__ void __launch_bounds__(256)
+rpe_expand_kernel(float* __restrict__ out, const float* __restrict__ table, int H, int bnd, int R) {
+  const int W = 2 * R + 1;
+  const int TS = (W + W * W + 3) & ~3;
+  const int nrpe = 2 * bnd + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * TS) return;
+  const int h = i / TS, e = i % TS;
+  float v = 0.f;
+  if (e < W) {
+    v = table[(e - R + bnd) * H + h];
+  } else if (e < W + W * W) {
+    const int iy = (e - W) / W, iz = (e - W) % W;
+    v = table[(nrpe + iy - R + bnd) * H + h] + table[(2 * nrpe + iz - R + bnd) * H + h];
+  }
+  out[i] = v * 1.4426950408889634f;
+}
+
+static int g_window_variant = 4;
+static int g_window_v4_wgs_per_cu = 2;
+static int g_window_dbg = 0;
 static int g_window_wgs_per_cu = 3;
 static int g_window_v2_wgs_per_cu = 16;
 static int g_window_heads_per_wg = 4;
@@ -739,7 +1160,32 @@ static int launch_window(const WinParams& p, hipStream_t s) {
     const int capx = hfl_num_cus() * g_window_v2_wgs_per_cu / groups;
     if (bx > capx) bx = capx;
     dim3 grid((unsigned)bx, (unsigned)groups);
-    if (g_window_variant == 3) {
+    const int64_t rows_total = G > 0 ? p.rt_row0 + p.n_windows : p.n_tokens;
+    const int R4 = (1 << (p.depth > 0 && p.depth <= 5 ? p.depth : 0)) - 1, W4 = 2 * R4 + 1;
+    const size_t ts4 = p.table ? (size_t)((W4 + W4 * W4 + 3) & ~3) : 0;
+    const size_t lds4 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts4 * 4;
+    if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
+        (p.table == nullptr || p.rpe2 != nullptr) && rows_total * 3 * p.H * 16 * 4 < (int64_t)1 << 32 &&
+        lds4 <= 72 * 1024 && hpw * 64 >= LP) {
+      int px = hfl_num_cus() * g_window_v4_wgs_per_cu / groups;
+      if (px < 1) px = 1;
+      if (px > p.n_windows) px = p.n_windows;
+      dim3 grid4((unsigned)px, (unsigned)groups);
+      if (lds4 > 48 * 1024) {
+        hipError_t e;
+        if (p.table == nullptr)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v4<T, G, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        else
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v4<T, G, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        if (e != hipSuccess) return (int)e;
+      }
+      if (p.table == nullptr)
+        window_attn_kernel_v4<T, G, false><<<grid4, hpw * 64, lds4, s>>>(p);
+      else
+        window_attn_kernel_v4<T, G, true><<<grid4, hpw * 64, lds4, s>>>(p);
+    } else if (g_window_variant == 3) {
       // persistent: about g_window_wgs_per_cu workgroups per CU in total, each walking a strided
       // list of windows with the next window's loads in flight
       const size_t lds3 = (p.table ? (size_t)hpw * 3 * nrpe * 4 : 0) + (size_t)2 * LP * (16 + 16 + 4 + 4);
@@ -866,6 +1312,20 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_cpe_chunk(value);
     return HFL_OK;
   }
+  const char* k8 = "window_debug";
+  i = 0;
+  while (k8[i] != 0 && key[i] == k8[i]) ++i;
+  if (k8[i] == 0 && key[i] == 0) {
+    g_window_dbg = value;
+    return HFL_OK;
+  }
+  const char* k7 = "window_v4_wgs_per_cu";
+  i = 0;
+  while (k7[i] != 0 && key[i] == k7[i]) ++i;
+  if (k7[i] == 0 && key[i] == 0) {
+    g_window_v4_wgs_per_cu = value;
+    return HFL_OK;
+  }
   const char* k6 = "window_v2_wgs_per_cu";
   i = 0;
   while (k6[i] != 0 && key[i] == k6[i]) ++i;
@@ -907,6 +1367,9 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
   WinParams p;
   p.out = static_cast<float*>(out); p.qkv = qkv; p.meta = tok_meta; p.table = rpe_table;
   p.qkv_bias = qkv_bias; p.out_split = out_split3;
+  p.rpe2 = rpe_table != nullptr ? d->rpe_expanded : nullptr;
+  p.depth = d->depth;
+  p.dbg = g_window_dbg;
   p.n_tokens = d->n_tokens; p.rt_row0 = d->rt_row0; p.n_windows = d->n_windows;
   p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd;
   p.batch = d->batch_size; p.scale = d->scale;
@@ -930,6 +1393,21 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
     case 5: return launch_window<5, 1>(p, s);
     default: return HFL_EINVAL;
   }
+}
+
+int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth) {
+  if (n_heads <= 0 || depth < 1 || depth > 5 || ((1 << depth) - 1) > pos_bnd) return 0;
+  const int W = 2 * ((1 << depth) - 1) + 1;
+  return (int64_t)n_heads * ((W + W * W + 3) & ~3);
+}
+
+int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth,
+                          hfl_stream_t stream) {
+  const int64_t n = hfl_window_rpe_expand_size(n_heads, pos_bnd, depth);
+  if (n <= 0 || out == nullptr || rpe_table == nullptr) return HFL_EINVAL;
+  rpe_expand_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      out, rpe_table, n_heads, pos_bnd, (1 << depth) - 1);
+  HFL_RETURN_LAST_ERROR();
 }
 
 int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_rows,

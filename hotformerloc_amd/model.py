@@ -61,6 +61,7 @@ def _add_ln(x, y, m: nn.LayerNorm):
 # (hi|hi|lo) x (hi|lo|hi) operands with fp32 accumulation/output (include/hotformerloc_hip.h section 9).
 _GEMM_MODE = os.environ.get('HFL_GEMM', 'bf16x3')
 _PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
+_SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 
 
 def set_pyramid_streams(enabled: bool):
@@ -500,17 +501,27 @@ class HOTFormerStage(nn.Module):
                 # three CUDA streams too, hotformerloc_backbone.py:604-633): the coarse depths'
                 # small GEMMs and kernels overlap the fine depth's.  Fork/join discipline: side
                 # streams wait for the main stream's event, the main stream waits for theirs.
+                # Only SMALL depths go to a side stream (_SIDE_STREAM_MAX_ROWS): they are the ones
+                # that cannot fill 256 CUs, and hipBLASLt's stream-K GEMMs (workgroups that wait on
+                # their peers' partial tiles) dead-lock when several chip-filling ones share the CUs.
                 main = torch.cuda.current_stream()
                 side = self._side_streams(data.device)
+                keep = []         # inputs allocated on the main stream stay alive until the join
+                used = []
                 for j, d in enumerate(depths):
-                    if j == 0:
+                    if j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS:
                         continue
                     side[j - 1].wait_stream(main)
+                    keep.append(bufs[d])
                     with torch.cuda.stream(side[j - 1]):
                         bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
-                bufs[depths[0]] = self.hosa_blocks[0][i](bufs[depths[0]], plan, depths[0])
-                for st in side:
-                    main.wait_stream(st)
+                    used.append(j)
+                for j, d in enumerate(depths):
+                    if j not in used:
+                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+                for j in used:
+                    main.wait_stream(side[j - 1])
+                del keep
             else:
                 for j, d in enumerate(depths):
                     bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)

@@ -6,6 +6,7 @@ never synchronises.  Inputs must live on the GPU -- there is no CPU path.
 """
 
 import ctypes
+import weakref
 
 import torch
 
@@ -304,6 +305,31 @@ def octree_gather(data, neigh):
 
 
 # ---------------------------------------------------------------------- attention
+_RPE2_CACHE = {}        # (id(table), depth) -> (weakref to table, version, expanded table)
+
+
+def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int):
+    """Expanded relative-position table of the two-lookup window kernel (hfl_window_rpe_expand), cached
+    per (table, depth) and rebuilt when the table is modified in place.  None when the depth is not
+    eligible (deeper than 5 or coordinates beyond pos_bnd)."""
+    lib = _native.load()
+    n = lib.hfl_window_rpe_expand_size(n_heads, pos_bnd, depth)
+    if n <= 0:
+        return None
+    key = (id(rpe_table), depth)
+    hit = _RPE2_CACHE.get(key)
+    if hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version:
+        return hit[2]
+    out = torch.empty(n, dtype=torch.float32, device=rpe_table.device)
+    src = _f32c(rpe_table.detach())
+    check(lib.hfl_window_rpe_expand(out.data_ptr(), src.data_ptr(), n_heads, pos_bnd, depth, _stream()),
+          'hfl_window_rpe_expand')
+    if len(_RPE2_CACHE) > 512:
+        _RPE2_CACHE.clear()
+    _RPE2_CACHE[key] = (weakref.ref(rpe_table), rpe_table._version, out)
+    return out
+
+
 def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, patch_size: int,
                      dilation: int, n_relay: int, n_heads: int, batch_size: int, rt_row0: int = 0,
                      depth: int = 0, qkv_bias=None, out_split: bool = False):
@@ -327,8 +353,11 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
                           batch_size=batch_size, scale=16 ** -0.5, depth=depth)
     table_ptr = None
     if rpe_table is not None:
-        rpe_table = _f32c(rpe_table)
         assert tuple(rpe_table.shape) == (3 * (2 * desc.pos_bnd + 1), n_heads)
+        expanded = rpe_expand(rpe_table, n_heads, desc.pos_bnd, depth)   # keeps the tensor alive below
+        if expanded is not None:
+            desc.rpe_expanded = expanded.data_ptr()
+        rpe_table = _f32c(rpe_table)
         table_ptr = rpe_table.data_ptr()
     used = n_tokens + (n_windows if n_relay else 0)          # rows the kernel touches
     seq = patch_size + n_relay

@@ -162,6 +162,8 @@ typedef struct {
   int32_t batch_size;   /* B: batch id given to padding                                  */
   float scale;          /* 16^-0.5                                                       */
   int32_t depth;        /* octree depth of the tokens (coords < 2^depth); 0 = unknown    */
+  const float* rpe_expanded; /* optional: hfl_window_rpe_expand(rpe_table, depth) output, enables
+                              * the two-lookup forward kernel; NULL = three axis lookups     */
 } hfl_window_attn_desc;
 
 /* qkv (rows, 3*H*16): per row [q(H,16) | k(H,16) | v(H,16)], the layout produced by
@@ -181,6 +183,14 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
 int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
                                 const uint32_t* tok_meta, const float* rpe_table,
                                 const hfl_window_attn_desc* desc, int out_split3, hfl_stream_t stream);
+
+/* Expanded relative-position table for the forward kernel: per head the x-axis table restricted to
+ * |dx| <= R = 2^depth - 1 followed by the pre-added (dy, dz) table of (2R+1)^2 entries, scaled by
+ * log2(e).  Valid when R <= pos_bnd and depth <= 5 (size() returns 0 otherwise: use the plain path).
+ * out holds hfl_window_rpe_expand_size() floats; rebuild it whenever rpe_table changes. */
+int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth);
+int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth,
+                          hfl_stream_t stream);
 
 /* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (1 = first
  * version, 2 = default), "window_heads_per_wg" (waves per workgroup of the window kernel,

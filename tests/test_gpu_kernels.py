@@ -269,17 +269,28 @@ def test_window_attention_matches_oracle(cfg, sizes):
         # depth given: the kernel may drop the RPE clamp (coordinates < 2^depth <= pos_bnd)
         got_d = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth],
                                      table.to(DEV), nt, W, K, dil, G, H, B, rt_row0=nt, depth=depth).cpu()
-        assert torch.equal(got_d[:nt], got[:nt])
+        err = (got_d[:nt] - want_tok).abs().max().item()      # two-lookup kernel (expanded table)
+        assert err < 2e-5, ('depth given', cfg, depth, G, dil, err)
+        if G:
+            real_w = -(-nt // K)
+            assert (got_d[nt:nt + real_w] - want[:real_w, 0]).abs().max().item() < 2e-5
+        got_s = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth],
+                                     table.to(DEV), nt, W, K, dil, G, H, B, rt_row0=nt, depth=depth,
+                                     out_split=True).float().cpu()
+        rec = got_s[:, :C] + got_s[:, 2 * C:]                     # hi + lo of the split output
+        assert torch.equal(got_s[:, :C], got_s[:, C:2 * C])
+        assert (rec[:nt] - want_tok).abs().max().item() < 3e-5
         if G:
             real = -(-nt // K)                       # windows that hold at least one token
             err = (got[nt:nt + real] - want[:real, 0]).abs().max().item()
             assert err < 2e-5, ('relay rows', cfg, depth, err)
             assert torch.isfinite(got).all()
         # no RPE (disable_RPE=True path)
-        got0 = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth], None,
-                                    nt, W, K, dil, G, H, B, rt_row0=nt).cpu()
         want0 = hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(-1, K + G, C)
-        assert (got0[:nt] - oplan.from_windows(want0[:, G:], depth, dil > 1)).abs().max() < 2e-5
+        for dd in (0, depth):
+            got0 = ops.window_attention(torch.cat([qkv_tok, qkv_rt]).to(DEV), plan.meta[depth], None,
+                                        nt, W, K, dil, G, H, B, rt_row0=nt, depth=dd).cpu()
+            assert (got0[:nt] - oplan.from_windows(want0[:, G:], depth, dil > 1)).abs().max() < 2e-5
 
 
 @pytest.mark.parametrize('cfg,sizes,depth', [('wild-places', [4096, 30, 2500, 4096], 7),

@@ -8,8 +8,12 @@ params, depth = load_config('wild-places')
 octree = build_batch_octree(syn.make_clouds(2, 32, 4096, params.coordinates), depth, 2, 'cuda')
 plan = WindowPlan(octree, 48, 4, 5, 2, 3, 1, None)
 g = torch.Generator(device='cuda').manual_seed(0)
-split = len(sys.argv) > 1 and sys.argv[1] == 'split'
-for d, H, G in ((4, 16, 1), (5, 8, 0)):
+split = 'split' in sys.argv[1:]
+from hotformerloc_amd import _native
+for a in sys.argv[1:]:
+    if a.startswith('v'):
+        _native.load().hfl_set_variant(b'window_attention', int(a[1:]))
+for d, H, G in ((4, 16, 1),):
     C = H * 16
     nt, W = plan.n_tokens[d], plan.n_windows[d]
     qkv = torch.randn(nt + (W if G else 0), 3 * C, device='cuda', generator=g)

@@ -37,18 +37,20 @@ def main():
         nbytes = rows * C * 16
         flops = 4 * (K + G) ** 2 * C * (-(-nt // K))
         res = {}
-        for name, var, hpw, wgs in (('v2/cap16', 2, 4, 16), ('v2/cap8', 2, 4, 8), ('v2/cap6', 2, 4, 6), ('v2/cap4', 2, 4, 4),
-                                    ('v2/cap3', 2, 4, 3), ('v2/hpw2/cap6', 2, 2, 6), ('v2/hpw1/cap12', 2, 1, 12)):
+        for name, var, wgs, dbg in (('v2', 2, 16, 0), ('v4/cap2', 4, 2, 0), ('v4/cap3', 4, 3, 0), ('v4/cap4', 4, 4, 0), ('v4/cap6', 4, 6, 0), ('v4/cap8', 4, 8, 0),
+                                    ('v4 cached+nostore', 4, 3, 6)):
             lib.hfl_set_variant(b'window_attention', var)
-            lib.hfl_set_variant(b'window_heads_per_wg', hpw if hpw else H)
-            lib.hfl_set_variant(b'window_v2_wgs_per_cu', wgs)
-            f = lambda: ops.window_attention(qkv, plan.meta[d], table, nt, W, K, dil, G, H, B, rt_row0=nt, depth=d)
-            med, mn = timeit(f)
-            res[name] = med
-            print('window_attn d=%d H=%d G=%d D=%d %-9s med %7.1f us  min %7.1f us  %6.0f GB/s  %5.1f TF/s' %
-                  (d, H, G, dil, name, med, mn, nbytes / med / 1e3, flops / med / 1e6))
-    lib.hfl_set_variant(b'window_attention', 2)
+            lib.hfl_set_variant(b'window_v4_wgs_per_cu', wgs)
+            lib.hfl_set_variant(b'window_debug', dbg)
+            for split in (False, True):
+                f = lambda: ops.window_attention(qkv, plan.meta[d], table, nt, W, K, dil, G, H, B, rt_row0=nt, depth=d, out_split=split)
+                med, mn = timeit(f)
+                print('window_attn d=%d H=%d G=%d D=%d split=%d %-18s med %7.1f us  min %7.1f us  %6.0f GB/s  %5.1f TF/s' %
+                      (d, H, G, dil, split, name, med, mn, (nbytes + (rows * C * 2 if split else 0)) / med / 1e3, flops / med / 1e6))
+        lib.hfl_set_variant(b'window_debug', 0)
+    lib.hfl_set_variant(b'window_attention', 4)
     lib.hfl_set_variant(b'window_heads_per_wg', 4)
+    lib.hfl_set_variant(b'window_v4_wgs_per_cu', 4)
     lib.hfl_set_variant(b'window_v2_wgs_per_cu', 16)
     # CPE
     for d, C in ((md, 128), (md - 1, 256), (md - 2, 256)):
