@@ -46,6 +46,7 @@ def parse():
                     help="Linear layers: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) operands, fp32 "
                          "accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
+    ap.add_argument('--attn-variant', type=int, default=0, help='A/B: window attention kernel variant (0 = default)')
     ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8, help='clouds in the CPU baseline sample')
@@ -125,6 +126,9 @@ def main():
     batch = {'octree': octree}
     torch.cuda.synchronize()
     log('octree ready', octree.nnum_nempty.tolist())
+    if args.attn_variant:
+        from hotformerloc_amd import _native
+        _native.load().hfl_set_variant(b'window_attention', args.attn_variant)
     from hotformerloc_amd.distributed import all_gather_descriptors
 
     if args.train:
@@ -163,6 +167,22 @@ def main():
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         kern = timer.summary()
+        # Roofline leg: the same K steps once more with the pyramid depths on ONE stream.  In the timed
+        # region above three streams share the GPU, so a kernel's start-to-end HIP-event time includes
+        # the CUs it lent to its neighbours; serialised, the events bracket the kernel alone (this is
+        # also what rocprofv3 --kernel-trace reports: profiles/r01_c_summary.md).  Not part of `value`.
+        kern_iso = None
+        if not args.no_streams and not args.train:
+            from hotformerloc_amd.model import set_pyramid_streams
+            set_pyramid_streams(False)
+            model(batch)
+            torch.cuda.synchronize()
+            with ops.KernelTimer() as timer_iso:
+                for _ in range(args.steps):
+                    model(batch)
+                torch.cuda.synchronize()
+            kern_iso = timer_iso.summary()
+            set_pyramid_streams(True)
     log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
     assert torch.isfinite(y).all()
 
@@ -173,7 +193,8 @@ def main():
 
     if rank == 0:
         total_clouds = args.batch * world * args.steps
-        n, ms, nbytes, flops = kern.get('hfl_window_attention_fwd', (0, 0.0, 0, 0))
+        n_c, ms_c, nbytes_c, _ = kern.get('hfl_window_attention_fwd', (0, 0.0, 0, 0))
+        n, ms, nbytes, flops = (kern_iso or kern).get('hfl_window_attention_fwd', (0, 0.0, 0, 0))
         roof = None
         if n:
             gbs = nbytes / (ms * 1e-3) / 1e9
@@ -182,7 +203,7 @@ def main():
             if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
                 # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
-                rec = json.load(open(pmc)).get('window_attn_kernel_v2')
+                rec = json.load(open(pmc)).get('window_attn_kernel_v4') or json.load(open(pmc)).get('window_attn_kernel_v2')
                 if rec:
                     traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json'
             roof = {'kernel': 'hfl_window_attention_fwd', 'bound': 'hbm',
@@ -191,7 +212,11 @@ def main():
                     'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                     'algorithmic_bytes_per_launch': int(nbytes / n),
                     'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 2),
-                    'mfma_frac': round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+                    'mfma_frac': round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                    'timing': ('HIP events per launch over %d steps, pyramid streams serialised (re-run right '
+                               'after the timed region)' % args.steps) if kern_iso else
+                              'HIP events per launch over the timed region',
+                    'frac_in_timed_region': round(nbytes_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if n_c else None}
         others = {}
         for name, (kn, kms, kb, kf) in kern.items():
             others[name] = {'launches_per_step': kn // args.steps,

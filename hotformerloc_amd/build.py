@@ -21,7 +21,7 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 # per-file extras.  attention.hip: MFMA results feed VALU softmax code directly, so keep the MFMA
 # destination in arch VGPRs (the default heuristic parks it in AGPRs and pays a v_accvgpr_read per score)
-EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'] + os.environ.get('HFL_ATTENTION_FLAGS', '').split()}
+EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _hipcc() -> str:

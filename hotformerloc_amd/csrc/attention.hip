@@ -744,14 +744,15 @@ window_attn_kernel_v3(const WinParams p) {
 //   * P stays un-normalised into the P V MFMAs; the 1/sum lands on the 4 output registers;
 //   * v_rcp_f32 instead of an IEEE divide, 32-bit byte offsets from the qkv / out base pointers
 //     (saddr + voffset addressing; the caller falls back to v2 when a buffer exceeds 4 GiB).
-#ifndef HFL_V4_PF
-#define HFL_V4_PF 1
-#endif
-#ifndef HFL_V4_WAVES
-#define HFL_V4_WAVES 2
-#endif
+// Occupancy target: 3 waves per SIMD (168 VGPRs) when the window has at most 3 token tiles (K = 48),
+// 2 otherwise (K = 64 needs ~190 VGPRs; forcing 3 spills).  Measured with back-to-back launches
+// (tools/kbench.py): 3 waves 109 us vs 2 waves + next-window register prefetch 161 us at depth 4 --
+// the prefetch variant lost to plain occupancy and was dropped.
+constexpr int v4_waves_per_simd(int T, int G) { return (T - G) <= 3 ? 3 : 2; }
+
 template <int T, int G, bool RPE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HFL_V4_WAVES, HFL_V4_WAVES)))
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(v4_waves_per_simd(T, G), v4_waves_per_simd(T, G))))
 window_attn_kernel_v4(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LP = T * 16;
@@ -852,20 +853,12 @@ window_attn_kernel_v4(const WinParams p) {
     }
   };
 
-  float4 kf[T], qf[T], kf_n[T], qf_n[T];
-  float vf[T][4], vf_n[T][4];
-  uint2 mt, mt_n;
-  if ((int)blockIdx.x < p.n_windows) request(kf, qf, vf, mt, blockIdx.x);
+  float4 kf[T], qf[T];
+  float vf[T][4];
+  uint2 mt;
   int it = 0;
   for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
-    // the next window of this workgroup is requested before this one is touched: its round trip
-    // to HBM hides behind the softmax/MFMA work below (the last request repeats a window: the
-    // instruction stream stays static, so the waits the compiler places stay partial)
-    const int wn = min(w + (int)gridDim.x, p.n_windows - 1);
-    if (HFL_V4_PF)
-      request(kf_n, qf_n, vf_n, mt_n, wn);
-    else if (it > 0)
-      request(kf, qf, vf, mt, w);
+    request(kf, qf, vf, mt, w);
 
     const int tstep = p.D;
     const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
@@ -1100,16 +1093,6 @@ window_attn_kernel_v4(const WinParams p) {
       body(std::false_type{});
     else
       body(std::true_type{});
-    if (HFL_V4_PF) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        kf[t] = kf_n[t];
-        qf[t] = qf_n[t];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vf[t][r] = vf_n[t][r];
-      }
-      mt = mt_n;
-    }
   }
 }
 
@@ -1135,7 +1118,7 @@ rpe_expand_kernel(float* __restrict__ out, const float* __restrict__ table, int 
 }
 
 static int g_window_variant = 4;
-static int g_window_v4_wgs_per_cu = 2;
+static int g_window_v4_wgs_per_cu = 1;   // multiples of the resident workgroup count
 static int g_window_dbg = 0;
 static int g_window_wgs_per_cu = 3;
 static int g_window_v2_wgs_per_cu = 16;
@@ -1167,7 +1150,13 @@ static int launch_window(const WinParams& p, hipStream_t s) {
     if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
         (p.table == nullptr || p.rpe2 != nullptr) && rows_total * 3 * p.H * 16 * 4 < (int64_t)1 << 32 &&
         lds4 <= 72 * 1024 && hpw * 64 >= LP) {
-      int px = hfl_num_cus() * g_window_v4_wgs_per_cu / groups;
+      // persistent grid: exactly the workgroups that are resident at once (waves-per-SIMD target of
+      // the kernel, LDS), times g_window_v4_wgs_per_cu
+      int resident = v4_waves_per_simd(T, G) * 4 / hpw;
+      const int lds_fit = (int)((size_t)160 * 1024 / (lds4 + 512));
+      if (resident > lds_fit) resident = lds_fit;
+      if (resident < 1) resident = 1;
+      int px = hfl_num_cus() * resident * g_window_v4_wgs_per_cu / groups;
       if (px < 1) px = 1;
       if (px > p.n_windows) px = p.n_windows;
       dim3 grid4((unsigned)px, (unsigned)groups);

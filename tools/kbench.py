@@ -6,12 +6,17 @@ import torch
 from hotformerloc_amd import build_batch_octree, load_config, ops, _native, synthetic as syn
 from hotformerloc_amd.plan import WindowPlan
 
-def timeit(fn, rounds=20):
+def timeit(fn, rounds=12, inner=10):
+    """median / min microseconds per call; `inner` calls are queued back to back between the two
+    events so that host launch overhead (tens of us per ctypes call) does not count."""
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     ts = []
     for _ in range(rounds):
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3 / inner)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 
@@ -37,12 +42,11 @@ def main():
         nbytes = rows * C * 16
         flops = 4 * (K + G) ** 2 * C * (-(-nt // K))
         res = {}
-        for name, var, wgs, dbg in (('v2', 2, 16, 0), ('v4/cap2', 4, 2, 0), ('v4/cap3', 4, 3, 0), ('v4/cap4', 4, 4, 0), ('v4/cap6', 4, 6, 0), ('v4/cap8', 4, 8, 0),
-                                    ('v4 cached+nostore', 4, 3, 6)):
+        for name, var, wgs, dbg in (('v2', 2, 16, 0), ('v4/x1', 4, 1, 0), ('v4/x2', 4, 2, 0), ('v4/x3', 4, 3, 0)):
             lib.hfl_set_variant(b'window_attention', var)
             lib.hfl_set_variant(b'window_v4_wgs_per_cu', wgs)
             lib.hfl_set_variant(b'window_debug', dbg)
-            for split in (False, True):
+            for split in (True,):
                 f = lambda: ops.window_attention(qkv, plan.meta[d], table, nt, W, K, dil, G, H, B, rt_row0=nt, depth=d, out_split=split)
                 med, mn = timeit(f)
                 print('window_attn d=%d H=%d G=%d D=%d split=%d %-18s med %7.1f us  min %7.1f us  %6.0f GB/s  %5.1f TF/s' %
