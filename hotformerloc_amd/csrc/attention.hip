@@ -1276,6 +1276,7 @@ relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
 extern "C" {
 
 extern "C" void hfl_internal_set_cpe_chunk(int rows);
+extern "C" void hfl_internal_set_cpe_variant(int v, int wgs);
 extern "C" void hfl_internal_set_linear_ablate(int v);
 /* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
 int hfl_set_variant(const char* key, int value) {
@@ -1292,6 +1293,20 @@ int hfl_set_variant(const char* key, int value) {
   while (k4[i] != 0 && key[i] == k4[i]) ++i;
   if (k4[i] == 0 && key[i] == 0) {
     hfl_internal_set_linear_ablate(value);
+    return HFL_OK;
+  }
+  const char* k9 = "cpe_variant";
+  i = 0;
+  while (k9[i] != 0 && key[i] == k9[i]) ++i;
+  if (k9[i] == 0 && key[i] == 0) {
+    hfl_internal_set_cpe_variant(value, 0);
+    return HFL_OK;
+  }
+  const char* k10 = "cpe_lds_wgs_per_cu";
+  i = 0;
+  while (k10[i] != 0 && key[i] == k10[i]) ++i;
+  if (k10[i] == 0 && key[i] == 0) {
+    hfl_internal_set_cpe_variant(-1, value);
     return HFL_OK;
   }
   const char* k3 = "cpe_chunk_rows";

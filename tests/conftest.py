@@ -12,6 +12,17 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'timeout: per-test time limit (pytest-timeout)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress should fail with a stack dump, not stall the run
+    (pytest-timeout is part of the image; without it the marker is inert)."""
+    if not config.pluginmanager.hasplugin('timeout'):
+        return
+    for item in items:
+        if 'gpu' in item.keywords and item.get_closest_marker('timeout') is None:
+            item.add_marker(pytest.mark.timeout(600))
 
 
 @pytest.fixture(scope='session')

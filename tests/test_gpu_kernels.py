@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from hotformerloc_amd import Octree, Points, merge_octrees, build_batch_octree, load_config, ops
+from hotformerloc_amd import _native, Octree, Points, merge_octrees, build_batch_octree, load_config, ops
 from hotformerloc_amd import dwconv as hdw
 from hotformerloc_amd import synthetic as syn
 from hotformerloc_amd.plan import WindowPlan
@@ -207,11 +207,17 @@ def test_cpe_fused_and_gather():
               'c.norm.bias': 0.1 * torch.randn(C, generator=g)}
         want = hotformer_ref.cpe(x, sd, 'c', ref, depth)
         neigh = dev.get_neigh(depth, '333', 1, True)
-        for residual in (False, True):
-            got = ops.cpe_forward(x.to(DEV), sd['c.conv.weights'].to(DEV), sd['c.norm.weight'].to(DEV),
-                                  sd['c.norm.bias'].to(DEV), neigh, residual).cpu()
-            w = want + x if residual else want
-            assert torch.allclose(got, w, atol=2e-5, rtol=1e-5), (depth, C, residual)
+        lib = _native.load()
+        try:
+            for variant in (0, 1):                     # direct gathers / LDS-staged de-duplicated gathers
+                lib.hfl_set_variant(b'cpe_variant', variant)
+                for residual in (False, True):
+                    got = ops.cpe_forward(x.to(DEV), sd['c.conv.weights'].to(DEV), sd['c.norm.weight'].to(DEV),
+                                          sd['c.norm.bias'].to(DEV), neigh, residual).cpu()
+                    w = want + x if residual else want
+                    assert torch.allclose(got, w, atol=2e-5, rtol=1e-5), (depth, C, residual, variant)
+        finally:
+            lib.hfl_set_variant(b'cpe_variant', 0)
     # gather == octree2col, both neighbour kinds and a 3-channel input
     for depth, C, kernel, stride in ((7, 3, '333', 1), (6, 64, '333', 1), (6, 64, '222', 2), (7, 32, '222', 2)):
         n = int(ref.nnum_nempty[depth])

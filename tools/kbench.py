@@ -64,11 +64,21 @@ def main():
         gm = torch.ones(C, device='cuda'); bt = torch.zeros(C, device='cuda')
         neigh = plan.neigh(d)
         nb = n * C * 8 + n * 27 * 4
-        for chunk in (0,):
-            lib.hfl_set_variant(b'cpe_chunk_rows', chunk)
-            med, mn = timeit(lambda: ops.cpe_forward(x, w, gm, bt, neigh, True))
-            print('cpe d=%d C=%d n=%d chunk=%4d med %7.1f us  min %7.1f us  %6.0f GB/s' % (d, C, n, chunk, med, mn, nb / med / 1e3))
-        lib.hfl_set_variant(b'cpe_chunk_rows', 0)
+        ref = None
+        for var, wgs in ((0, 0), (1, 2), (1, 3), (1, 4), (1, 6)):
+            lib.hfl_set_variant(b'cpe_variant', var)
+            if wgs:
+                lib.hfl_set_variant(b'cpe_lds_wgs_per_cu', wgs)
+            f = lambda: ops.cpe_forward(x, w, gm, bt, neigh, True)
+            med, mn = timeit(f)
+            o = f()
+            if ref is None:
+                ref = o
+            else:
+                assert (o - ref).abs().max().item() < 2e-5, (o - ref).abs().max().item()
+            print('cpe d=%d C=%d n=%d variant=%d wgs/cu=%d med %7.1f us  min %7.1f us  %6.0f GB/s' % (d, C, n, var, wgs, med, mn, nb / med / 1e3))
+        lib.hfl_set_variant(b'cpe_variant', 0)
+        lib.hfl_set_variant(b'cpe_lds_wgs_per_cu', 3)
         med, mn = timeit(lambda: torch.nn.functional.layer_norm(x, (C,), gm, bt))
         print('   torch LN same shape   med %7.1f us  %6.0f GB/s' % (med, n * C * 8 / med / 1e3))
         y = torch.randn_like(x)
