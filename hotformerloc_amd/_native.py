@@ -72,6 +72,7 @@ SIGNATURES = {
     'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
+    'hfl_gemm_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_window_rpe_expand_size': (c_int64, [c_int, c_int, c_int]),
     'hfl_window_rpe_expand': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -113,7 +114,8 @@ def load():
 def check(rc: int, what: str):
     if rc != 0:
         kind = {-1: 'HFL_EINVAL (unsupported shape/argument)',
-                -2: 'HFL_ECAPACITY (input exceeds a kernel limit)'}.get(rc, 'hipError %d' % rc)
+                -2: 'HFL_ECAPACITY (input exceeds a kernel limit)'}.get(
+                    rc, 'hipBLASLt status %d' % (-100 - rc) if rc <= -100 else 'hipError %d' % rc)
         raise NativeLibraryError('%s failed: %s' % (what, kind))
 
 

@@ -16,9 +16,12 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libhotformerloc_hip.so'
 ARCH = 'gfx950'
-SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'window_misc.hip', 'attention.hip', 'linear.hip']
+SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'window_misc.hip', 'attention.hip', 'linear.hip', 'gemm_lt.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
+# hipBLASLt for hfl_gemm_bf16 (the ROCm copy that matches the headers; rpath so the loader finds it)
+ROCM = os.environ.get('ROCM_PATH', '/opt/rocm')
+LINK_FLAGS = ['-L' + os.path.join(ROCM, 'lib'), '-lhipblaslt', '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]
 # per-file extras.  attention.hip: MFMA results feed VALU softmax code directly, so keep the MFMA
 # destination in arch VGPRs (the default heuristic parks it in AGPRs and pays a v_accvgpr_read per score)
 EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
@@ -68,7 +71,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
     lib = os.path.join(LIBDIR, LIBNAME)
     if force or jobs or not os.path.exists(lib):
-        cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs
+        cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs + LINK_FLAGS
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr)

@@ -62,6 +62,7 @@ def _add_ln(x, y, m: nn.LayerNorm):
 _GEMM_MODE = os.environ.get('HFL_GEMM', 'bf16x3')
 _PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
 _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
+_LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
 
 def set_pyramid_streams(enabled: bool):
@@ -101,6 +102,12 @@ def _w3(lin: nn.Linear):
 def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
     """proj -> +residual -> LN2 -> fc1 -> GELU -> fc2 -> +residual with every bias folded into
     the element-wise kernel that follows its GEMM."""
+    if _LT_EPILOGUE:
+        # bias + residual ride in the GEMM launch (hfl_gemm_bf16): no pass over the residual stream
+        x = ops.gemm_bf16(attn_out3, _w3(attn.proj), bias=attn.proj.bias, residual=x)
+        h3 = ops.layer_norm_split3(x, norm2.weight, norm2.bias, norm2.eps)
+        g3 = ops.bias_gelu_split3(ops.split_mm(h3, _w3(mlp.fc1)), mlp.fc1.bias)
+        return ops.gemm_bf16(g3, _w3(mlp.fc2), bias=mlp.fc2.bias, residual=x)
     p = ops.split_mm(attn_out3, _w3(attn.proj))
     x, h3 = ops.add_layer_norm_split3(x, p, norm2.weight, norm2.bias, norm2.eps, add_bias=attn.proj.bias)
     g3 = ops.bias_gelu_split3(ops.split_mm(h3, _w3(mlp.fc1)), mlp.fc1.bias)

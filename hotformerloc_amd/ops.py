@@ -289,6 +289,25 @@ def split_mm(a3: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     return torch.mm(a3, w3.t(), out_dtype=torch.float32)
 
 
+def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None) -> torch.Tensor:
+    """fp32 (rows, N) = A3 @ W3^T [+ bias] [+ residual] in one hipBLASLt launch (hfl_gemm_bf16): the
+    Linear + bias + residual add of a transformer block without a pass over the residual stream."""
+    _dev(a3, w3, bias, residual)
+    assert a3.dtype == torch.bfloat16 and w3.dtype == torch.bfloat16 and a3.is_contiguous() and w3.is_contiguous()
+    m, k = a3.shape
+    n = w3.shape[0]
+    assert w3.shape[1] == k
+    out = torch.empty((m, n), dtype=torch.float32, device=a3.device)
+    if residual is not None:
+        residual = _f32c(residual)
+        assert tuple(residual.shape) == (m, n)
+    check(_native.load().hfl_gemm_bf16(out.data_ptr(), a3.data_ptr(), w3.data_ptr(),
+                                       None if bias is None else _f32c(bias).data_ptr(),
+                                       None if residual is None else residual.data_ptr(), m, n, k, _stream()),
+          'hfl_gemm_bf16')
+    return out
+
+
 # ------------------------------------------------------------------------- gather
 def octree_gather(data, neigh):
     """(N,C),(M,K) int32 -> (M, K*C): ocnn octree2col with zero fill."""

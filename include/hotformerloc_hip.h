@@ -31,6 +31,7 @@ typedef void* hfl_stream_t; /* hipStream_t */
 #define HFL_OK 0
 #define HFL_EINVAL (-1)      /* unsupported shape / argument            */
 #define HFL_ECAPACITY (-2)   /* input exceeds a documented kernel limit */
+#define HFL_EBACKEND (-100)  /* hipBLASLt refused the problem: code = -100 - hipblasStatus_t */
 
 /* library / device identification: returns the version as major*100+minor */
 int hfl_version(void);
@@ -191,6 +192,17 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
 int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth);
 int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth,
                           hfl_stream_t stream);
+
+/* Linear on the split operands through hipBLASLt, with the block's epilogue in the same launch:
+ *   out (n_rows, out_features) f32 = a (n_rows, k_concat) bf16 . w (out_features, k_concat)^T bf16
+ *                                    [+ bias (out_features) f32] [+ residual (n_rows, out_features) f32]
+ * a / w are the K-concatenated [hi|hi|lo] / [hi|lo|hi] operands of section 9 (k_concat = 3 * in_features),
+ * fp32 accumulation.  Replaces `x = x + proj(attn)` / `x = x + mlp(x)` of
+ * models/octformer_backbone.py:275-278 and models/hotformerloc_backbone.py:213-216 (Linear + bias +
+ * residual add) without a separate pass over the residual stream.  bias / residual may be NULL;
+ * residual must not alias out.  Returns HFL_EBACKEND - status when the library rejects the problem. */
+int hfl_gemm_bf16(float* out, const uint16_t* a, const uint16_t* w, const float* bias, const float* residual,
+                  int64_t n_rows, int out_features, int k_concat, hfl_stream_t stream);
 
 /* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (1 = first
  * version, 2 = default), "window_heads_per_wg" (waves per workgroup of the window kernel,
