@@ -26,7 +26,9 @@ import os
 import sys
 import time
 
-os.environ.setdefault('TENSILE_STREAMK_DATA_PARALLEL', '1')    # see hotformerloc_amd/__init__.py
+# hipBLASLt schedule (hotformerloc_amd/__init__.py): data-parallel for the forward path; the training step's weight
+# gradients contract over ~10^5 rows into small (N, K) outputs and need the stream-K split (145 vs 206 ms/step)
+os.environ.setdefault('TENSILE_STREAMK_DATA_PARALLEL', '0' if '--train' in sys.argv else '1')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -72,6 +72,7 @@ SIGNATURES = {
     'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
+    'hfl_gemm_bf16_tn': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_gemm_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_window_rpe_expand_size': (c_int64, [c_int, c_int, c_int]),
     'hfl_window_rpe_expand': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

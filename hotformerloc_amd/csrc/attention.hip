@@ -1769,9 +1769,11 @@ extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const fl
 
 // ======================================================================================
 // Backward of the ragged relay-token attention (training path).  One workgroup per (cloud, head):
-// the cloud's Q, K, V, dO rows of that head are staged in LDS (R x 16 floats each), one thread per
-// query row recomputes its softmax, accumulates dQ in registers and adds its contributions to
-// dK / dV in LDS (ds_add_f32); the sums are written once.  Work is tiny (R ~ 56..250).
+// the cloud's Q, K, V, dO rows of that head are staged in LDS (R x 16 floats each).  Two orientations,
+// no atomics: (A) one thread per QUERY row recomputes its softmax statistics (max, 1/sum, D = sum_j p dp),
+// accumulates dQ in registers and leaves the statistics in LDS; (B) one thread per KEY row walks the
+// queries (LDS broadcasts), rebuilds p_ij from the statistics and accumulates dK, dV in registers.
+// Work is tiny (R ~ 56..250).
 namespace {
 
 __global__ void __launch_bounds__(256)
@@ -1788,8 +1790,9 @@ relay_attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ qkv,
   float* sk = sq + R * 16;
   float* sv = sk + R * 16;
   float* sd = sv + R * 16;
-  float* dk = sd + R * 16;
-  float* dv = dk + R * 16;
+  float* s_m = sd + R * 16;                         // [R] row max (scaled scores)
+  float* s_inv = s_m + R;                           // [R] 1 / sum exp
+  float* s_D = s_inv + R;                           // [R] sum_j p_ij (dO_i . v_j)
   for (int i = threadIdx.x; i < R * 4; i += blockDim.x) {
     const int j = i >> 2, f = i & 3;
     const int64_t row = seq_rows[r0 + j];
@@ -1798,10 +1801,9 @@ relay_attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ qkv,
     reinterpret_cast<float4*>(sk)[i] = *reinterpret_cast<const float4*>(base + C);
     reinterpret_cast<float4*>(sv)[i] = *reinterpret_cast<const float4*>(base + 2 * C);
     reinterpret_cast<float4*>(sd)[i] = *reinterpret_cast<const float4*>(dout + row * C + h * 16 + 4 * f);
-    reinterpret_cast<float4*>(dk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    reinterpret_cast<float4*>(dv)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
+  // ---- (A) thread = query row ------------------------------------------------------------------
   for (int i = threadIdx.x; i < R; i += blockDim.x) {
     float q[16], g[16], dq[16];
 #pragma unroll
@@ -1828,25 +1830,39 @@ relay_attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ qkv,
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < 16; ++d) { s = fmaf(q[d], sk[j * 16 + d], s); dp = fmaf(g[d], sv[j * 16 + d], dp); }
-      const float pj = __expf(s * scale - m) * inv;
-      const float ds = pj * (dp - D) * scale;
+      const float ds = __expf(s * scale - m) * inv * (dp - D) * scale;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        dq[d] = fmaf(ds, sk[j * 16 + d], dq[d]);
-        atomicAdd(dk + j * 16 + d, ds * q[d]);
-        atomicAdd(dv + j * 16 + d, pj * g[d]);
-      }
+      for (int d = 0; d < 16; ++d) dq[d] = fmaf(ds, sk[j * 16 + d], dq[d]);
     }
+    s_m[i] = m; s_inv[i] = inv; s_D[i] = D;
     float* o = dqkv + (int64_t)seq_rows[r0 + i] * 3 * C + h * 16;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) o[d] = dq[d];
+    for (int d = 0; d < 16; d += 4) *reinterpret_cast<float4*>(o + d) = make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < R * 4; i += blockDim.x) {
-    const int j = i >> 2, f = i & 3;
-    float* base = dqkv + (int64_t)seq_rows[r0 + j] * 3 * C + h * 16 + 4 * f;
-    *reinterpret_cast<float4*>(base + C) = reinterpret_cast<const float4*>(dk)[i];
-    *reinterpret_cast<float4*>(base + 2 * C) = reinterpret_cast<const float4*>(dv)[i];
+  // ---- (B) thread = key row ---------------------------------------------------------------------
+  for (int j = threadIdx.x; j < R; j += blockDim.x) {
+    float k[16], v[16], dk[16], dv[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { k[d] = sk[j * 16 + d]; v[d] = sv[j * 16 + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < R; ++i) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { s = fmaf(sq[i * 16 + d], k[d], s); dp = fmaf(sd[i * 16 + d], v[d], dp); }
+      const float pj = __expf(s * scale - s_m[i]) * s_inv[i];
+      const float ds = pj * (dp - s_D[i]) * scale;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        dk[d] = fmaf(ds, sq[i * 16 + d], dk[d]);
+        dv[d] = fmaf(pj, sd[i * 16 + d], dv[d]);
+      }
+    }
+    float* base = dqkv + (int64_t)seq_rows[r0 + j] * 3 * C + h * 16;
+#pragma unroll
+    for (int d = 0; d < 16; d += 4) {
+      *reinterpret_cast<float4*>(base + C + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+      *reinterpret_cast<float4*>(base + 2 * C + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+    }
   }
 }
 
@@ -1856,7 +1872,7 @@ extern "C" int hfl_relay_attention_bwd(float* dqkv, const float* qkv, const floa
                                        const int32_t* seq_rows, const int32_t* seq_off, int batch,
                                        int n_heads, float scale, int max_seq_len, hfl_stream_t stream) {
   if (batch <= 0 || n_heads <= 0 || max_seq_len < 0) return HFL_EINVAL;
-  const size_t lds = (size_t)max_seq_len * 16 * 4 * 6;
+  const size_t lds = (size_t)max_seq_len * (16 * 4 * 4 + 3 * 4);
   if (lds > 160 * 1024) return HFL_ECAPACITY;
   if (max_seq_len == 0) return HFL_OK;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(relay_attn_bwd_kernel),

@@ -11,7 +11,7 @@
 //
 // Row-major operands map onto the column-major API as D^T (N x M) = op(A) . B with A = w (K' x N,
 // ld K', transposed) and B = a (K' x M, ld K').  Algorithms come from the library heuristic for the exact
-// problem and are cached; one 32 MiB workspace per stream (concurrent GEMMs on the pyramid streams must
+// problem and are cached; one 128 MiB workspace per stream (concurrent GEMMs on the pyramid streams must
 // not share one).
 #include "hfl_common.h"
 
@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr size_t kLtWorkspace = 32u << 20;
+constexpr size_t kLtWorkspace = 128u << 20;   // stream-K schedules keep partial tiles here (32 MiB faulted)
 
 struct LtPlan {
   hipblasLtMatmulDesc_t desc = nullptr;
@@ -32,7 +32,7 @@ struct LtPlan {
   bool ok = false;
 };
 
-typedef std::tuple<int64_t, int, int, int, int> LtKey;          // M, N, K, bias, residual
+typedef std::tuple<int64_t, int, int, int, int> LtKey;          // M, N, K, bias (2 = weight-gradient form), residual
 
 std::mutex g_lt_mutex;
 hipblasLtHandle_t g_lt_handle = nullptr;
@@ -140,5 +140,73 @@ extern "C" int hfl_gemm_bf16(float* out, const uint16_t* a, const uint16_t* w, c
       hipblasLtMatmul(g_lt_handle, p.desc, &alpha, w, p.la, a, p.lb, &beta,
                       residual != nullptr ? (const void*)residual : (const void*)out, p.lc, out, p.lc, &p.algo,
                       ws, kLtWorkspace, s);
+  return st == HIPBLAS_STATUS_SUCCESS ? HFL_OK : HFL_EBACKEND - (int)st;
+}
+
+// Weight gradient of the split Linear: out (N,K) f32 = a (R,N)^T bf16 . b (R,K) bf16, the contraction
+// running over the R = 3M stacked rows  a = [dy_hi; dy_hi; dy_lo],  b = [x_hi; x_lo; x_hi]
+// (dW = dy^T x as dy_hi^T x_hi + dy_hi^T x_lo + dy_lo^T x_hi).  Column-major view: D^T (K x N) =
+// B_c (K x R, ld K) . A_c^T (A_c: N x R, ld N).
+extern "C" int hfl_gemm_bf16_tn(float* out, const uint16_t* a, const uint16_t* b, int64_t n_rows_stacked,
+                                 int n_out, int k_out, hfl_stream_t stream) {
+  if (n_rows_stacked <= 0 || n_out <= 0 || k_out <= 0 || out == nullptr || a == nullptr || b == nullptr)
+    return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::lock_guard<std::mutex> lock(g_lt_mutex);
+  if (g_lt_handle == nullptr) {
+    const hipblasStatus_t st = hipblasLtCreate(&g_lt_handle);
+    if (st != HIPBLAS_STATUS_SUCCESS) {
+      g_lt_handle = nullptr;
+      return HFL_EBACKEND - (int)st;
+    }
+  }
+  void*& ws = g_lt_ws[s];
+  if (ws == nullptr) {
+    const hipError_t e = hipMalloc(&ws, kLtWorkspace);
+    if (e != hipSuccess) {
+      ws = nullptr;
+      return (int)e;
+    }
+  }
+  const LtKey key(n_rows_stacked, n_out, k_out, 2, 0);
+  if (g_lt_plans.size() > 4096) {
+    for (auto& kv : g_lt_plans) lt_destroy(kv.second);
+    g_lt_plans.clear();
+  }
+  LtPlan& p = g_lt_plans[key];
+  if (!p.ok) {
+    hipblasStatus_t st = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F);
+    const hipblasOperation_t ta = HIPBLAS_OP_N, tb = HIPBLAS_OP_T;
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta));
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb));
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16BF, (uint64_t)k_out, (uint64_t)n_rows_stacked, (int64_t)k_out);
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_16BF, (uint64_t)n_out, (uint64_t)n_rows_stacked, (int64_t)n_out);
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatrixLayoutCreate(&p.lc, HIP_R_32F, (uint64_t)k_out, (uint64_t)n_out, (int64_t)k_out);
+    hipblasLtMatmulPreference_t pref = nullptr;
+    if (st == HIPBLAS_STATUS_SUCCESS) st = hipblasLtMatmulPreferenceCreate(&pref);
+    const uint64_t wsb = kLtWorkspace;
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsb, sizeof(wsb));
+    hipblasLtMatmulHeuristicResult_t heur[1];
+    int found = 0;
+    if (st == HIPBLAS_STATUS_SUCCESS)
+      st = hipblasLtMatmulAlgoGetHeuristic(g_lt_handle, p.desc, p.la, p.lb, p.lc, p.lc, pref, 1, heur, &found);
+    if (pref) hipblasLtMatmulPreferenceDestroy(pref);
+    if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
+      lt_destroy(p);
+      g_lt_plans.erase(key);
+      return st != HIPBLAS_STATUS_SUCCESS ? HFL_EBACKEND - (int)st : HFL_EBACKEND;
+    }
+    p.algo = heur[0].algo;
+    p.ok = true;
+  }
+  const float alpha = 1.0f, beta = 0.0f;
+  const hipblasStatus_t st = hipblasLtMatmul(g_lt_handle, p.desc, &alpha, b, p.la, a, p.lb, &beta, out, p.lc, out,
+                                             p.lc, &p.algo, ws, kLtWorkspace, s);
   return st == HIPBLAS_STATUS_SUCCESS ? HFL_OK : HFL_EBACKEND - (int)st;
 }

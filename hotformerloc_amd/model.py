@@ -62,7 +62,17 @@ def _add_ln(x, y, m: nn.LayerNorm):
 _GEMM_MODE = os.environ.get('HFL_GEMM', 'bf16x3')
 _PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
 _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
+# training-path Linear layers on split-bf16 GEMMs (autograd.LinearSplitFn).  Off by default: parity-tested, but
+# at 191 ms/step (B=32, Wild-Places) still slower than the fp32 hipBLASLt route (145 ms) because the operand
+# splits of the backward are torch element-wise passes; needs fused split kernels to pay off.
+_TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
+
+
+def set_train_split(enabled: bool):
+    """Route the training-path Linear layers through the split-bf16 GEMMs (experimental, see _TRAIN_SPLIT)."""
+    global _TRAIN_SPLIT
+    _TRAIN_SPLIT = bool(enabled)
 
 
 def set_pyramid_streams(enabled: bool):
@@ -97,6 +107,17 @@ def _w3(lin: nn.Linear):
         hit = (weakref.ref(w), w._version, ops.split_weight(w))
         _W3_CACHE[id(w)] = hit
     return hit[2]
+
+
+class SplitLinear(nn.Linear):
+    """`nn.Linear` whose training-path products use the split-bf16 GEMMs (autograd.LinearSplitFn) when the
+    GEMM mode is 'bf16x3'; parameters, names and the fp32 fallback are those of nn.Linear."""
+
+    def forward(self, x):
+        if (_GEMM_MODE == 'bf16x3' and _TRAIN_SPLIT and x.is_cuda and torch.is_grad_enabled()
+                and self.in_features % 8 == 0 and self.out_features % 8 == 0 and x.numel() > 0):
+            return ag.linear_split(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
 
 
 def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
@@ -231,8 +252,8 @@ class MLP(nn.Module):
 
     def __init__(self, in_features, hidden_features=None, out_features=None):
         super().__init__()
-        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
-        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.fc1 = SplitLinear(in_features, hidden_features or in_features)
+        self.fc2 = SplitLinear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x):
         return self.fc2(F.gelu(self.fc1(x)))
@@ -277,8 +298,8 @@ class OctreeAttention(nn.Module):
             raise NotImplementedError('head dim must be 16 (all shipped configs)')
         self.dim, self.patch_size, self.num_heads = dim, patch_size, num_heads
         self.dilation, self.rt_per_window = dilation, rt_per_window
-        self.qkv = nn.Linear(dim, dim * 3)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = SplitLinear(dim, dim * 3)
+        self.proj = SplitLinear(dim, dim)
         self.rpe = RPE(patch_size, num_heads, dilation) if use_rpe else None
 
     def core(self, qkv, plan: WindowPlan, depth: int, qkv_bias=None, out_split=False):
@@ -386,13 +407,13 @@ class RTAttention(nn.Module):
     def __init__(self, dim, num_heads):
         super().__init__()
         self.dim, self.num_heads = dim, num_heads
-        self.qkv = nn.Linear(dim, dim * 3)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = SplitLinear(dim, dim * 3)
+        self.proj = SplitLinear(dim, dim)
 
     def forward(self, rt, plan: WindowPlan):
         qkv = self.qkv(rt)
         if _grad_path(qkv):
-            if plan.max_seq_len <= 426:             # LDS capacity of the HIP backward
+            if plan.max_seq_len <= 611:             # LDS capacity of the HIP backward
                 return self.proj(ag.relay_attention(qkv, plan, self.num_heads))
             return self.proj(ag.relay_attention_torch(qkv, plan, self.num_heads))
         out = ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, self.num_heads,

@@ -308,6 +308,28 @@ def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None) -> t
     return out
 
 
+def stack3(x: torch.Tensor, order: str) -> torch.Tensor:
+    """(M, C) fp32 -> (3M, C) bf16 planes stacked along the rows: 'hhl' = [hi; hi; lo], 'hlh' = [hi; lo; hi]
+    (operands of `gemm_bf16_tn`, the contraction runs over the rows)."""
+    x = _f32c(x)
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, hi, lo] if order == 'hhl' else [hi, lo, hi], 0)
+
+
+def gemm_bf16_tn(a_stack: torch.Tensor, b_stack: torch.Tensor) -> torch.Tensor:
+    """fp32 (N, K) = a_stack^T @ b_stack over the stacked rows (hfl_gemm_bf16_tn): dW = dy^T x."""
+    _dev(a_stack, b_stack)
+    assert a_stack.dtype == torch.bfloat16 and b_stack.dtype == torch.bfloat16
+    assert a_stack.is_contiguous() and b_stack.is_contiguous() and a_stack.shape[0] == b_stack.shape[0]
+    r, n = a_stack.shape
+    k = b_stack.shape[1]
+    out = torch.empty((n, k), dtype=torch.float32, device=a_stack.device)
+    check(_native.load().hfl_gemm_bf16_tn(out.data_ptr(), a_stack.data_ptr(), b_stack.data_ptr(), r, n, k,
+                                          _stream()), 'hfl_gemm_bf16_tn')
+    return out
+
+
 # ------------------------------------------------------------------------- gather
 def octree_gather(data, neigh):
     """(N,C),(M,K) int32 -> (M, K*C): ocnn octree2col with zero fill."""

@@ -204,6 +204,12 @@ int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int p
 int hfl_gemm_bf16(float* out, const uint16_t* a, const uint16_t* w, const float* bias, const float* residual,
                   int64_t n_rows, int out_features, int k_concat, hfl_stream_t stream);
 
+/* Weight gradient of that Linear (training path): out (n_out, k_out) f32 = a^T b with the contraction over the
+ * n_rows_stacked = 3M rows of  a = [dy_hi; dy_hi; dy_lo] (3M, n_out) bf16  and  b = [x_hi; x_lo; x_hi] (3M, k_out)
+ * bf16, i.e. dW = dy^T x to the same 2^-17 operand accuracy as the forward (torch autograd of nn.Linear). */
+int hfl_gemm_bf16_tn(float* out, const uint16_t* a, const uint16_t* b, int64_t n_rows_stacked, int n_out,
+                     int k_out, hfl_stream_t stream);
+
 /* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (1 = first
  * version, 2 = default), "window_heads_per_wg" (waves per workgroup of the window kernel,
  * default 4).  Returns HFL_EINVAL for an unknown key. */
@@ -312,8 +318,8 @@ int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv, c
                              const uint32_t* tok_meta, const float* rpe_table,
                              const hfl_window_attn_desc* desc, hfl_stream_t stream);
 /* Gradient of hfl_relay_attention_fwd.  dqkv (rows, 3*H*16): rows listed in seq_rows are written, the
- * others left untouched (the caller zero-fills).  max_seq_len * 384 B of LDS per workgroup: returns
- * HFL_ECAPACITY beyond 426 relay tokens per cloud. */
+ * others left untouched (the caller zero-fills).  max_seq_len * 268 B of LDS per workgroup: returns
+ * HFL_ECAPACITY beyond 611 relay tokens per cloud. */
 int hfl_relay_attention_bwd(float* dqkv, const float* qkv, const float* dout, const int32_t* seq_rows,
                             const int32_t* seq_off, int batch, int n_heads, float scale,
                             int max_seq_len, hfl_stream_t stream);
