@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- pyt
 stats=$(find $out/${tag}_stats -name '*kernel_stats.csv' | head -1)
 cp "$stats" $out/${tag}_kernel_stats.csv
 grep '^{' $out/${tag}_stats.log > $out/${tag}_bench_under_profiler.json
-python tools/summarize_rocprof.py $out/${tag}_kernel_stats.csv 13 > $out/${tag}_summary_table.md
+python tools/summarize_rocprof.py $out/${tag}_kernel_stats.csv 18 > $out/${tag}_summary_table.md
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/${tag}_pmc_$c -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_$c.log 2>&1
 done
