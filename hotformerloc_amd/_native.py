@@ -72,6 +72,8 @@ SIGNATURES = {
     'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
+    'hfl_smoothap_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_float, c_void_p]),
     'hfl_gemm_bf16_tn': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_gemm_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_window_rpe_expand_size': (c_int64, [c_int, c_int, c_int]),

@@ -289,7 +289,7 @@ def split_mm(a3: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     return torch.mm(a3, w3.t(), out_dtype=torch.float32)
 
 
-def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None) -> torch.Tensor:
+def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, out=None) -> torch.Tensor:
     """fp32 (rows, N) = A3 @ W3^T [+ bias] [+ residual] in one hipBLASLt launch (hfl_gemm_bf16): the
     Linear + bias + residual add of a transformer block without a pass over the residual stream."""
     _dev(a3, w3, bias, residual)
@@ -297,7 +297,10 @@ def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None) -> t
     m, k = a3.shape
     n = w3.shape[0]
     assert w3.shape[1] == k
-    out = torch.empty((m, n), dtype=torch.float32, device=a3.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a3.device)
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (m, n)
     if residual is not None:
         residual = _f32c(residual)
         assert tuple(residual.shape) == (m, n)

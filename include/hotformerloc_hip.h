@@ -336,6 +336,18 @@ int hfl_relay_token_init_bwd(float* dx, const float* drt, const uint32_t* tok_me
                              int32_t n_windows, int32_t patch_size, int64_t channels,
                              hfl_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * 11. TruncatedSmoothAP ranking core (replaces the (B,P,B) tensor algebra of
+ *     models/losses/truncated_smoothap.py:44-93 and its autograd graph)
+ * ---------------------------------------------------------------------- */
+/* sim (B,B) f32 = E E^T, pos_mask / neg_mask (B,B) uint8 (0/1), closest_pos (B,P) int64 = top-P positives of
+ * every query by similarity (entries that are not positives are skipped, as the reference zeroes them,
+ * :85-87).  ap (B): sum_j valid r_j / n_valid (0 for a query without positives); dap_ds (B,B): d ap[q] / d sim[q,z]
+ * with the clamped-sigmoid gradient of loss_utils.py:40-48.  HFL_ECAPACITY beyond 17066 rows (9 B of LDS each). */
+int hfl_smoothap_rows(float* ap, float* dap_ds, const float* sim, const uint8_t* pos_mask,
+                      const uint8_t* neg_mask, const int64_t* closest_pos, int batch, int positives_per_query,
+                      float tau, hfl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
