@@ -36,10 +36,26 @@ from . import ops
 from .plan import WindowPlan
 
 
-def _grad_path(x) -> bool:
+_FORCE_TRAIN_PATH = False
+
+
+def _grad_path(x=None) -> bool:
     """True when autograd must see the op (training / fine-tuning): route through the
     autograd Functions instead of the fused inference kernels."""
-    return torch.is_grad_enabled()
+    return torch.is_grad_enabled() or _FORCE_TRAIN_PATH
+
+
+@contextlib.contextmanager
+def training_numerics():
+    """Run the training-path kernels even with autograd off.  Stage 1 of the multi-staged step
+    (`training/trainer.py:305-317`) must produce the SAME descriptors as stage 3 recomputes with autograd --
+    the loss gradient is taken at the stage-1 values, and tau1 = 0.01 amplifies any difference 100x."""
+    global _FORCE_TRAIN_PATH
+    old, _FORCE_TRAIN_PATH = _FORCE_TRAIN_PATH, True
+    try:
+        yield
+    finally:
+        _FORCE_TRAIN_PATH = old
 
 
 def _ln(x, m: nn.LayerNorm):
@@ -94,7 +110,7 @@ def get_gemm_mode() -> str:
 
 
 def _split_path(x) -> bool:
-    return _GEMM_MODE == 'bf16x3' and x.is_cuda and not torch.is_grad_enabled()
+    return _GEMM_MODE == 'bf16x3' and x.is_cuda and not _grad_path()
 
 
 def _w3(lin: nn.Linear):
@@ -114,7 +130,7 @@ class SplitLinear(nn.Linear):
     GEMM mode is 'bf16x3'; parameters, names and the fp32 fallback are those of nn.Linear."""
 
     def forward(self, x):
-        if (_GEMM_MODE == 'bf16x3' and _TRAIN_SPLIT and x.is_cuda and torch.is_grad_enabled()
+        if (_GEMM_MODE == 'bf16x3' and _TRAIN_SPLIT and x.is_cuda and _grad_path()
                 and self.in_features % 8 == 0 and self.out_features % 8 == 0 and x.numel() > 0):
             return ag.linear_split(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)

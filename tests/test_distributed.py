@@ -66,3 +66,82 @@ def test_shard_bounds_cover_batch_in_order():
 def test_single_process_is_identity():
     x = torch.randn(3, 5)
     assert all_gather_descriptors(x) is x
+
+
+# ---------------------------------------------------------------- multi-staged step
+class _ToyEncoder(torch.nn.Module):
+    """Stands in for the encoder on CPU: {'x': (b, 6)} -> {'global': unit-norm (b, 5)}."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = torch.nn.Linear(6, 7)
+        self.b = torch.nn.Linear(7, 5)
+
+    def forward(self, batch):
+        return {'global': torch.nn.functional.normalize(self.b(torch.tanh(self.a(batch['x']))), dim=1)}
+
+
+def _toy_listwise_loss(emb, pos, neg):
+    s = emb @ emb.t()
+    loss = (torch.sigmoid((s * neg.float()).sum(1) - (s * pos.float()).sum(1))).mean()
+    return loss, {'loss': loss.item()}
+
+
+def _toy_data(n_total):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n_total, 6, generator=g)
+    lab = torch.arange(n_total) // 2
+    pos = (lab[:, None] == lab[None, :]) & ~torch.eye(n_total, dtype=torch.bool)
+    neg = lab[:, None] != lab[None, :]
+    return x, pos, neg
+
+
+def _step_worker(rank, world, port, n_total, result_dir):
+    from hotformerloc_amd.training import multistaged_training_step
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        x, pos, neg = _toy_data(n_total)
+        lo, hi = shard_bounds(n_total, rank, world)
+        mine = x[lo:hi]
+        half = (hi - lo + 1) // 2
+        minibatches = [{'x': mine[:half]}, {'x': mine[half:]}]           # batch_split_size chunks
+        model = _ToyEncoder()
+        stats = multistaged_training_step(model, minibatches, pos, neg, _toy_listwise_loss, n_total=n_total)
+        torch.save({'grads': [p.grad.clone() for p in model.parameters()], 'loss': stats['loss']},
+                   os.path.join(result_dir, 'step_%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_total', [8, 7])
+def test_multistaged_step_gloo_world2_matches_single_process(tmp_path, n_total):
+    """Two ranks, two minibatches each: the all-reduced parameter gradients equal those of one process that
+    back-propagates the same listwise loss through the whole batch directly."""
+    world = 2
+    mp.spawn(_step_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'step_0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'step_1.pt'))
+    x, pos, neg = _toy_data(n_total)
+    model = _ToyEncoder()
+    loss, _ = _toy_listwise_loss(model({'x': x})['global'], pos, neg)
+    loss.backward()
+    assert abs(r0['loss'] - loss.item()) < 1e-6 and abs(r1['loss'] - loss.item()) < 1e-6
+    for g0, g1, p in zip(r0['grads'], r1['grads'], model.parameters()):
+        assert torch.allclose(g0, g1, atol=0, rtol=0)
+        assert torch.allclose(g0, p.grad, atol=1e-6), (g0 - p.grad).abs().max()
+
+
+def test_multistaged_step_single_process_equals_direct():
+    from hotformerloc_amd.training import multistaged_training_step
+    x, pos, neg = _toy_data(10)
+    model = _ToyEncoder()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    multistaged_training_step(model, [{'x': x[:4]}, {'x': x[4:7]}, {'x': x[7:]}], pos, neg, _toy_listwise_loss, opt)
+    ref = _ToyEncoder()
+    loss, _ = _toy_listwise_loss(ref({'x': x})['global'], pos, neg)
+    loss.backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6)

@@ -59,3 +59,53 @@ def test_loss_rejects_cpu_tensors():
     from hotformerloc_amd._native import NativeLibraryError
     with pytest.raises(NativeLibraryError):
         TruncatedSmoothAP()(torch.zeros(4, 8), torch.zeros(4, 4, dtype=torch.bool), torch.zeros(4, 4, dtype=torch.bool))
+
+
+def test_multistaged_step_on_the_encoder_matches_oracle_chain():
+    """SURVEY 8f rank 1 end to end on one GPU: two minibatches through the HIP encoder, GPU TruncatedSmoothAP,
+    stage-3 back-propagation -- against (a) direct autograd through both minibatches on the GPU and (b) the
+    CPU oracle chain (oracle encoder + loss oracle, torch autograd).  drop_path = 0 (RNG parity is impossible)."""
+    from hotformerloc_amd import build_batch_octree, load_config, model_factory
+    from hotformerloc_amd import synthetic as syn
+    from hotformerloc_amd.training import multistaged_training_step
+    from oracle import hotformer_ref
+    from oracle.testing import oracle_octree, synthetic_state_dict
+    params, depth = load_config('wild-places')
+    params.drop_path = 0.0
+    clouds = [syn.cylindrical(syn.unit_ball_cloud(3100 + i, 900 + 100 * i)) for i in range(6)]
+    parts = [clouds[:3], clouds[3:]]
+    lab = torch.arange(6) // 2
+    pos = (lab[:, None] == lab[None, :]) & ~torch.eye(6, dtype=torch.bool)
+    neg = lab[:, None] != lab[None, :]
+    loss_fn = TruncatedSmoothAP(tau1=0.01, positives_per_query=1)
+
+    def fresh():
+        m = model_factory(params)
+        syn.fill_synthetic_weights(m, 'stress')
+        return m.cuda()
+
+    model = fresh()
+    mbs = [{'octree': build_batch_octree(p, depth, 2, 'cuda')} for p in parts]
+    stats = multistaged_training_step(model, mbs, pos, neg, loss_fn)
+    # (a) direct autograd on the GPU
+    direct = fresh().train()
+    emb = torch.cat([direct({'octree': build_batch_octree(p, depth, 2, 'cuda')})['global'] for p in parts], 0)
+    loss, _ = loss_fn(emb, pos, neg)
+    loss.backward()
+    assert abs(stats['loss'] - loss.item()) < 1e-5
+    for (n, p), q in zip(model.named_parameters(), direct.parameters()):
+        d = (p.grad - q.grad).norm().item()
+        assert d <= 2e-4 * max(q.grad.norm().item(), 1e-9) + 1e-9, (n, d, q.grad.norm().item())
+    # (b) the CPU oracle chain
+    sd = {k: v.clone().requires_grad_() for k, v in synthetic_state_dict(params, 'stress').items()}
+    emb_ref = torch.cat([hotformer_ref.forward_with_grad(sd, params, oracle_octree(p, depth)) for p in parts], 0)
+    want, _ = loss_ref.truncated_smooth_ap(emb_ref, pos, neg, 0.01, 1)
+    want.backward()
+    assert abs(stats['loss'] - want.item()) < 1e-4
+    worst = 0.0
+    for n, p in model.named_parameters():
+        gref = sd[n].grad
+        err = (p.grad.cpu() - gref).norm().item() / max(gref.norm().item(), 1e-12)
+        worst = max(worst, err if gref.norm().item() > 1e-9 else 0.0)
+        assert err < 2e-3 or gref.norm().item() < 1e-9, (n, err, gref.norm().item())
+    print('multistaged step: loss', stats['loss'], want.item(), 'worst param-grad rel-L2 vs oracle', worst)
