@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
     ap.add_argument('--attn-variant', type=int, default=0, help='A/B: window attention kernel variant (0 = default)')
     ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
+    ap.add_argument('--multistaged', action='store_true',
+                    help='with --train: the full multi-staged step (stage 1 no-grad encode, TruncatedSmoothAP on the '
+                         'all-gathered descriptors, stage 3 forward+backward, gradient all-reduce, AdamW step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16, help='clouds in the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=16,
@@ -144,7 +147,20 @@ def main():
         proj = torch.from_numpy(syn.hash_uniform(99, args.batch * params.output_dim).reshape(
             args.batch, params.output_dim).astype('float32')).to(dev)
 
+    if args.train and args.multistaged:
+        from hotformerloc_amd.losses import TruncatedSmoothAP
+        from hotformerloc_amd.training import multistaged_training_step
+        n_tot = args.batch * world
+        lab = torch.arange(n_tot) // 4                     # groups of 4 consecutive clouds are mutual positives
+        pos_mask = ((lab[:, None] == lab[None, :]) & ~torch.eye(n_tot, dtype=torch.bool)).to(dev)
+        neg_mask = (lab[:, None] != lab[None, :]).to(dev)
+        loss_fn = TruncatedSmoothAP(tau1=0.01, positives_per_query=4)
+        optim = torch.optim.AdamW(model.parameters(), lr=1e-5)
+
     def step():
+        if args.train and args.multistaged:
+            multistaged_training_step(model, [batch], pos_mask, neg_mask, loss_fn, optim, n_total=n_tot)
+            return torch.ones(1, device=dev)
         if args.train:
             model.zero_grad(set_to_none=True)
             y = model(batch)['global']
@@ -241,7 +257,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': '%s cfg, batch=%d clouds/GPU x %d pts, octree depth %d, %s, '
                                    'octree+neighbours resident' % (args.config, args.batch, args.points, depth,
-                                                                   'forward+backward' if args.train else 'forward-only'),
+                                                                   ('multi-staged training step (stage 1 + TruncatedSmoothAP + stage 3 + grad all-reduce + AdamW)'
+                                                                    if args.multistaged else 'forward+backward') if args.train else 'forward-only'),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
                        'collective': 'rccl all_gather (B_local,256) f32' if world > 1 else 'none'},
             'roofline': roof, 'kernels': others,
