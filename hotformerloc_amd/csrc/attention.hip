@@ -488,247 +488,6 @@ window_attn_kernel_v2(const WinParams p) {
 
 
 // ----------------------------------------------------------------------------------
-// v3 = v2 + software pipelining across windows.  The SQ counters of v2 show 59 % of the wave cycles
-// parked on memory: a wave issues the loads of its (window, head), waits a full HBM/L2 round trip,
-// computes, and only then touches the next window.  Here a workgroup is persistent over a strided
-// list of windows and holds TWO fragment sets: while set A is being consumed by the MFMA/softmax
-// pipeline the loads of the next window already fill set B (metadata double-buffered in LDS).
-template <int T>
-struct WinFrag {
-  float4 kf[T], qf[T];
-  float vf[T][4];
-};
-
-template <int T, int G, bool CLAMP, bool RPE>
-__global__ void __launch_bounds__(256)
-window_attn_kernel_v3(const WinParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int LP = T * 16;
-  constexpr int TW = T - G;
-  constexpr float kLog2e = 1.4426950408889634f;
-  const int H = p.H, K = p.K;
-  const int C = H * 16;
-  const int nrpe = 2 * p.bnd + 1;
-  int4* s_key = reinterpret_cast<int4*>(smem);                         // [2][LP]
-  int4* s_qry = s_key + 2 * LP;                                        // [2][LP]
-  int* s_row = reinterpret_cast<int*>(s_qry + 2 * LP);                 // [2][LP]  row or -1
-  uint32_t* s_off = reinterpret_cast<uint32_t*>(s_row + 2 * LP);       // [2][LP]  row * 3C (dead -> 0)
-  float* s_tab = reinterpret_cast<float*>(s_off + 2 * LP);             // [nhw][3*nrpe] * log2e
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int hw = tid >> 6;
-  const int nhw = blockDim.x >> 6;
-  const int h = blockIdx.y * nhw + hw;
-  const int c = lane & 15, g = lane >> 4;
-  constexpr bool rpe = RPE;
-
-  if (rpe)
-    for (int i = tid; i < 3 * nrpe * nhw; i += blockDim.x) {
-      const int r = i / nhw, hh = i % nhw;
-      s_tab[hh * 3 * nrpe + r] = p.table[r * H + blockIdx.y * nhw + hh] * kLog2e;
-    }
-  const int hu = __builtin_amdgcn_readfirstlane(hw);
-  const int tabx = (int)(size_t)(s_tab + hu * 3 * nrpe);
-  const int taby = tabx + nrpe * 4;
-  const int tabz = taby + nrpe * 4;
-  const int hi4 = 8 * p.bnd;
-  const float scale2 = p.scale * kLog2e;
-  const float mask2 = kMaskValue * kLog2e;
-
-  float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bk = bq;
-  float bv = 0.f;
-  if (p.qkv_bias != nullptr) {
-    bq = *reinterpret_cast<const float4*>(p.qkv_bias + h * 16 + 4 * g);
-    bk = *reinterpret_cast<const float4*>(p.qkv_bias + C + h * 16 + 4 * g);
-    bv = p.qkv_bias[2 * C + h * 16 + c];
-  }
-
-  auto stage_meta = [&](int w, int buf) {
-    for (int j = tid; j < LP; j += blockDim.x) {
-      int bid = -1, row = -1;
-      int x = 0, y = 0, z = 0;
-      if (j < K) {
-        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
-                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
-        if (t < p.n_tokens) {
-          const uint32_t xyz = p.meta[2 * t];
-          x = (int)(xyz & 1023u); y = (int)((xyz >> 10) & 1023u); z = (int)(xyz >> 20);
-          bid = (int)p.meta[2 * t + 1];
-          row = (int)t;
-        }
-      } else if (G > 0 && j == K) {
-        const int64_t t0 = (int64_t)w * K;
-        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
-        row = (int)(p.rt_row0 + w);
-      }
-      s_key[buf * LP + j] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), bid);
-      s_qry[buf * LP + j] = make_int4(4 * x, 4 * y, 4 * z, row >= 0 ? bid : -2);
-      s_row[buf * LP + j] = row;
-      s_off[buf * LP + j] = row >= 0 ? (uint32_t)row * (uint32_t)(3 * C) : 0u;
-    }
-  };
-
-  // Unconditional loads (dead positions read row 0: finite data that the -1e3 mask turns into an exact
-  // zero weight, and dead queries are never stored), offsets first, then all loads back to back.
-  const float* qbase = p.qkv + h * 16 + 4 * g;
-  const float* vbase = p.qkv + 2 * C + h * 16 + c;
-  auto load_frag = [&](WinFrag<T>& f, int buf) {
-    uint32_t oq[T], ov[T][4];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      oq[t] = s_off[buf * LP + t * 16 + c];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ov[t][r] = s_off[buf * LP + t * 16 + 4 * g + r];
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      f.qf[t] = *reinterpret_cast<const float4*>(qbase + oq[t]);
-      f.kf[t] = *reinterpret_cast<const float4*>(qbase + C + oq[t]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (G > 0 && t == T - 1 && r > 0) { f.vf[t][r] = 0.f; continue; }
-        f.vf[t][r] = vbase[ov[t][r]];
-      }
-    }
-  };
-
-  auto compute = [&](WinFrag<T>& f, int buf) {
-    const int4* key = s_key + buf * LP;
-    const int4* qry = s_qry + buf * LP;
-    const int* rowp = s_row + buf * LP;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {      // biases are added here (after the data has landed)
-      f.qf[t].x = (f.qf[t].x + bq.x) * scale2; f.qf[t].y = (f.qf[t].y + bq.y) * scale2;
-      f.qf[t].z = (f.qf[t].z + bq.z) * scale2; f.qf[t].w = (f.qf[t].w + bq.w) * scale2;
-      f.kf[t].x += bk.x; f.kf[t].y += bk.y; f.kf[t].z += bk.z; f.kf[t].w += bk.w;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (!(G > 0 && t == T - 1 && r > 0)) f.vf[t][r] += bv;
-    }
-#pragma unroll
-    for (int qt = 0; qt < T; ++qt) {
-      int4 q = qry[qt * 16 + c];
-      const bool q_rpe = rpe && !(G > 0 && qt == T - 1);
-      q.x += tabx; q.y += taby; q.z += tabz;
-
-      f32x4 s[T];
-#pragma unroll
-      for (int kt = 0; kt < T; ++kt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.kf[kt].x, f.qf[qt].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.kf[kt].y, f.qf[qt].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.kf[kt].z, f.qf[qt].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(f.kf[kt].w, f.qf[qt].w, acc, 0, 0, 0);
-        s[kt] = acc;
-      }
-      float mx = kDeadValue;
-#pragma unroll
-      for (int kt = 0; kt < TW; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int4 k = key[kt * 16 + 4 * g + r];
-          float v = s[kt][r];
-          if (q_rpe) {
-            int ox = q.x + k.x, oy = q.y + k.y, oz = q.z + k.z;
-            if (CLAMP) {
-              ox = min(max(ox, tabx), tabx + hi4);
-              oy = min(max(oy, taby), taby + hi4);
-              oz = min(max(oz, tabz), tabz + hi4);
-            }
-            typedef __attribute__((address_space(3))) const float lds_f32;
-            v += (*reinterpret_cast<lds_f32*>(ox) + *reinterpret_cast<lds_f32*>(oy)) +
-                 *reinterpret_cast<lds_f32*>(oz);
-          }
-          if (k.w != q.w) v += mask2;
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      }
-      if (G > 0) {
-        const int kb = key[K].w;
-        float v = s[T - 1][0];
-        if (g != 0 || kb != q.w) v += mask2;
-        s[T - 1][0] = v;
-        mx = fmaxf(mx, v);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < TW; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-          s[kt][r] = e;
-          sum += e;
-        }
-      }
-      if (G > 0) {
-        const float e = __builtin_amdgcn_exp2f(s[T - 1][0] - mx);
-        s[T - 1][0] = e;
-        sum += e;
-      }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < TW; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r] * inv, f.vf[kt][r], o, 0, 0, 0);
-      }
-      if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[T - 1][0] * inv, f.vf[T - 1][0], o, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int orow = rowp[qt * 16 + 4 * g + r];
-        if (orow >= 0) {
-          if (p.out_split) {
-            uint16_t* orow16 = reinterpret_cast<uint16_t*>(p.out) + (int64_t)orow * 3 * C + h * 16 + c;
-            const uint16_t hi = att_bf16_rne(o[r]);
-            orow16[0] = hi;
-            orow16[C] = hi;
-            orow16[2 * C] = att_bf16_rne(o[r] - __uint_as_float((uint32_t)hi << 16));
-          } else {
-            p.out[(int64_t)orow * C + h * 16 + c] = o[r];
-          }
-        }
-      }
-    }
-  };
-
-  int w = blockIdx.x;
-  if (w >= p.n_windows) return;              // uniform per workgroup
-  WinFrag<T> fa, fb;
-  stage_meta(w, 0);
-  __syncthreads();
-  load_frag(fa, 0);
-  for (;;) {
-    int wn = w + gridDim.x;
-    bool more = wn < p.n_windows;
-    if (more) stage_meta(wn, 1);
-    __syncthreads();
-    if (more) load_frag(fb, 1);
-    compute(fa, 0);
-    if (!more) break;
-    w = wn;
-    wn = w + gridDim.x;
-    more = wn < p.n_windows;
-    __syncthreads();                          // every wave is done with metadata buffer 0
-    if (more) stage_meta(wn, 0);
-    __syncthreads();
-    if (more) load_frag(fa, 0);
-    compute(fb, 1);
-    if (!more) break;
-    w = wn;
-    __syncthreads();                          // every wave is done with metadata buffer 1
-  }
-}
-
-
-// ----------------------------------------------------------------------------------
 // v4: v2 after a second instruction diet.  The ISA of v2<5,1> is 3250 instructions per (window,
 // head) for 148 MFMAs -- ~50 issue slots per score against a floor of ~8 -- so the kernel is
 // VALU/issue bound, not memory bound (SQ counters: profiles/r01_b_summary.md).  What changes:
@@ -1120,7 +879,6 @@ rpe_expand_kernel(float* __restrict__ out, const float* __restrict__ table, int 
 static int g_window_variant = 4;
 static int g_window_v4_wgs_per_cu = 1;   // multiples of the resident workgroup count
 static int g_window_dbg = 0;
-static int g_window_wgs_per_cu = 3;
 static int g_window_v2_wgs_per_cu = 16;
 static int g_window_heads_per_wg = 4;
 
@@ -1174,20 +932,6 @@ static int launch_window(const WinParams& p, hipStream_t s) {
         window_attn_kernel_v4<T, G, false><<<grid4, hpw * 64, lds4, s>>>(p);
       else
         window_attn_kernel_v4<T, G, true><<<grid4, hpw * 64, lds4, s>>>(p);
-    } else if (g_window_variant == 3) {
-      // persistent: about g_window_wgs_per_cu workgroups per CU in total, each walking a strided
-      // list of windows with the next window's loads in flight
-      const size_t lds3 = (p.table ? (size_t)hpw * 3 * nrpe * 4 : 0) + (size_t)2 * LP * (16 + 16 + 4 + 4);
-      int px = hfl_num_cus() * g_window_wgs_per_cu / groups;
-      if (px < 1) px = 1;
-      if (px > p.n_windows) px = p.n_windows;
-      dim3 grid3((unsigned)px, (unsigned)groups);
-      if (p.table == nullptr)
-        window_attn_kernel_v3<T, G, false, false><<<grid3, hpw * 64, lds3, s>>>(p);
-      else if (p.clamp)
-        window_attn_kernel_v3<T, G, true, true><<<grid3, hpw * 64, lds3, s>>>(p);
-      else
-        window_attn_kernel_v3<T, G, false, true><<<grid3, hpw * 64, lds3, s>>>(p);
     } else if (p.table == nullptr)
       window_attn_kernel_v2<T, G, false, false><<<grid, hpw * 64, lds, s>>>(p);
     else if (p.clamp)
@@ -1335,13 +1079,6 @@ int hfl_set_variant(const char* key, int value) {
   while (k6[i] != 0 && key[i] == k6[i]) ++i;
   if (k6[i] == 0 && key[i] == 0) {
     g_window_v2_wgs_per_cu = value;
-    return HFL_OK;
-  }
-  const char* k5 = "window_wgs_per_cu";
-  i = 0;
-  while (k5[i] != 0 && key[i] == k5[i]) ++i;
-  if (k5[i] == 0 && key[i] == 0) {
-    g_window_wgs_per_cu = value;
     return HFL_OK;
   }
   const char* k2 = "window_heads_per_wg";

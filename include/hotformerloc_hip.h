@@ -210,9 +210,12 @@ int hfl_gemm_bf16(float* out, const uint16_t* a, const uint16_t* w, const float*
 int hfl_gemm_bf16_tn(float* out, const uint16_t* a, const uint16_t* b, int64_t n_rows_stacked, int n_out,
                      int k_out, hfl_stream_t stream);
 
-/* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (1 = first
- * version, 2 = default), "window_heads_per_wg" (waves per workgroup of the window kernel,
- * default 4).  Returns HFL_EINVAL for an unknown key. */
+/* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (4 = default two-lookup
+ * kernel, 2 = three-lookup kernel, also the fallback for depth > 5 or |delta| > pos_bnd, 1 = first version),
+ * "window_heads_per_wg" (waves per workgroup, default 4), "window_v4_wgs_per_cu" / "window_v2_wgs_per_cu"
+ * (persistent-grid multipliers), "window_debug" (ablation bits of tools/kbench.py), "cpe_variant" (0 = direct
+ * gathers, default; 1 = LDS-staged de-duplicated gathers), "cpe_lds_wgs_per_cu", "cpe_chunk_rows",
+ * "linear_ablate".  Returns HFL_EINVAL for an unknown key. */
 int hfl_set_variant(const char* key, int value);
 
 /* ------------------------------------------------------------------------
