@@ -211,3 +211,22 @@ def test_drop_path_is_per_cloud_and_off_in_eval():
     for b in range(3):
         rows = y[bid == b]
         assert torch.all(rows == rows[0, 0]) and rows[0, 0].item() in (0.0, 2.0)
+
+
+def test_large_oxford_batch_completes_and_is_deterministic():
+    """Regression for the stream-K dead-lock ("hipBLASLt schedule"): Oxford cfg, 48 clouds --
+    every pyramid depth is chip-filling (92k-194k rows).  With stream-K GEMMs on three streams this configuration
+    never returned from synchronize(); the data-parallel schedule + the side-stream row guard make it finish."""
+    params, depth = load_config('oxford')
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'init')
+    model = model.cuda().eval()
+    clouds = syn.make_clouds(5, 48, 4096, params.coordinates)
+    octree = build_batch_octree(clouds, depth, 2, 'cuda')
+    with torch.inference_mode():
+        y1 = model({'octree': octree})['global']
+        y2 = model({'octree': octree})['global']
+    torch.cuda.synchronize()
+    assert y1.shape == (48, 256) and torch.isfinite(y1).all()
+    assert torch.equal(y1, y2)
+    assert torch.allclose(y1.norm(dim=1), torch.ones(48, device='cuda'), atol=1e-5)
