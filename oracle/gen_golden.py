@@ -40,6 +40,7 @@ CASES = {
                                                   (9, 'ball'), (4096, 'forest')]),
     'cs_wild_places_b2':  ('cs-wild-places', 7, 3, [(6000, 'forest'), (4096, 'ball')]),
     'oxford_b2':          ('oxford', 9, 5, [(4096, 'ball')] * 2),
+    'cs_campus3d_b2':     ('cs-campus3d', 7, 7, [(4096, 'forest'), (5000, 'ball')]),
 }
 
 
@@ -95,10 +96,26 @@ def build_case(case):
     return out
 
 
+def dump_state_dicts(dst):
+    """tests/golden/state_dict_<cfg>.json: [[name, shape], ...] of the reference model's state_dict, in order
+    (tests/test_host_logic.py::test_state_dict_matches_reference_layout)."""
+    import json
+    for cfg in ('wild-places', 'cs-wild-places', 'oxford', 'cs-campus3d'):
+        cfg_path = os.path.join(ref_import.REFERENCE_ROOT, 'models', 'hotformerloc_%s_cfg.txt' % cfg)
+        model, _ = ref_import.reference_model(cfg_path)
+        spec = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        with open(os.path.join(dst, 'state_dict_%s.json' % cfg.replace('-', '_')), 'w') as f:
+            json.dump(spec, f)
+        print('state_dict', cfg, len(spec), 'tensors', sum(p.numel() for p in model.parameters()), 'parameters')
+
+
 def main():
     dst = os.path.join(ROOT, 'tests', 'golden')
     os.makedirs(dst, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if sys.argv[1:] == ['state_dicts']:
+        dump_state_dicts(dst)
+        return
     for case in (sys.argv[1:] or CASES):
         out = build_case(case)
         path = os.path.join(dst, 'model_%s.npz' % case)

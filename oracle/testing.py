@@ -10,7 +10,8 @@ import torch
 from hotformerloc_amd import synthetic as syn
 from oracle.ocnn_ref import Octree, Points, merge_octrees
 
-_NAME = {'wild-places': 'wild-places', 'cs-wild-places': 'cs-wild-places', 'oxford': 'oxford'}
+_NAME = {'wild-places': 'wild-places', 'cs-wild-places': 'cs-wild-places', 'oxford': 'oxford',
+         'cs-campus3d': 'cs-campus3d'}
 
 
 def load_case(golden_dir: str, case: str) -> dict:

@@ -18,7 +18,7 @@ from oracle import hotformer_ref
 from oracle.testing import load_case, oracle_octree, synthetic_state_dict
 
 REL_TOL = 1e-3
-CASES = ['wild_places_b1', 'wild_places_b3', 'wild_places_ragged', 'cs_wild_places_b2', 'oxford_b2']
+CASES = ['wild_places_b1', 'wild_places_b3', 'wild_places_ragged', 'cs_wild_places_b2', 'oxford_b2', 'cs_campus3d_b2']
 
 
 def _device_model(params, profile='stress'):

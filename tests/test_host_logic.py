@@ -18,7 +18,7 @@ from oracle.testing import load_case, oracle_octree
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('name', ['wild-places', 'cs-wild-places', 'oxford'])
+@pytest.mark.parametrize('name', ['wild-places', 'cs-wild-places', 'oxford', 'cs-campus3d'])
 def test_state_dict_matches_reference_layout(golden_dir, name):
     """Names, shapes and order of the reference state_dict; the JSON was
     dumped from the reference model in the build container."""
@@ -28,7 +28,7 @@ def test_state_dict_matches_reference_layout(golden_dir, name):
     mine = [[k, list(v.shape)] for k, v in model.state_dict().items()]
     assert mine == spec
     assert sum(p.numel() for p in model.parameters()) == {
-        'wild-places': 35313124, 'cs-wild-places': 35371176, 'oxford': 35329992}[name]
+        'wild-places': 35313124, 'cs-wild-places': 35371176, 'oxford': 35329992, 'cs-campus3d': 35415236}[name]
 
 
 def test_model_params_fields():

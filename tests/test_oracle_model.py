@@ -16,7 +16,7 @@ from oracle import hotformer_ref
 from oracle.ocnn_ref import Octree, Points, merge_octrees
 from oracle.testing import load_case, oracle_octree, synthetic_state_dict
 
-CASES = ['wild_places_b1', 'wild_places_ragged', 'cs_wild_places_b2', 'oxford_b2', 'wild_places_b3']
+CASES = ['wild_places_b1', 'wild_places_ragged', 'cs_wild_places_b2', 'oxford_b2', 'wild_places_b3', 'cs_campus3d_b2']
 
 
 @pytest.mark.parametrize('case', CASES)
