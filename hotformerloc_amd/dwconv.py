@@ -1,8 +1,15 @@
 """Drop-in for the reference's `dwconv` package (`libs/dwconv/dwconv/{__init__,nn}.py`) and
-its compiled `dwconv.core` (`libs/dwconv/csrc/pybind.cpp:10-14`): same names, argument
-meaning and autograd behaviour, HIP kernels underneath (csrc/dwconv.hip)."""
+its compiled `dwconv.core` (`libs/dwconv/csrc/pybind.cpp:10-14`): the same public names
+(`octree_dwconv`, `OctreeDWConvFunction`, `OctreeDWConv`, `dwconv_forward_backward`,
+`dwconv_weight_backward`, `inverse_neigh`), argument meaning and autograd behaviour, on the HIP
+kernels of csrc/dwconv.hip.
 
-from typing import List
+One difference in mechanism: the data gradient needs the inverse neighbour table; the reference rebuilds it
+in every backward call (`nn.py:36-38`), here it is built once per neighbour table and kept while that
+table is alive (the octree caches its tables, so all 37 CPE calls of a step share three of them)."""
+
+import weakref
+from typing import List, Optional, Sequence
 
 import torch
 from torch.autograd import Function
@@ -10,56 +17,70 @@ from torch.autograd import Function
 from . import ops
 from .ops import dwconv_forward_backward, dwconv_weight_backward, inverse_neigh  # noqa: F401 (dwconv.core)
 
-__all__ = ['octree_dwconv', 'OctreeDWConv', 'dwconv_forward_backward', 'dwconv_weight_backward',
-           'inverse_neigh']
+__all__ = ['octree_dwconv', 'OctreeDWConv', 'OctreeDWConvFunction', 'dwconv_forward_backward',
+           'dwconv_weight_backward', 'inverse_neigh']
+
+_INVERSE_TABLES = {}        # id(table) -> (weakref to the table, its version, inverse table)
+
+
+def _inverse_of(table: torch.Tensor) -> torch.Tensor:
+    hit = _INVERSE_TABLES.get(id(table))
+    if hit is not None and hit[0]() is table and hit[1] == table._version:
+        return hit[2]
+    if len(_INVERSE_TABLES) > 256:
+        _INVERSE_TABLES.clear()
+    inv = ops.inverse_neigh(table)
+    _INVERSE_TABLES[id(table)] = (weakref.ref(table), table._version, inv)
+    return inv
 
 
 class OctreeDWConvFunction(Function):
-    """libs/dwconv/dwconv/nn.py:17-43"""
+    """out[h, c] = sum_k weights[k, 0, c] * data[neigh[h, k], c]  (libs/dwconv/dwconv/nn.py:17-43).
+    d/d data is the same kernel driven by the inverse table, d/d weights a slab reduction
+    (`hfl_dwconv_weight_backward`)."""
 
     @staticmethod
     def forward(ctx, data: torch.Tensor, weights: torch.Tensor, neigh: torch.Tensor):
-        data, weights, neigh = data.contiguous(), weights.contiguous(), neigh.contiguous()
-        out = ops.dwconv_forward_backward(data, weights, neigh)
-        ctx.save_for_backward(data, weights, neigh)
-        return out
+        operands = tuple(t.contiguous() for t in (data, weights, neigh))
+        ctx.save_for_backward(*operands)
+        return ops.dwconv_forward_backward(*operands)
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad_out):
         data, weights, neigh = ctx.saved_tensors
-        grad = grad.contiguous()
-        grad_d = grad_w = None
-        if ctx.needs_input_grad[0]:
-            grad_d = ops.dwconv_forward_backward(grad, weights, ops.inverse_neigh(neigh))
-        if ctx.needs_input_grad[1]:
-            grad_w = ops.dwconv_weight_backward(grad, data, neigh)
-        return grad_d, grad_w, None
+        want_data, want_weights = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = grad_out.contiguous()
+        d_data = ops.dwconv_forward_backward(g, weights, _inverse_of(neigh)) if want_data else None
+        d_weights = ops.dwconv_weight_backward(g, data, neigh) if want_weights else None
+        return d_data, d_weights, None
 
 
 octree_dwconv = OctreeDWConvFunction.apply
 
 
+def _kernel_code(kernel_size: Sequence[int]) -> str:
+    ks = list(kernel_size) * 3 if len(kernel_size) == 1 else list(kernel_size)
+    assert len(ks) == 3
+    return ''.join(str(k) for k in ks)
+
+
 class OctreeDWConv(torch.nn.Module):
-    """libs/dwconv/dwconv/nn.py:49-63 (parameter `weights` (kdim,1,C), optional `bias`)."""
+    """`dwconv.OctreeDWConv(channels, kernel_size=[3], nempty=False, use_bias=False)`
+    (libs/dwconv/dwconv/nn.py:49-63 over `ocnn.nn.OctreeDWConv`): parameter `weights` (kdim, 1, C),
+    optional `bias` (C); `forward(data, octree, depth)`."""
 
     def __init__(self, channels: int, kernel_size: List[int] = [3], nempty: bool = False,
                  use_bias: bool = False):
         super().__init__()
-        ks = list(kernel_size) * 3 if len(kernel_size) == 1 else list(kernel_size)
-        self.kernel = ''.join(str(k) for k in ks)
-        self.kdim = ks[0] * ks[1] * ks[2]
-        self.stride = 1
-        self.nempty = nempty
-        self.use_bias = use_bias
+        self.kernel = _kernel_code(kernel_size)
+        self.kdim = int(self.kernel[0]) * int(self.kernel[1]) * int(self.kernel[2])
         self.in_channels = self.out_channels = channels
+        self.stride, self.nempty, self.use_bias = 1, nempty, use_bias
         self.weights = torch.nn.Parameter(torch.empty(self.kdim, 1, channels))
         torch.nn.init.xavier_uniform_(self.weights)
-        if use_bias:
-            self.bias = torch.nn.Parameter(torch.zeros(channels))
+        self.bias: Optional[torch.nn.Parameter] = torch.nn.Parameter(torch.zeros(channels)) if use_bias else None
 
     def forward(self, data: torch.Tensor, octree, depth: int):
-        neigh = octree.get_neigh(depth, self.kernel, self.stride, self.nempty)
-        out = octree_dwconv(data, self.weights, neigh)
-        if self.use_bias:
-            out = out + self.bias
-        return out
+        table = octree.get_neigh(depth, self.kernel, self.stride, self.nempty)
+        y = octree_dwconv(data, self.weights, table)
+        return y if self.bias is None else y + self.bias

@@ -37,34 +37,29 @@ def _unsupported(params: ModelParams):
                                   + ', '.join(bad))
 
 
+# constructor argument <- ModelParams field (the reads of models/model_factory.py:27-70 that the shipped
+# configs exercise; the remaining ones are checked by _unsupported above)
+_BACKBONE_ARGS = {
+    'channels': 'channels', 'num_blocks': 'num_blocks', 'num_heads': 'num_heads',
+    'num_pyramid_levels': 'num_pyramid_levels', 'num_octf_levels': 'num_octf_levels',
+    'patch_size': 'patch_size', 'dilation': 'dilation', 'drop_path': 'drop_path',
+    'stem_down': 'num_input_downsamples', 'ADaPE_mode': 'ADaPE_mode', 'disable_RPE': 'disable_RPE',
+    'conv_norm': 'conv_norm', 'qkv_init': 'qkv_init',
+}
+_POOLING_ARGS = {
+    'pool_method': 'pooling', 'in_dim': 'feature_size', 'output_dim': 'output_dim',
+    'num_pyramid_levels': 'num_pyramid_levels', 'k_pooled_tokens': 'k_pooled_tokens',
+}
+
+
 def model_factory(model_params: ModelParams):
-    if 'hotformerloc' not in model_params.model.lower():
-        raise NotImplementedError('Model not implemented: {}'.format(model_params.model))
-    _unsupported(model_params)
-    backbone = HOTFormer(
-        in_channels=get_in_channels(model_params.input_features),
-        channels=model_params.channels,
-        num_blocks=model_params.num_blocks,
-        num_heads=model_params.num_heads,
-        num_pyramid_levels=model_params.num_pyramid_levels,
-        num_octf_levels=model_params.num_octf_levels,
-        patch_size=model_params.patch_size,
-        dilation=model_params.dilation,
-        drop_path=model_params.drop_path,
-        stem_down=model_params.num_input_downsamples,
-        ADaPE_mode=model_params.ADaPE_mode,
-        disable_RPE=model_params.disable_RPE,
-        conv_norm=model_params.conv_norm,
-        qkv_init=model_params.qkv_init,
-    )
-    pooling = PoolingWrapper(
-        pool_method=model_params.pooling,
-        in_dim=model_params.feature_size,
-        output_dim=model_params.output_dim,
-        num_pyramid_levels=model_params.num_pyramid_levels,
-        channels=model_params.channels[model_params.num_octf_levels:],
-        k_pooled_tokens=model_params.k_pooled_tokens,
-    )
-    return HOTFormerLoc(backbone=backbone, pooling=pooling,
-                        normalize_embeddings=model_params.normalize_embeddings,
-                        input_features=model_params.input_features)
+    p = model_params
+    if 'hotformerloc' not in p.model.lower():
+        raise NotImplementedError('Model not implemented: {}'.format(p.model))
+    _unsupported(p)
+    backbone = HOTFormer(in_channels=get_in_channels(p.input_features),
+                         **{arg: getattr(p, field) for arg, field in _BACKBONE_ARGS.items()})
+    pooling = PoolingWrapper(channels=p.channels[p.num_octf_levels:],
+                             **{arg: getattr(p, field) for arg, field in _POOLING_ARGS.items()})
+    return HOTFormerLoc(backbone=backbone, pooling=pooling, normalize_embeddings=p.normalize_embeddings,
+                        input_features=p.input_features)
