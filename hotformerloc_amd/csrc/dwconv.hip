@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4* s_w = reinterpret_cast<float4*>(smem);
   int32_t* s_idx = reinterpret_cast<int32_t*>(smem + (size_t)K * C * sizeof(float));
+  unsigned char* s_tap = reinterpret_cast<unsigned char*>(s_idx + (256 / TPR) * K);
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
   for (int i = threadIdx.x; i < K * TPR; i += blockDim.x)
     s_w[i] = reinterpret_cast<const float4*>(weight)[i];
@@ -265,28 +266,63 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
     const int64_t h = base + ty;
     const bool live = h < n_rows;
     __syncthreads();
-    if (live)
+    // Live taps of the row, compacted (tap, neighbour row): octree neighbourhoods are sparse (17.7 of 27 taps
+    // at depth 4, 5.6 at depth 5) and the kernel is bound by the L1/TA request rate, so dead taps must not
+    // cost a request.  TPR >= 27 lanes own the row: ballot + prefix popcount, order of k preserved.
+    int n_live = 0;
+    if (TPR >= kMaxTaps) {
+      const int ni = (live && tx < K) ? neigh[h * K + tx] : -1;
+      const unsigned long long bal = __ballot(ni >= 0);
+      const int shift = (threadIdx.x & 63) - tx;                     // first lane of this row inside the wave
+      const unsigned mask = (unsigned)((bal >> shift) & ((1ull << kMaxTaps) - 1ull));
+      n_live = __popc(mask);
+      if (ni >= 0) {
+        const int rank = __popc(mask & ((1u << tx) - 1u));
+        s_idx[ty * K + rank] = ni;
+        s_tap[ty * K + rank] = (unsigned char)tx;
+      }
+    } else if (live) {
       for (int k = tx; k < K; k += TPR) s_idx[ty * K + k] = neigh[h * K + k];
+    }
     __syncthreads();
     // all lanes of a wave stay in the loop body: the butterflies below need every lane
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int B = 9;
+    if (TPR >= kMaxTaps) {
 #pragma unroll 1
-    for (int k0 = 0; k0 < K; k0 += B) {
-      float4 v[B];
-      bool ok[B];
+      for (int k0 = 0; k0 < n_live; k0 += B) {
+        float4 v[B];
+        int e[B];
 #pragma unroll
-      for (int j = 0; j < B; ++j) {
-        const int k = k0 + j;
-        int64_t ni = (live && k < K) ? (int64_t)s_idx[ty * K + k] : -1;
-        ok[j] = ni >= 0;
-        if (!ok[j]) ni = 0;
-        v[j] = reinterpret_cast<const float4*>(x + ni * C)[tx];
+        for (int j = 0; j < B; ++j) {                 // past the end: repeat the last live tap (same line, weight 0)
+          e[j] = ty * K + min(k0 + j, n_live - 1);
+          v[j] = reinterpret_cast<const float4*>(x + (int64_t)s_idx[e[j]] * C)[tx];
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+          float4 w = s_w[(int)s_tap[e[j]] * TPR + tx];
+          if (k0 + j >= n_live) w = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc = hfl_fma4(w, v[j], acc);
+        }
       }
+    } else {
+#pragma unroll 1
+      for (int k0 = 0; k0 < K; k0 += B) {
+        float4 v[B];
+        bool ok[B];
 #pragma unroll
-      for (int j = 0; j < B; ++j) {
-        const int k = k0 + j;
-        if (k < K && ok[j]) acc = hfl_fma4(s_w[k * TPR + tx], v[j], acc);
+        for (int j = 0; j < B; ++j) {
+          const int k = k0 + j;
+          int64_t ni = (live && k < K) ? (int64_t)s_idx[ty * K + k] : -1;
+          ok[j] = ni >= 0;
+          if (!ok[j]) ni = 0;
+          v[j] = reinterpret_cast<const float4*>(x + ni * C)[tx];
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+          const int k = k0 + j;
+          if (k < K && ok[j]) acc = hfl_fma4(s_w[k * TPR + tx], v[j], acc);
+        }
       }
     }
     const float inv_c = 1.0f / (float)C;
@@ -510,7 +546,7 @@ static int launch_cpe(float* out, const float* x, const float* w, const float* g
                       const float* beta, const int32_t* neigh, int64_t n, int K, float eps,
                       int residual, hipStream_t s) {
   constexpr int RPB = 256 / TPR;
-  const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * sizeof(int32_t);
+  const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * (sizeof(int32_t) + 1) + 16;
   const int64_t need = hfl_cdiv(n, RPB);
   const int blocks = (int)(need < (int64_t)hfl_num_cus() * 8 ? need : (int64_t)hfl_num_cus() * 8);
   cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual,

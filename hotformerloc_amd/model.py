@@ -82,6 +82,7 @@ _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 # at 191 ms/step (B=32, Wild-Places) still slower than the fp32 hipBLASLt route (145 ms) because the operand
 # splits of the backward are torch element-wise passes; needs fused split kernels to pay off.
 _TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
+_SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
 
@@ -198,12 +199,36 @@ class OctreeConv(nn.Module):
         nn.init.xavier_uniform_(self.weights)
 
     def forward(self, data: torch.Tensor, octree, depth: int):
+        if (_SPARSE_CONV and self.kernel == '333' and self.stride == 1 and self.in_channels >= 32
+                and self.bias is None and data.is_cuda and not _grad_path(data)):
+            return self._forward_live_taps(data, octree, depth)
         neigh = octree.get_neigh(depth, self.kernel, self.stride, nempty=True)
         col = ag.octree_gather(data, neigh) if _grad_path(data) else ops.octree_gather(data, neigh)
         w = self.weights.reshape(self.kdim * self.in_channels, self.out_channels)
         if self.bias is not None:
             return torch.addmm(self.bias, col, w)
         return torch.mm(col, w)
+
+
+    def _forward_live_taps(self, data, octree, depth):
+        """3x3x3 conv over the LIVE taps only.  The dense form gathers (N, 27*Cin) -- 80 % zeros on surface-like
+        clouds (5.6 live taps of 27 at depth 5, 4 at depth 6) -- and multiplies all of it.  Here: gather one row
+        per live (row, tap) pair in tap-major order, one GEMM per tap on its contiguous slice (W[k] is (Cin, Cout)),
+        then every output row sums its own partial products through the slot table (the depth-wise conv kernel
+        with unit weights: no atomics, fixed summation order)."""
+        src, slot, edges = octree.sparse_taps(depth)
+        g = ops.octree_gather(data, src)                                  # (P, Cin)
+        part = torch.empty((g.shape[0], self.out_channels), dtype=torch.float32, device=data.device)
+        w = self.weights
+        for k in range(self.kdim):
+            a, b = edges[k], edges[k + 1]
+            if b > a:
+                torch.mm(g[a:b], w[k], out=part[a:b])
+        ones = self.__dict__.get('_unit_taps')
+        if ones is None or ones.device != data.device:
+            ones = torch.ones((self.kdim, 1, self.out_channels), dtype=torch.float32, device=data.device)
+            self.__dict__['_unit_taps'] = ones
+        return ops.dwconv_forward_backward(part, ones, slot)
 
 
 class OctreeDWConvParams(nn.Module):
