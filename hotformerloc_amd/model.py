@@ -199,8 +199,8 @@ class OctreeConv(nn.Module):
         nn.init.xavier_uniform_(self.weights)
 
     def forward(self, data: torch.Tensor, octree, depth: int):
-        if (_SPARSE_CONV and self.kernel == '333' and self.stride == 1 and self.in_channels >= 32
-                and self.bias is None and data.is_cuda and not _grad_path(data)):
+        if (_SPARSE_CONV and (self.kernel, self.stride) in (('333', 1), ('222', 2)) and self.in_channels >= 32
+                and data.is_cuda and not _grad_path(data)):
             return self._forward_live_taps(data, octree, depth)
         neigh = octree.get_neigh(depth, self.kernel, self.stride, nempty=True)
         col = ag.octree_gather(data, neigh) if _grad_path(data) else ops.octree_gather(data, neigh)
@@ -211,12 +211,12 @@ class OctreeConv(nn.Module):
 
 
     def _forward_live_taps(self, data, octree, depth):
-        """3x3x3 conv over the LIVE taps only.  The dense form gathers (N, 27*Cin) -- 80 % zeros on surface-like
+        """3x3x3 (stride 1) or 2x2x2 (stride 2) conv over the LIVE taps only.  The dense form gathers (N, 27*Cin) -- 80 % zeros on surface-like
         clouds (5.6 live taps of 27 at depth 5, 4 at depth 6) -- and multiplies all of it.  Here: gather one row
         per live (row, tap) pair in tap-major order, one GEMM per tap on its contiguous slice (W[k] is (Cin, Cout)),
         then every output row sums its own partial products through the slot table (the depth-wise conv kernel
         with unit weights: no atomics, fixed summation order)."""
-        src, slot, edges = octree.sparse_taps(depth)
+        src, slot, edges = octree.sparse_taps(depth, self.kernel, self.stride)
         g = ops.octree_gather(data, src)                                  # (P, Cin)
         part = torch.empty((g.shape[0], self.out_channels), dtype=torch.float32, device=data.device)
         w = self.weights
@@ -228,7 +228,8 @@ class OctreeConv(nn.Module):
         if ones is None or ones.device != data.device:
             ones = torch.ones((self.kdim, 1, self.out_channels), dtype=torch.float32, device=data.device)
             self.__dict__['_unit_taps'] = ones
-        return ops.dwconv_forward_backward(part, ones, slot)
+        out = ops.dwconv_forward_backward(part, ones, slot)
+        return out if self.bias is None else out + self.bias
 
 
 class OctreeDWConvParams(nn.Module):

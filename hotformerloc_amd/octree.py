@@ -215,26 +215,29 @@ class Octree:
         cols = torch.tensor(_KERNEL_LUT[kernel], device=neigh.device)
         return neigh[:, cols].contiguous()
 
-    def sparse_taps(self, depth: int):
+    def sparse_taps(self, depth: int, kernel: str = '333', stride: int = 1):
         """Tap-major list of the live (row, tap) pairs of the 27-neighbour table at `depth` (octree convolutions over
         surface-like clouds touch 4-6 of their 27 taps): returns
             src   (P, 1) int32  input row of every pair, pairs ordered by tap then by output row,
-            slot  (nne_d, 27) int32  position of (row, tap) in that list, -1 where the neighbour is missing,
-            edges list of 28 ints (host)  pairs of tap k are [edges[k], edges[k+1]).
+            slot  (rows, taps) int32  position of (row, tap) in that list, -1 where the neighbour is missing,
+            edges list of taps+1 ints (host)  pairs of tap k are [edges[k], edges[k+1]).
+        kernel '333' stride 1: the 27-neighbour table; kernel '222' stride 2: the eight children of every parent.
         Built once per (octree, depth) -- one device->host read of the 27 counts -- and cached like the tables."""
         cache = self.__dict__.setdefault('_sparse_taps', {})
-        if depth not in cache:
-            neigh = self.get_neigh(depth, '333', 1, nempty=True)
-            live_t = (neigh >= 0).t().contiguous()                       # (27, n): tap-major
+        key = (depth, kernel, stride)
+        if key not in cache:
+            neigh = self.get_neigh(depth, kernel, stride, nempty=True)   # (rows, taps); stride 2: the 8 children
+            taps = neigh.shape[1]
+            live_t = (neigh >= 0).t().contiguous()                       # (taps, n): tap-major
             rank = torch.cumsum(live_t.reshape(-1).to(torch.int32), 0, dtype=torch.int32) - 1
-            slot = torch.where(live_t, rank.view(27, -1), torch.full_like(rank.view(27, -1), -1)).t().contiguous()
+            slot = torch.where(live_t, rank.view(taps, -1), torch.full_like(rank.view(taps, -1), -1)).t().contiguous()
             src = neigh.t()[live_t].to(torch.int32).view(-1, 1).contiguous()
             counts = live_t.sum(1).tolist()
             edges = [0]
             for c in counts:
                 edges.append(edges[-1] + int(c))
-            cache[depth] = (src, slot, edges)
-        return cache[depth]
+            cache[key] = (src, slot, edges)
+        return cache[key]
 
     def get_input_feature(self, feature: str = 'P', nempty: bool = True):
         """`ocnn.modules.InputFeature('P', nempty=True)` (models/hotformerloc.py:28-31):
