@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--multistaged', action='store_true',
                     help='with --train: the full multi-staged step (stage 1 no-grad encode, TruncatedSmoothAP on the '
                          'all-gathered descriptors, stage 3 forward+backward, gradient all-reduce, AdamW step)')
+    ap.add_argument('--no-collective', action='store_true', help='A/B: skip the descriptor all-gather (N > 1 diagnostics)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=16, help='clouds in the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=16,
@@ -119,7 +120,9 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', device_id=dev)
+        # no device_id: binding the group to the device at init (eager communicator) cost 0.8 ms per step on the
+        # host-bound issue path of this model (19.3 vs 20.1 ms/step at N=1 under the launcher)
+        dist.init_process_group('nccl')
 
     params, depth = load_config(args.config)
     model = model_factory(params)
@@ -167,7 +170,7 @@ def main():
             (y * proj).sum().backward()
             return y.detach()
         y = model(batch)['global']
-        if use_dist:
+        if use_dist and not args.no_collective:
             all_gather_descriptors(y, args.batch * world, force=True)      # (B_total, 256) on every rank
         return y
 
@@ -182,14 +185,14 @@ def main():
             torch.cuda.synchronize()
             log('warmup step', i)
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
         with ops.KernelTimer() as timer:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 y = step()
             if use_dist:
-                dist.barrier()
+                dist.barrier(device_ids=[local_rank])
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
         kern = timer.summary()
