@@ -7,22 +7,26 @@ GPU over RCCL.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by
 `torch.cuda.synchronize()`; max over ranks; rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): batch of 32 synthetic 4096-point clouds per GPU,
-Wild-Places cfg (octree depth 7, cylindrical, K=48), forward only, eval mode, fp32, random-init
+Wild-Places cfg (octree depth 7, cylindrical, K=48), forward only, eval mode, random-init
 style closed-form weights; the batch octree is resident on the device with neighbour tables
 built when the timed region starts (the reference's model boundary: `misc/torch_utils.py:47-51`
 happens before `model(batch)`).  A step = `model(batch)['global']` on every rank followed, for
 N > 1, by the RCCL all-gather of the (B_local,256) descriptors.  Weak scaling: each rank
 encodes its own contiguous slice of the global batch.
 
-Extra objects on the JSON line: `roofline` for the dominant hand-written kernel (windowed
-attention) from HIP events recorded around every launch inside the timed region, and
-`cpu_baseline` = the CPU oracle (a port of the reference forward) timed on this box's host cores
-on a bounded sample of the same workload (rank 0, N=1 only).
+What one default run times (all with the same W-warm-up / K-step / barrier protocol, on rank 0 at N = 1):
+  value          Linear layers as 3-term split-bf16 products with fp32 accumulation (`--gemm bf16x3`)
+  fp32_linear    the same forward with every Linear as an fp32 GEMM -- the reference's arithmetic
+  e2e            a FRESH octree per step: device build + neighbour tables + tap lists + window plan + forward
+                 (SURVEY 8d "report separately the end-to-end rate including device octree build")
+and then, outside any timed value: the `roofline` legs (HIP events per launch) and the `cpu_baseline`
+(the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol).
 """
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -35,19 +39,23 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+ATTN = 'hfl_window_attention_fwd'
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='wild-places')
-    ap.add_argument('--batch', type=int, default=32, help='clouds per GPU')
+    ap.add_argument('--batch', type=int, default=None, help='clouds per GPU (default 32; 64 for cs-wild-places --train)')
     ap.add_argument('--points', type=int, default=4096)
+    ap.add_argument('--points-max', type=int, default=None,
+                    help='variable density: per-cloud point count ~ U{points..points_max}, forest / unit-ball mix '
+                         '(default for cs-wild-places: 32768, BASELINE config 3)')
     ap.add_argument('--gemm', default='bf16x3', choices=['bf16x3', 'fp32'],
-                    help="Linear layers: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) operands, fp32 "
-                         "accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
+                    help="Linear layers of the headline `value`: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) "
+                         "operands, fp32 accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
     ap.add_argument('--attn-variant', type=int, default=0, help='A/B: window attention kernel variant (0 = default)')
     ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
@@ -55,16 +63,19 @@ def parse():
                     help='with --train: the full multi-staged step (stage 1 no-grad encode, TruncatedSmoothAP on the '
                          'all-gathered descriptors, stage 3 forward+backward, gradient all-reduce, AdamW step)')
     ap.add_argument('--no-collective', action='store_true', help='A/B: skip the descriptor all-gather (N > 1 diagnostics)')
+    ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no fp32 / e2e / roofline legs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=16, help='clouds in the CPU baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=16,
                     help='torch threads of the CPU baseline (8-16 is the optimum measured on the 2x64-core host; more threads are slower)')
+    ap.add_argument('--cpu-budget-s', type=float, default=240.0,
+                    help='stop adding timed CPU runs once this much wall time is spent (at least 1 run per batch size)')
     return ap.parse_args()
 
 
 def cpu_baseline(params, depth, args):
-    """Oracle forward (port of the reference, torch CPU fp32) on the first `cpu_sample` clouds
-    of the same workload; returns the dict for the JSON line."""
+    """Oracle forward (port of the reference, torch CPU fp32), BASELINE.md section 3: octree prebuilt with neighbour
+    tables (the model boundary), eval / inference mode, 2 warm-ups + 5 timed runs, median, at B=1 (BASELINE config 1)
+    and at the GPU workload's batch (B=32, the first clouds of the same workload).  Bounded by --cpu-budget-s."""
     import torch
     from hotformerloc_amd import synthetic as syn
     from oracle import hotformer_ref
@@ -72,23 +83,35 @@ def cpu_baseline(params, depth, args):
     cores = min(args.cpu_threads, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     sd = synthetic_state_dict(params, 'init')
-    warm = syn.make_clouds(2, 2, args.points, params.coordinates)
-    log('cpu baseline: warm-up on %d threads' % cores)
-    hotformer_ref.forward(sd, params, oracle_octree(warm, depth))            # warm-up, B=2
-    log('cpu baseline: timed sample')
-    clouds = syn.make_clouds(2, args.cpu_sample, args.points, params.coordinates)
-    per = 8                                                                  # clouds per CPU batch
-    octrees = [oracle_octree(clouds[i:i + per], depth) for i in range(0, len(clouds), per)]   # boundary: prebuilt
-    t0 = time.perf_counter()
-    for octree in octrees:
-        hotformer_ref.forward(sd, params, octree)
-    dt = time.perf_counter() - t0
-    return {'value': round(args.cpu_sample / dt, 4), 'unit': 'clouds/s', 'cores': cores,
-            'kind': 'port',
-            'sample': 'oracle forward, %d batch(es) of <=%d clouds x %d pts (first %d clouds of the GPU workload), '
-                      '%s cfg, %.1f s, torch %d threads (host has %d logical CPUs)'
-                      % (len(octrees), per, args.points, args.cpu_sample, args.config, dt,
-                         torch.get_num_threads(), os.cpu_count() or 1)}
+    t_start = time.perf_counter()
+    out = {}
+    for b in (1, args.batch):
+        clouds = syn.make_clouds(2, b, args.points, params.coordinates)
+        t0 = time.perf_counter()
+        octree = oracle_octree(clouds, depth)                                # boundary: prebuilt, timed separately
+        t_build = time.perf_counter() - t0
+        runs = []
+        for i in range(2 + 5):
+            if i >= 3 and time.perf_counter() - t_start > args.cpu_budget_s * (0.1 if b == 1 else 1.0):
+                break
+            t0 = time.perf_counter()
+            with torch.inference_mode():
+                hotformer_ref.forward(sd, params, octree)
+            dt = time.perf_counter() - t0
+            log('cpu baseline: B=%d run %d %.2f s%s' % (b, i, dt, ' (warm-up)' if i < 2 else ''))
+            if i >= 2:
+                runs.append(dt)
+        med = statistics.median(runs)
+        out[b] = {'clouds_per_s': round(b / med, 4), 'median_s': round(med, 3), 'timed_runs': len(runs),
+                  'warmups': 2, 'octree_build_s': round(t_build, 3)}
+    big = out[args.batch]
+    return {'value': big['clouds_per_s'], 'unit': 'clouds/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle forward (CPU port of the reference), %s cfg, first %d clouds x %d pts of the GPU workload as '
+                      'one batch, octree + neighbours prebuilt, 2 warm-ups + %d timed runs, median %.2f s; torch %d '
+                      'threads (host has %d logical CPUs)'
+                      % (args.config, args.batch, args.points, big['timed_runs'], big['median_s'],
+                         torch.get_num_threads(), os.cpu_count() or 1),
+            'b1': out[1], 'b%d' % args.batch: big}
 
 
 _T0 = time.perf_counter()
@@ -107,6 +130,10 @@ def main():
     from hotformerloc_amd.model import set_gemm_mode, set_pyramid_streams
     set_gemm_mode(args.gemm)
     set_pyramid_streams(not args.no_streams)
+    if args.batch is None:
+        args.batch = 64 if (args.config == 'cs-wild-places' and args.train) else 32
+    if args.points_max is None and args.config == 'cs-wild-places':
+        args.points_max = 32768
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -125,14 +152,21 @@ def main():
         dist.init_process_group('nccl')
 
     params, depth = load_config(args.config)
+    if args.train:
+        params.drop_path = 0.0
     model = model_factory(params)
     syn.fill_synthetic_weights(model, 'init')
     model = model.to(dev).eval()
     log('model ready')
 
     # this rank's contiguous slice of the global batch (ordered)
-    clouds = syn.make_clouds(2, args.batch, args.points, params.coordinates,
-                             first_index=rank * args.batch)
+    if args.points_max:
+        clouds = []
+        for i in range(rank * args.batch, (rank + 1) * args.batch):        # forest / unit-ball mix, n ~ U{points..max}
+            clouds += syn.make_clouds(3, 1, args.points, params.coordinates, kind='forest' if i % 2 == 0 else 'ball',
+                                      n_points_max=args.points_max, first_index=i)
+    else:
+        clouds = syn.make_clouds(2, args.batch, args.points, params.coordinates, first_index=rank * args.batch)
     octree = build_batch_octree(clouds, depth, 2, dev, construct_neigh=True)
     batch = {'octree': octree}
     torch.cuda.synchronize()
@@ -144,9 +178,6 @@ def main():
 
     if args.train:
         model.train()
-        for m in model.modules():
-            if hasattr(m, 'drop_prob'):
-                m.drop_prob = 0.0
         proj = torch.from_numpy(syn.hash_uniform(99, args.batch * params.output_dim).reshape(
             args.batch, params.output_dim).astype('float32')).to(dev)
 
@@ -160,6 +191,8 @@ def main():
         loss_fn = TruncatedSmoothAP(tau1=0.01, positives_per_query=4)
         optim = torch.optim.AdamW(model.parameters(), lr=1e-5)
 
+    collective = use_dist and not args.no_collective and not args.train
+
     def step():
         if args.train and args.multistaged:
             multistaged_training_step(model, [batch], pos_mask, neg_mask, loss_fn, optim, n_total=n_tot)
@@ -170,50 +203,81 @@ def main():
             (y * proj).sum().backward()
             return y.detach()
         y = model(batch)['global']
-        if use_dist and not args.no_collective:
+        if collective:
             all_gather_descriptors(y, args.batch * world, force=True)      # (B_total, 256) on every rank
         return y
 
-    with (torch.enable_grad() if args.train else torch.inference_mode()):
-        # clock ramp-up, lazy code-object loads of every GEMM shape, allocator growth: a few untimed steps
-        # on top of the W the caller asked for (a fresh box has shown 25 % slower first processes)
-        for i in range(5):
-            step()
-        torch.cuda.synchronize()
-        for i in range(args.warmup):
-            step()
+    dev_clouds = [torch.from_numpy(c).to(dev) for c in clouds]             # e2e leg: points resident, octree not
+
+    def step_e2e():
+        fresh = build_batch_octree(dev_clouds, depth, 2, dev, construct_neigh=True)
+        return model({'octree': fresh})['global']
+
+    def timed(fn, steps, warmup, timer=None):
+        """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; seconds (this rank)."""
+        for i in range(warmup):
+            fn()
             torch.cuda.synchronize()
-            log('warmup step', i)
         if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
-        with ops.KernelTimer() as timer:
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                y = step()
-            if use_dist:
-                dist.barrier(device_ids=[local_rank])
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-        kern = timer.summary()
-        # Roofline leg: the same K steps once more with the pyramid depths on ONE stream.  In the timed
-        # region above three streams share the GPU, so a kernel's start-to-end HIP-event time includes
-        # the CUs it lent to its neighbours; serialised, the events bracket the kernel alone (this is
-        # also what rocprofv3 --kernel-trace reports: profiles/r01_c_summary.md).  Not part of `value`.
-        kern_iso = None
-        if not args.no_streams and not args.train:
-            from hotformerloc_amd.model import set_pyramid_streams
-            set_pyramid_streams(False)
-            model(batch)
-            torch.cuda.synchronize()
-            with ops.KernelTimer() as timer_iso:
+        if timer is not None:
+            timer.__enter__()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = fn()
+        if use_dist:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if timer is not None:
+            timer.__exit__(None, None, None)
+        assert torch.isfinite(y).all()
+        return dt
+
+    extras = world == 1 and not args.train and not args.no_extras
+    fp32_line = e2e_line = kern_iso = kern_all = None
+    with (torch.enable_grad() if args.train else torch.inference_mode()):
+        # ---- the headline: W warm-ups, K timed steps.  Inside the timed region only the roofline kernel carries
+        # HIP events (2 per launch, 34 launches per step); everything else runs un-instrumented.
+        timer = ops.KernelTimer(only=[ATTN]) if not args.train else None
+        elapsed = timed(step, args.steps, args.warmup, timer)
+        kern = timer.summary() if timer is not None else {}
+        log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
+        if extras:
+            other = 'fp32' if args.gemm == 'bf16x3' else 'bf16x3'
+            set_gemm_mode(other)
+            dt = timed(step, args.steps, args.warmup)
+            set_gemm_mode(args.gemm)
+            fp32_line = {'gemm': other, 'value': round(args.batch * args.steps / dt, 2), 'unit': 'clouds/s',
+                         'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup}
+            log('%s Linear leg: %.3f s' % (other, dt))
+            dt = timed(step_e2e, args.steps, args.warmup)
+            e2e_line = {'value': round(args.batch * args.steps / dt, 2), 'unit': 'clouds/s',
+                        'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                        'what': 'fresh octree every step from device-resident points: HIP octree build + merge + '
+                                'neighbour tables + live-tap lists (one device->host read of counts each for build and '
+                                'taps) + window plan + forward'}
+            log('e2e leg: %.3f s' % dt)
+            # ---- roofline legs (not part of any value): every hand-written kernel instrumented, streams as in the
+            # timed region, then once more with the pyramid depths on ONE stream.  With three streams sharing the GPU
+            # a kernel's start-to-end event time includes the CUs it lent to its neighbours; serialised, the events
+            # bracket the kernel alone (what rocprofv3 --kernel-trace reports, profiles/).
+            with ops.KernelTimer() as t_all:
                 for _ in range(args.steps):
-                    model(batch)
+                    step()
                 torch.cuda.synchronize()
-            kern_iso = timer_iso.summary()
-            set_pyramid_streams(True)
-    log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
-    assert torch.isfinite(y).all()
+            kern_all = t_all.summary()
+            if not args.no_streams:
+                set_pyramid_streams(False)
+                step()
+                torch.cuda.synchronize()
+                with ops.KernelTimer(only=[ATTN]) as t_iso:
+                    for _ in range(args.steps):
+                        step()
+                    torch.cuda.synchronize()
+                kern_iso = t_iso.summary()
+                set_pyramid_streams(True)
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
@@ -222,51 +286,76 @@ def main():
 
     if rank == 0:
         total_clouds = args.batch * world * args.steps
-        n_c, ms_c, nbytes_c, _ = kern.get('hfl_window_attention_fwd', (0, 0.0, 0, 0))
-        n, ms, nbytes, flops = (kern_iso or kern).get('hfl_window_attention_fwd', (0, 0.0, 0, 0))
         roof = None
-        if n:
+        rec_t = kern.get(ATTN)
+        rec = (kern_iso or {}).get(ATTN) or rec_t
+        if rec:
+            n, ms, nbytes, flops, moved = rec
             gbs = nbytes / (ms * 1e-3) / 1e9
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
-                # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-                # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
-                rec = json.load(open(pmc)).get('window_attn_kernel_v4') or json.load(open(pmc)).get('window_attn_kernel_v2')
-                if rec:
-                    traffic, traffic_src = rec['hbm_bytes_per_launch'], 'profiles/r01_pmc_traffic.json'
-            roof = {'kernel': 'hfl_window_attention_fwd', 'bound': 'hbm',
+            for cand in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+                pmc = os.path.join(ROOT, 'profiles', cand)
+                if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
+                    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+                    # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
+                    j = json.load(open(pmc))
+                    hit = [v for k, v in j.items() if k.startswith('window_attn_kernel') and isinstance(v, dict)]
+                    if hit:
+                        traffic, traffic_src = hit[0]['hbm_bytes_per_launch'], 'profiles/' + cand
+                        break
+            roof = {'kernel': ATTN, 'bound': 'hbm',
                     'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                     'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
                     'algorithmic_bytes_per_launch': int(nbytes / n),
+                    'algorithmic_bytes': 'SURVEY 8(d): 16 B x (row, channel) = read q,k,v + write out in f32',
+                    'moved_bytes_per_launch': int(moved / n),
                     'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 2),
                     'mfma_frac': round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                     'timing': ('HIP events per launch over %d steps, pyramid streams serialised (re-run right '
-                               'after the timed region)' % args.steps) if kern_iso else
-                              'HIP events per launch over the timed region',
-                    'frac_in_timed_region': round(nbytes_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if n_c else None}
+                               'after the timed region; agrees with rocprofv3 --kernel-trace)' % args.steps) if kern_iso else
+                              'HIP events per launch inside the timed region'}
+            if rec_t:
+                nt_, mst, bt, _, _ = rec_t
+                roof['timed_region'] = {'frac': round(bt / (mst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        'avg_launch_us': round(mst * 1e3 / nt_, 2), 'launches': nt_,
+                                        'note': 'events inside the timed region; three HIP streams overlap, so a launch '
+                                                'shares the CUs with its neighbours'}
         others = {}
-        for name, (kn, kms, kb, kf) in kern.items():
+        for name, (kn, kms, kb, kf, kmv) in (kern_all or {}).items():
             others[name] = {'launches_per_step': kn // args.steps,
                             'ms_per_step': round(kms / args.steps, 4),
                             'GBps': round(kb / (kms * 1e-3) / 1e9, 1) if kms > 0 else None}
+        mode_txt = {'fp32': 'f32',
+                    'bf16x3': 'f32 (Linear products as 3-term bf16 split, f32 accumulate; fp32_linear = all-f32 rate)'}
         line = {
             'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)', 'value': round(total_clouds / elapsed, 2),
             'unit': 'clouds/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.gemm == 'fp32' else 'f32 (Linear products as 3-term bf16 split, f32 accumulate)',
+            'dtype': mode_txt[args.gemm],
             'data': 'synthetic',
-            'config': {'workload': '%s cfg, batch=%d clouds/GPU x %d pts, octree depth %d, %s, '
-                                   'octree+neighbours resident' % (args.config, args.batch, args.points, depth,
-                                                                   ('multi-staged training step (stage 1 + TruncatedSmoothAP + stage 3 + grad all-reduce + AdamW)'
-                                                                    if args.multistaged else 'forward+backward') if args.train else 'forward-only'),
+            'config': {'workload': '%s cfg, batch=%d clouds/GPU x %s pts, octree depth %d, %s, '
+                                   'octree+neighbours resident'
+                                   % (args.config, args.batch,
+                                      '%d..%d (forest/ball mix)' % (args.points, args.points_max) if args.points_max
+                                      else '%d' % args.points, depth,
+                                      ('multi-staged training step (stage 1 + TruncatedSmoothAP + stage 3 + grad all-reduce + AdamW)'
+                                       if args.multistaged else 'forward+backward') if args.train else 'forward-only'),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
-                       'collective': 'rccl all_gather (B_local,256) f32' if world > 1 else 'none'},
-            'roofline': roof, 'kernels': others,
+                       'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
+                                     ('rccl all_gather at world size 1' if collective else 'none')},
+            'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if fp32_line:
+            line['fp32_linear' if fp32_line['gemm'] == 'fp32' else 'bf16x3_linear'] = fp32_line
+        if e2e_line:
+            line['e2e'] = e2e_line
+        if others:
+            line['kernels'] = others
+        if args.train:
+            line['peak_memory_GiB'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        if world == 1 and not args.no_cpu_baseline and not args.train:
             line['cpu_baseline'] = cpu_baseline(params, depth, args)
             line['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)

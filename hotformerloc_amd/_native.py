@@ -50,6 +50,8 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     'hfl_token_meta': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'hfl_octree_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    'hfl_tap_lists_workspace': (c_int64, [c_int64, c_int]),
+    'hfl_tap_lists': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
     'hfl_window_attention_fwd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

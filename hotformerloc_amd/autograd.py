@@ -55,7 +55,7 @@ _INV_CACHE = {}
 
 
 def _inverse_table(neigh, n_src):
-    key = (neigh.data_ptr(), neigh.shape[0], neigh.shape[1], n_src)
+    key = (id(neigh), n_src)
     hit = _INV_CACHE.get(key)
     if hit is not None and hit[0]() is neigh:
         return hit[1]
@@ -63,8 +63,8 @@ def _inverse_table(neigh, n_src):
     inv = torch.empty((n_src, neigh.shape[1]), dtype=torch.int32, device=neigh.device)
     check(_native.load().hfl_inverse_table(inv.data_ptr(), n_src, neigh.data_ptr(), neigh.shape[0],
                                            neigh.shape[1], ops._stream()), 'hfl_inverse_table')
-    if len(_INV_CACHE) > 64:
-        _INV_CACHE.clear()
+    if hit is None:                       # evicted when the gather table dies (a new octree every training batch)
+        weakref.finalize(neigh, _INV_CACHE.pop, key, None)
     _INV_CACHE[key] = (weakref.ref(neigh), inv)
     return inv
 

@@ -12,7 +12,7 @@
 // Row-major operands map onto the column-major API as D^T (N x M) = op(A) . B with A = w (K' x N,
 // ld K', transposed) and B = a (K' x M, ld K').  Algorithms come from the library heuristic for the exact
 // problem and are cached; one 128 MiB workspace per stream (concurrent GEMMs on the pyramid streams must
-// not share one).
+// not share one).  hipBLASLt state is per device, workspaces per (device, stream); they live for the process.
 #include "hfl_common.h"
 
 #include <hipblaslt/hipblaslt.h>
@@ -32,12 +32,42 @@ struct LtPlan {
   bool ok = false;
 };
 
-typedef std::tuple<int64_t, int, int, int, int> LtKey;          // M, N, K, bias (2 = weight-gradient form), residual
+typedef std::tuple<int, int64_t, int, int, int, int> LtKey;     // device, M, N, K, bias (2 = weight-gradient form), residual
 
+// All state is per device (the handle binds to the device current at creation; the null stream is a different
+// queue on every device), workspaces per (device, stream).  Callers pass tensors of the CURRENT device.
 std::mutex g_lt_mutex;
-hipblasLtHandle_t g_lt_handle = nullptr;
+std::map<int, hipblasLtHandle_t> g_lt_handles;
+thread_local hipblasLtHandle_t g_lt_handle = nullptr;           // handle of the call in progress (set under the mutex)
 std::map<LtKey, LtPlan> g_lt_plans;
-std::map<hipStream_t, void*> g_lt_ws;
+std::map<std::pair<int, hipStream_t>, void*> g_lt_ws;
+
+// handle + workspace of the current device for `s`; HFL_OK or an error code
+int lt_context(hipStream_t s, int* device, void** ws_out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  hipblasLtHandle_t& h = g_lt_handles[dev];
+  if (h == nullptr) {
+    const hipblasStatus_t st = hipblasLtCreate(&h);
+    if (st != HIPBLAS_STATUS_SUCCESS) {
+      h = nullptr;
+      return HFL_EBACKEND - (int)st;
+    }
+  }
+  g_lt_handle = h;
+  void*& ws = g_lt_ws[std::make_pair(dev, s)];
+  if (ws == nullptr) {
+    e = hipMalloc(&ws, kLtWorkspace);
+    if (e != hipSuccess) {
+      ws = nullptr;
+      return (int)e;
+    }
+  }
+  *device = dev;
+  *ws_out = ws;
+  return HFL_OK;
+}
 
 void lt_destroy(LtPlan& p) {
   if (p.desc) hipblasLtMatmulDescDestroy(p.desc);
@@ -101,22 +131,13 @@ extern "C" int hfl_gemm_bf16(float* out, const uint16_t* a, const uint16_t* w, c
   if (n_rows == 0) return HFL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(g_lt_mutex);
-  if (g_lt_handle == nullptr) {
-    const hipblasStatus_t st = hipblasLtCreate(&g_lt_handle);
-    if (st != HIPBLAS_STATUS_SUCCESS) {
-      g_lt_handle = nullptr;
-      return HFL_EBACKEND - (int)st;
-    }
+  int dev = 0;
+  void* ws = nullptr;
+  {
+    const int rc = lt_context(s, &dev, &ws);
+    if (rc != HFL_OK) return rc;
   }
-  void*& ws = g_lt_ws[s];
-  if (ws == nullptr) {
-    const hipError_t e = hipMalloc(&ws, kLtWorkspace);
-    if (e != hipSuccess) {
-      ws = nullptr;
-      return (int)e;
-    }
-  }
-  const LtKey key(n_rows, out_features, k_concat, bias != nullptr, residual != nullptr);
+  const LtKey key(dev, n_rows, out_features, k_concat, bias != nullptr, residual != nullptr);
   if (g_lt_plans.size() > 4096) {                       // token counts change with every batch
     for (auto& kv : g_lt_plans) lt_destroy(kv.second);
     g_lt_plans.clear();
@@ -153,22 +174,13 @@ extern "C" int hfl_gemm_bf16_tn(float* out, const uint16_t* a, const uint16_t* b
     return HFL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   std::lock_guard<std::mutex> lock(g_lt_mutex);
-  if (g_lt_handle == nullptr) {
-    const hipblasStatus_t st = hipblasLtCreate(&g_lt_handle);
-    if (st != HIPBLAS_STATUS_SUCCESS) {
-      g_lt_handle = nullptr;
-      return HFL_EBACKEND - (int)st;
-    }
+  int dev = 0;
+  void* ws = nullptr;
+  {
+    const int rc = lt_context(s, &dev, &ws);
+    if (rc != HFL_OK) return rc;
   }
-  void*& ws = g_lt_ws[s];
-  if (ws == nullptr) {
-    const hipError_t e = hipMalloc(&ws, kLtWorkspace);
-    if (e != hipSuccess) {
-      ws = nullptr;
-      return (int)e;
-    }
-  }
-  const LtKey key(n_rows_stacked, n_out, k_out, 2, 0);
+  const LtKey key(dev, n_rows_stacked, n_out, k_out, 2, 0);
   if (g_lt_plans.size() > 4096) {
     for (auto& kv : g_lt_plans) lt_destroy(kv.second);
     g_lt_plans.clear();

@@ -377,6 +377,120 @@ __global__ void token_meta_kernel(uint32_t* __restrict__ meta, const int64_t* __
   meta[2 * t + 1] = (uint32_t)(key >> 48);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Live-tap lists of a (rows, taps) index table (taps <= 32): the tap-major list of the (row, tap) pairs whose
+// neighbour exists, for the octree convolutions that run over live taps only (model.py OctreeConv).
+//   src   (P)          input row of every pair, pairs ordered by tap, then by row
+//   slot  (rows, taps) position of (row, tap) in that list, -1 where the neighbour is missing
+//   edges (taps + 1)   pairs of tap k are [edges[k], edges[k+1])
+// Three launches, no atomics, fixed order: per-block per-tap counts (wave ballots), a scan over blocks
+// (one wave per tap), then the fill pass recomputes the ballots and writes.
+constexpr int kTapRows = 1024;         // rows per block (256 threads x 4)
+constexpr int kTapMax = 32;
+
+__global__ void __launch_bounds__(256)
+tap_count_kernel(const int32_t* __restrict__ table, int64_t rows, int taps, int32_t* __restrict__ block_counts) {
+  __shared__ int32_t wave_cnt[4][kTapMax];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t acc[kTapMax];
+#pragma unroll
+  for (int k = 0; k < kTapMax; ++k) acc[k] = 0;
+  const int64_t row0 = (int64_t)blockIdx.x * kTapRows;
+  for (int it = 0; it < kTapRows / 256; ++it) {
+    const int64_t r = row0 + it * 256 + threadIdx.x;
+    const bool in = r < rows;
+#pragma unroll
+    for (int k = 0; k < kTapMax; ++k) {
+      if (k < taps) {
+        const bool live = in && table[r * taps + k] >= 0;
+        acc[k] += __popcll(__ballot(live));
+      }
+    }
+  }
+  if (lane == 0)
+    for (int k = 0; k < taps; ++k) wave_cnt[wave][k] = acc[k];
+  __syncthreads();
+  if ((int)threadIdx.x < taps)
+    block_counts[(int64_t)blockIdx.x * taps + threadIdx.x] =
+        wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+}
+
+// one wave per tap (16 waves, taps k and k + 16): exclusive scan of that tap's block counts (in place), totals -> edges
+__global__ void __launch_bounds__(1024)
+tap_scan_kernel(int32_t* __restrict__ block_counts, int nblocks, int taps, int32_t* __restrict__ edges) {
+  __shared__ int32_t total[kTapMax];
+  const int lane = threadIdx.x & 63;
+  for (int k = threadIdx.x >> 6; k < taps; k += 16) {
+    int32_t run = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+      const int b = b0 + lane;
+      const int32_t v = b < nblocks ? block_counts[(int64_t)b * taps + k] : 0;
+      int32_t inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      if (b < nblocks) block_counts[(int64_t)b * taps + k] = run + inc - v;
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) total[k] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t e = 0;
+    for (int t = 0; t < taps; ++t) {
+      edges[t] = e;
+      e += total[t];
+    }
+    edges[taps] = e;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+tap_fill_kernel(const int32_t* __restrict__ table, int64_t rows, int taps, const int32_t* __restrict__ block_off,
+                const int32_t* __restrict__ edges, int32_t* __restrict__ src, int32_t* __restrict__ slot) {
+  __shared__ int32_t wave_cnt[4][kTapMax];
+  __shared__ int32_t base[kTapMax];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)threadIdx.x < taps) base[threadIdx.x] = edges[threadIdx.x] + block_off[(int64_t)blockIdx.x * taps + threadIdx.x];
+  const int64_t row0 = (int64_t)blockIdx.x * kTapRows;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int it = 0; it < kTapRows / 256; ++it) {
+    const int64_t r = row0 + it * 256 + threadIdx.x;
+    const bool in = r < rows;
+    int32_t v[kTapMax];
+    unsigned long long m[kTapMax];
+#pragma unroll
+    for (int k = 0; k < kTapMax; ++k) {
+      if (k < taps) {
+        v[k] = in ? table[r * taps + k] : -1;
+        m[k] = __ballot(v[k] >= 0);
+      }
+    }
+    __syncthreads();                       // base[] ready (first pass) / updated (later passes)
+    if (lane == 0)
+      for (int k = 0; k < taps; ++k) wave_cnt[wave][k] = __popcll(m[k]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kTapMax; ++k) {
+      if (k < taps) {
+        int32_t off = base[k];
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w][k];
+        const int32_t pos = off + __popcll(m[k] & lt);
+        if (in) {
+          slot[r * taps + k] = v[k] >= 0 ? pos : -1;
+          if (v[k] >= 0) src[pos] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < taps)
+      base[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] +
+                           wave_cnt[3][threadIdx.x];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -459,6 +573,25 @@ int hfl_token_meta(uint32_t* tok_meta, const int64_t* nkeys, int64_t n, int dept
   if (n == 0) return HFL_OK;
   token_meta_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
       tok_meta, nkeys, n, depth);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int64_t hfl_tap_lists_workspace(int64_t rows, int taps) {
+  return hfl_cdiv(rows > 0 ? rows : 1, kTapRows) * (int64_t)taps * (int64_t)sizeof(int32_t);
+}
+
+/* Live-tap lists of a (rows, taps) int32 index table (see above): src must hold rows*taps entries (only the
+ * first edges[taps] are written), slot (rows, taps), edges (taps + 1), all on the device; no host sync. */
+int hfl_tap_lists(int32_t* src, int32_t* slot, int32_t* edges, const int32_t* table, int64_t rows, int taps,
+                  void* workspace, hfl_stream_t stream) {
+  if (rows < 0 || taps < 1 || taps > kTapMax) return HFL_EINVAL;
+  if (rows * taps > 0x7fffffffLL) return HFL_ECAPACITY;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nblocks = (int)hfl_cdiv(rows > 0 ? rows : 1, kTapRows);
+  int32_t* bc = static_cast<int32_t*>(workspace);
+  tap_count_kernel<<<nblocks, 256, 0, s>>>(table, rows, taps, bc);
+  tap_scan_kernel<<<1, 1024, 0, s>>>(bc, nblocks, taps, edges);
+  tap_fill_kernel<<<nblocks, 256, 0, s>>>(table, rows, taps, bc, edges, src, slot);
   HFL_RETURN_LAST_ERROR();
 }
 

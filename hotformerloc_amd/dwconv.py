@@ -24,13 +24,14 @@ _INVERSE_TABLES = {}        # id(table) -> (weakref to the table, its version, i
 
 
 def _inverse_of(table: torch.Tensor) -> torch.Tensor:
-    hit = _INVERSE_TABLES.get(id(table))
+    key = id(table)
+    hit = _INVERSE_TABLES.get(key)
     if hit is not None and hit[0]() is table and hit[1] == table._version:
         return hit[2]
-    if len(_INVERSE_TABLES) > 256:
-        _INVERSE_TABLES.clear()
     inv = ops.inverse_neigh(table)
-    _INVERSE_TABLES[id(table)] = (weakref.ref(table), table._version, inv)
+    if hit is None:                       # the entry dies with its table (training sees a new octree every batch)
+        weakref.finalize(table, _INVERSE_TABLES.pop, key, None)
+    _INVERSE_TABLES[key] = (weakref.ref(table), table._version, inv)
     return inv
 
 

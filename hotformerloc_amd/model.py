@@ -117,11 +117,12 @@ def _split_path(x) -> bool:
 def _w3(lin: nn.Linear):
     w = lin.weight
     hit = _W3_CACHE.get(id(w))
-    if hit is None or hit[0]() is not w or hit[1] != w._version:
+    # data_ptr: `module.to(other_device)` swaps `.data` without bumping the version counter
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[3] != w.data_ptr():
         if len(_W3_CACHE) > 4096:                     # drop entries whose weight is gone
             for k in [k for k, v in _W3_CACHE.items() if v[0]() is None]:
                 del _W3_CACHE[k]
-        hit = (weakref.ref(w), w._version, ops.split_weight(w))
+        hit = (weakref.ref(w), w._version, ops.split_weight(w), w.data_ptr())
         _W3_CACHE[id(w)] = hit
     return hit[2]
 
@@ -631,10 +632,10 @@ class HOTFormerBase(nn.Module):
     def forward(self, data, octree, depth):
         data = self.patch_embed(data, octree, depth)
         depth = depth - self.stem_down
-        plan = WindowPlan(octree, self.patch_size, self.dilation, max_depth=depth,
-                          start_depth=depth - self.num_stages + 1,
-                          num_pyramid_levels=self.num_pyramid_levels,
-                          num_octf_levels=self.num_octf_levels, adape_mode=self.ADaPE_mode)
+        plan = WindowPlan.for_octree(octree, self.patch_size, self.dilation, max_depth=depth,
+                                     start_depth=depth - self.num_stages + 1,
+                                     num_pyramid_levels=self.num_pyramid_levels,
+                                     num_octf_levels=self.num_octf_levels, adape_mode=self.ADaPE_mode)
         for i in range(self.num_octf_levels):
             data = self.octf_stage[i](data, plan, depth)
             data = self.downsample[i](data, octree, depth)

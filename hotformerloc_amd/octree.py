@@ -156,13 +156,20 @@ class Octree:
 
     def construct_all_neigh(self):
         """ocnn builds (nnum_d,27) tables over all nodes; this builds the tables of the
-        NON-EMPTY nodes (what `get_neigh(..., nempty=True)` returns) for d >= 1."""
+        NON-EMPTY nodes (what `get_neigh(..., nempty=True)` returns) for d >= 1, plus the live-tap lists of
+        the octree convolutions (`sparse_taps`) for the depths below the input depth's 3x3x3 table."""
         self._need_built()
+        fresh = False
         for d in range(1, self.depth + 1):
             if self.neighs[d] is None:
+                fresh = True
                 self.neighs[d] = ops.octree_neigh(self.neighs[d - 1] if d > self.full_depth else None,
                                                   self.nidx[d], self.children[d], self.nkeys[d],
                                                   d, self.full_depth)
+        if fresh and self.device.type == 'cuda':
+            lo = max(self.full_depth + 1, 3)
+            keys = [(d, '333', 1) for d in range(lo, self.depth)] + [(d, '222', 2) for d in range(lo, self.depth + 1)]
+            self._build_tap_lists(keys)
 
     def _need_built(self):
         if not self._built:
@@ -222,22 +229,34 @@ class Octree:
             slot  (rows, taps) int32  position of (row, tap) in that list, -1 where the neighbour is missing,
             edges list of taps+1 ints (host)  pairs of tap k are [edges[k], edges[k+1]).
         kernel '333' stride 1: the 27-neighbour table; kernel '222' stride 2: the eight children of every parent.
-        Built once per (octree, depth) -- one device->host read of the 27 counts -- and cached like the tables."""
+        Built by `construct_all_neigh()` for every depth at once (HIP kernels, hfl_tap_lists) with ONE device->host
+        read of all the per-tap counts -- i.e. at the reference's `to_device` boundary (`misc/torch_utils.py:47-51`),
+        not inside `model(batch)`."""
         cache = self.__dict__.setdefault('_sparse_taps', {})
         key = (depth, kernel, stride)
         if key not in cache:
-            neigh = self.get_neigh(depth, kernel, stride, nempty=True)   # (rows, taps); stride 2: the 8 children
-            taps = neigh.shape[1]
-            live_t = (neigh >= 0).t().contiguous()                       # (taps, n): tap-major
-            rank = torch.cumsum(live_t.reshape(-1).to(torch.int32), 0, dtype=torch.int32) - 1
-            slot = torch.where(live_t, rank.view(taps, -1), torch.full_like(rank.view(taps, -1), -1)).t().contiguous()
-            src = neigh.t()[live_t].to(torch.int32).view(-1, 1).contiguous()
-            counts = live_t.sum(1).tolist()
-            edges = [0]
-            for c in counts:
-                edges.append(edges[-1] + int(c))
-            cache[key] = (src, slot, edges)
+            self._build_tap_lists([key])
         return cache[key]
+
+    def _build_tap_lists(self, keys):
+        """Tap lists for several (depth, kernel, stride) tables: all launches first, then one host read."""
+        cache = self.__dict__.setdefault('_sparse_taps', {})
+        todo = [k for k in keys if k not in cache]
+        if not todo:
+            return
+        tables = [self.get_neigh(d, kern, st, nempty=True).contiguous() for d, kern, st in todo]
+        taps = [t.shape[1] for t in tables]
+        edges_all = torch.empty(sum(n + 1 for n in taps), dtype=torch.int32, device=self.device)
+        built, off = [], 0
+        for t, n in zip(tables, taps):
+            built.append(ops.tap_lists(t, edges_all[off:off + n + 1]))
+            off += n + 1
+        host = edges_all.cpu().tolist()                                   # the one host read
+        off = 0
+        for key, (src, slot, _), n in zip(todo, built, taps):
+            edges = host[off:off + n + 1]
+            off += n + 1
+            cache[key] = (src[:edges[-1]].view(-1, 1), slot, edges)
 
     def get_input_feature(self, feature: str = 'P', nempty: bool = True):
         """`ocnn.modules.InputFeature('P', nempty=True)` (models/hotformerloc.py:28-31):

@@ -20,11 +20,14 @@ def _stream():
 
 class KernelTimer:
     """Optional per-launch HIP-event timing on the launch stream (bench.py roofline leg).
-    `with KernelTimer() as t: ...; t.summary()` -> {kernel: (launches, ms, bytes, flops)}."""
+    `with KernelTimer() as t: ...; t.summary()` -> {kernel: (launches, ms, algorithmic bytes, flops, moved bytes)};
+    "algorithmic" = SURVEY.md section 8(d)'s per-unit figure, "moved" = what this implementation actually
+    reads + writes when that differs (e.g. the duplicated bf16 `hi` plane of a split output)."""
     active = None
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []
+        self.only = None if only is None else frozenset(only)     # time just these kernels (cheap: 2 events each)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -36,17 +39,20 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, e0, e1, nbytes, flops in self.records:
-            n, ms, b, f = out.get(name, (0, 0.0, 0, 0))
-            out[name] = (n + 1, ms + e0.elapsed_time(e1), b + nbytes, f + flops)
+        for name, e0, e1, nbytes, flops, moved in self.records:
+            n, ms, b, f, mv = out.get(name, (0, 0.0, 0, 0, 0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), b + nbytes, f + flops, mv + moved)
         return out
 
 
 class _timed:
-    def __init__(self, name, nbytes, flops=0):
+    def __init__(self, name, nbytes, flops=0, moved=None):
         self.t = KernelTimer.active
+        if self.t is not None and self.t.only is not None and name not in self.t.only:
+            self.t = None
         if self.t is not None:
             self.name, self.nbytes, self.flops = name, int(nbytes), int(flops)
+            self.moved = int(nbytes if moved is None else moved)
 
     def __enter__(self):
         if self.t is not None:
@@ -58,14 +64,26 @@ class _timed:
     def __exit__(self, *exc):
         if self.t is not None:
             self.e1.record()
-            self.t.records.append((self.name, self.e0, self.e1, self.nbytes, self.flops))
+            self.t.records.append((self.name, self.e0, self.e1, self.nbytes, self.flops, self.moved))
 
 
 def _dev(*tensors):
+    """Every operand on the GPU, and on the CURRENT device: launches go to `torch.cuda.current_stream()` and the
+    library's hipBLASLt state is per (device, stream), so a tensor of another GPU would be read through the wrong
+    context.  Use `with torch.cuda.device(t.device):` around the model for a second GPU in one process."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _native.NativeLibraryError(
                 'hotformerloc_amd ops need GPU tensors (got %s); there is no CPU fallback' % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise _native.NativeLibraryError(
+                'tensor on %s but the current device is cuda:%d; wrap the call in torch.cuda.device(...)'
+                % (t.device, cur))
 
 
 def _f32c(t):
@@ -348,6 +366,25 @@ def octree_gather(data, neigh):
     return out
 
 
+def tap_lists(table: torch.Tensor, edges_out: torch.Tensor = None):
+    """Live-tap lists of a (rows, taps) int32 table (hfl_tap_lists): (src capacity rows*taps, slot (rows, taps),
+    edges (taps+1) int32 on the device).  No host synchronisation; the caller narrows `src` once it knows
+    edges[-1]."""
+    _dev(table)
+    assert table.dtype == torch.int32 and table.is_contiguous() and table.dim() == 2
+    rows, taps = table.shape
+    lib = _native.load()
+    dev = table.device
+    src = torch.empty(max(rows * taps, 1), dtype=torch.int32, device=dev)
+    slot = torch.empty((rows, taps), dtype=torch.int32, device=dev)
+    edges = torch.empty(taps + 1, dtype=torch.int32, device=dev) if edges_out is None else edges_out
+    assert edges.dtype == torch.int32 and edges.numel() == taps + 1 and edges.is_contiguous()
+    ws = torch.empty(int(lib.hfl_tap_lists_workspace(rows, taps)), dtype=torch.uint8, device=dev)
+    check(lib.hfl_tap_lists(src.data_ptr(), slot.data_ptr(), edges.data_ptr(), table.data_ptr(), rows, taps,
+                            ws.data_ptr(), _stream()), 'hfl_tap_lists')
+    return src, slot, edges
+
+
 # ---------------------------------------------------------------------- attention
 _RPE2_CACHE = {}        # (id(table), depth) -> (weakref to table, version, expanded table)
 
@@ -406,10 +443,10 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     used = n_tokens + (n_windows if n_relay else 0)          # rows the kernel touches
     seq = patch_size + n_relay
     real_windows = -(-n_tokens // patch_size)
-    # algorithmic work: read q,k,v + write out, 16 B per (row, channel); QK^T + PV = 4 L^2 C per window
-    # (bf16 [hi|hi|lo] output: 6 B instead of 4 B per written channel)
-    with _timed('hfl_window_attention_fwd', used * c * (18 if out_split else 16) + n_tokens * 8,
-                4 * seq * seq * c * real_windows):
+    # algorithmic work: read q,k,v + write out = 16 B per (row, channel); QK^T + PV = 4 L^2 C per
+    # window.  Moved: the bf16 [hi|hi|lo] output is 6 B instead of 4 B per channel, plus 8 B of metadata per token
+    with _timed('hfl_window_attention_fwd', used * c * 16, 4 * seq * seq * c * real_windows,
+                moved=used * c * (18 if out_split else 16) + n_tokens * 8):
         check(_native.load().hfl_window_attention_fwd_ex(
             out.data_ptr(), qkv.data_ptr(), None if qkv_bias is None else _f32c(qkv_bias).data_ptr(),
             tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), int(bool(out_split)), _stream()),

@@ -18,6 +18,8 @@ Formulas: SURVEY.md Appendix E (restating `models/octree.py:73-75,130-184,229-26
 
 from typing import Dict, List, Optional
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -89,7 +91,7 @@ class WindowPlan:
     def __init__(self, octree, patch_size: int, dilation: int, max_depth: int, start_depth: int,
                  num_pyramid_levels: int, num_octf_levels: int, adape_mode: Optional[str] = None):
         assert start_depth >= 1, 'Octree not deep enough for model depth'    # octree.py:71
-        self.octree = octree
+        self._octree = weakref.ref(octree)       # the octree caches its plans (WindowPlan.for_octree): no cycle
         self.K, self.D = patch_size, dilation
         self.B = octree.batch_size
         self.max_depth, self.start_depth = max_depth, start_depth
@@ -115,10 +117,9 @@ class WindowPlan:
             off = np.concatenate([[0], np.cumsum(nne[d])])
             self.cloud_off[d] = torch.from_numpy(off).to(dev, non_blocking=True)
             nmax = int(nne[d].max())
-            idx = np.full((self.B, nmax), int(off[-1]), dtype=np.int64)   # sentinel = zero row
-            for b in range(self.B):
-                idx[b, :nne[d][b]] = np.arange(off[b], off[b + 1])
-            self.pad_index[d] = torch.from_numpy(idx.reshape(-1)).to(dev, non_blocking=True)
+            ar = np.arange(nmax, dtype=np.int64)[None, :]
+            idx = np.where(ar < nne[d][:, None], off[:-1, None] + ar, int(off[-1]))   # sentinel = zero row
+            self.pad_index[d] = torch.from_numpy(np.ascontiguousarray(idx.reshape(-1))).to(dev, non_blocking=True)
         self.window_stats = {}
         if adape_mode is not None:
             if adape_mode != 'cov':
@@ -126,6 +127,28 @@ class WindowPlan:
             for d in self.pyramid_depths:
                 self.window_stats[d] = ops.window_stats(self.meta[d], self.n_tokens[d],
                                                         self.n_windows[d], self.K, d)
+
+    @property
+    def octree(self):
+        o = self._octree()
+        if o is None:
+            raise RuntimeError('the octree of this WindowPlan is gone')
+        return o
+
+    @classmethod
+    def for_octree(cls, octree, patch_size, dilation, max_depth, start_depth, num_pyramid_levels,
+                   num_octf_levels, adape_mode=None):
+        """The plan depends only on the octree and the model configuration: built once per (octree, cfg) and kept
+        on the octree next to its neighbour tables (the reference rebuilds `OctreeT` in every forward,
+        `models/hotformerloc_backbone.py:712-716`)."""
+        key = (patch_size, dilation, max_depth, start_depth, num_pyramid_levels, num_octf_levels, adape_mode)
+        cache = octree.__dict__.setdefault('_window_plans', {})
+        plan = cache.get(key)
+        if plan is None:
+            plan = cls(octree, patch_size, dilation, max_depth, start_depth, num_pyramid_levels,
+                       num_octf_levels, adape_mode)
+            cache[key] = plan
+        return plan
 
     def row_cloud(self, depth: int, with_relay: bool):
         """int64 cloud index of every row of a depth's buffer: tokens by their batch id, relay rows

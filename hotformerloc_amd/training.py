@@ -35,12 +35,26 @@ def _stage1_numerics(model, phase):
     return training_numerics()
 
 
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20,
+                        force: bool = False):
     """Sum `p.grad` over the ranks of `group` in flat buckets of ~bucket_bytes (xGMI is point to point:
     a ring all-reduce is per-link bound, so few large messages; the 141 MB of fp32 gradients are 3 buckets).
-    Parameters without a gradient on this rank contribute zeros (every rank must issue the same collectives)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Every rank must issue the same collectives, so a parameter without a gradient on this rank contributes
+    zeros -- but a parameter that received no gradient on ANY rank keeps `grad = None`, exactly as the
+    single-process reference step leaves it (AdamW skips such parameters: no weight decay, no moment update;
+    `training/trainer.py:344-362`).  `force`: issue the collectives at world size 1 too (tests)."""
+    if not dist.is_available() or not dist.is_initialized():
         return
+    if dist.get_world_size(group) == 1 and not force:
+        return
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    dev = params[0].device
+    # which parameters have a gradient somewhere: one small all-reduce of a flag vector
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=dev)
+    dist.all_reduce(has, op=dist.ReduceOp.SUM, group=group)
+    anywhere = (has > 0).tolist()
     bucket: List[torch.Tensor] = []
     size = 0
 
@@ -56,9 +70,9 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
             off += g.numel()
         bucket, size = [], 0
 
-    for p in params:
-        if not p.requires_grad:
-            continue
+    for p, used in zip(params, anywhere):
+        if not used:
+            continue                                   # None on every rank: stays None
         if p.grad is None:
             p.grad = torch.zeros_like(p)
         bucket.append(p.grad)
@@ -70,16 +84,18 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
 
 def multistaged_training_step(model: torch.nn.Module, minibatches: List[dict], positives_mask: torch.Tensor,
                               negatives_mask: torch.Tensor, loss_fn: Callable, optimizer=None,
-                              phase: str = 'train', n_total: Optional[int] = None, group=None) -> dict:
+                              phase: str = 'train', n_total: Optional[int] = None, group=None,
+                              force_collectives: bool = False) -> dict:
     """One step.  `minibatches`: this rank's batch dicts ({'octree': ...}, already on the device with
     neighbours built), in global order; masks are (B_total, B_total) over the whole batch.  Returns the
-    loss statistics (identical on every rank).  `n_total`: global batch size (default B_local * world)."""
+    loss statistics (identical on every rank).  `n_total`: global batch size (default B_local * world).
+    `force_collectives`: issue the all-gather and the gradient all-reduce at world size 1 too (single-GPU RCCL test)."""
     assert phase in ('train', 'val')
     model.train() if phase == 'train' else model.eval()
     # ---- stage 1 ------------------------------------------------------------------------------
     with torch.no_grad(), _stage1_numerics(model, phase):
         local = torch.cat([model(mb)['global'] for mb in minibatches], 0)
-    embeddings = all_gather_descriptors(local, n_total, group).detach()
+    embeddings = all_gather_descriptors(local, n_total, group, force=force_collectives).detach()
     # ---- stage 2 ------------------------------------------------------------------------------
     with torch.set_grad_enabled(phase == 'train'):
         if phase == 'train':
@@ -107,7 +123,7 @@ def multistaged_training_step(model: torch.nn.Module, minibatches: List[dict], p
         y = model(mb)['global']
         y.backward(gradient=grad_local[i:i + y.shape[0]])
         i += y.shape[0]
-    allreduce_gradients(model.parameters(), group)
+    allreduce_gradients(model.parameters(), group, force=force_collectives)
     if optimizer is not None:
         optimizer.step()
     return stats

@@ -145,6 +145,18 @@ int hfl_token_meta(uint32_t* tok_meta, const int64_t* nkeys, int64_t n, int dept
 int hfl_octree_gather(float* out, const float* data, const int32_t* neigh, int64_t n_out,
                       int kngh, int64_t channels, hfl_stream_t stream);
 
+/* Live-tap lists of a (rows, taps) int32 index table, taps <= 32 (ocnn.nn.OctreeConv multiplies an (N, K*Cin)
+ * octree2col matrix that is 80-94 % zeros on surface-like clouds; the convolutions here run over the live
+ * (row, tap) pairs only):
+ *   src   (rows*taps capacity) input row of every live pair, pairs ordered by tap then by row; the first
+ *         edges[taps] entries are written
+ *   slot  (rows, taps)         position of (row, tap) in that list, -1 where the neighbour is missing
+ *   edges (taps + 1)           pairs of tap k are [edges[k], edges[k+1])          -- all on the device
+ * No atomics, fixed order, no host synchronisation; `workspace` holds hfl_tap_lists_workspace() bytes. */
+int64_t hfl_tap_lists_workspace(int64_t rows, int taps);
+int hfl_tap_lists(int32_t* src, int32_t* slot, int32_t* edges, const int32_t* table, int64_t rows, int taps,
+                  void* workspace, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 4. Windowed multi-head attention over z-order octree windows
  *    (replaces OctreeAttention.forward's bias build + SDPA,

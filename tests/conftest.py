@@ -18,6 +18,13 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     """A GPU test that stops making progress should fail with a stack dump, not stall the run
     (pytest-timeout is part of the image; without it the marker is inert)."""
+    import torch
+    if not torch.cuda.is_available():
+        # a box without a GPU skips the GPU tests instead of failing them with "No HIP GPUs are available"
+        skip = pytest.mark.skip(reason='needs a real MI355X (torch.cuda.is_available() is False)')
+        for item in items:
+            if 'gpu' in item.keywords:
+                item.add_marker(skip)
     if not config.pluginmanager.hasplugin('timeout'):
         return
     for item in items:

@@ -145,3 +145,45 @@ def test_multistaged_step_single_process_equals_direct():
     loss.backward()
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad, atol=1e-6)
+
+
+class _ToyEncoderWithUnused(_ToyEncoder):
+    def __init__(self):
+        super().__init__()
+        self.never_used = torch.nn.Parameter(torch.ones(3))           # no gradient on any rank
+        self.sometimes = torch.nn.Parameter(torch.zeros(5))           # gradient on rank 0 only
+        self.use_sometimes = False
+
+    def forward(self, batch):
+        y = self.b(torch.tanh(self.a(batch['x'])))
+        if self.use_sometimes:
+            y = y + self.sometimes
+        return {'global': torch.nn.functional.normalize(y, dim=1)}
+
+
+def _unused_worker(rank, world, port, result_dir):
+    from hotformerloc_amd.training import multistaged_training_step
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        x, pos, neg = _toy_data(8)
+        lo, hi = shard_bounds(8, rank, world)
+        model = _ToyEncoderWithUnused()
+        model.use_sometimes = rank == 0
+        multistaged_training_step(model, [{'x': x[lo:hi]}], pos, neg, _toy_listwise_loss, n_total=8)
+        torch.save({'never': model.never_used.grad, 'sometimes': model.sometimes.grad},
+                   os.path.join(result_dir, 'unused_%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_keeps_grad_none_for_parameters_unused_on_every_rank(tmp_path):
+    """A parameter no rank touched keeps grad None (AdamW then skips it, as the single-process reference step
+    does); one that only some ranks touched is summed with zeros from the others."""
+    mp.spawn(_unused_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'unused_0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'unused_1.pt'))
+    assert r0['never'] is None and r1['never'] is None
+    assert r0['sometimes'] is not None and torch.equal(r0['sometimes'], r1['sometimes'])
+    assert r0['sometimes'].abs().sum() > 0

@@ -1,0 +1,164 @@
+"""BASELINE.json configs at their full per-GPU sizes, and the RCCL legs of configs 4 and 5 on ONE GPU.
+
+The oracle needs minutes per full-size batch, so these are property tests (finite, unit-norm, deterministic,
+first cloud batch-invariant, gradients for every tensor); value parity at oracle-sized inputs lives in
+tests/test_gpu_model.py.  The collectives of the multi-GPU configs run here in-process through RCCL at world size 1
+(`backend="nccl"` is RCCL on ROCm): same code path and library calls as N > 1, results must equal the
+no-process-group run bit for bit.
+
+Reference seams: `training/trainer.py:287-365` (multi-staged step), `datasets/dataset_utils.py:129-134`
+(contiguous ordered sub-batches)."""
+
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+from hotformerloc_amd import build_batch_octree, load_config, model_factory
+from hotformerloc_amd import synthetic as syn
+
+
+def _model(cfg, profile='init', train=False, drop_path=None):
+    params, depth = load_config(cfg)
+    if drop_path is not None:
+        params.drop_path = drop_path
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, profile)
+    model = model.cuda()
+    return (model.train() if train else model.eval()), params, depth
+
+
+def _cs_wild_places_batch(batch, seed=3):
+    """BASELINE config 3 / SURVEY 8(d): per-cloud point count n ~ U{4096..32768}, forest / unit-ball mix."""
+    clouds = []
+    for i in range(batch):
+        kind = 'forest' if i % 2 == 0 else 'ball'
+        clouds += syn.make_clouds(seed, 1, 4096, 'cartesian', kind=kind, n_points_max=32768, first_index=i)
+    return clouds
+
+
+@pytest.fixture(scope='module')
+def rccl_world1():
+    """An RCCL process group of one rank, created in-process (no launcher, no re-exec)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    assert not dist.is_initialized()
+    dist.init_process_group('nccl', world_size=1, rank=0, init_method='tcp://127.0.0.1:%d' % port)
+    try:
+        yield dist.group.WORLD
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ config 2: B=32 x 4096, Wild-Places, forward
+def test_wild_places_b32_forward_properties():
+    model, params, depth = _model('wild-places')
+    clouds = syn.make_clouds(2, 32, 4096, params.coordinates)           # the bench workload itself
+    with torch.inference_mode():
+        y = model({'octree': build_batch_octree(clouds, depth, 2, 'cuda')})['global']
+        again = model({'octree': build_batch_octree(clouds, depth, 2, 'cuda')})['global']
+        solo = model({'octree': build_batch_octree(clouds[:1], depth, 2, 'cuda')})['global']
+    assert y.shape == (32, 256) and torch.isfinite(y).all()
+    assert torch.allclose(y.norm(dim=1), torch.ones(32, device='cuda'), atol=1e-5)
+    assert torch.equal(y, again), 'same inputs must give the same bits'
+    # cloud 0 sees no straddling window from a predecessor: batch-invariant
+    rel = ((solo[0] - y[0]).norm() / y[0].norm()).item()
+    assert rel < 1e-4, rel
+    # descriptors of different clouds differ
+    assert (y[1:] - y[:1]).norm(dim=1).min().item() > 1e-4
+
+
+# ------------------------------------------- config 3: B=64 CS-Wild-Places, variable density, forward + backward
+@pytest.mark.timeout(1200)
+def test_cs_wild_places_b64_variable_density_forward_backward():
+    model, params, depth = _model('cs-wild-places', train=True, drop_path=0.0)
+    clouds = _cs_wild_places_batch(64)
+    sizes = [len(c) for c in clouds]
+    assert min(sizes) >= 4096 and max(sizes) <= 32768 and max(sizes) > 2 * min(sizes)
+    octree = build_batch_octree(clouds, depth, 2, 'cuda')
+    torch.cuda.reset_peak_memory_stats()
+    y = model({'octree': octree})['global']
+    assert y.shape == (64, 256) and torch.isfinite(y).all()
+    proj = torch.from_numpy(syn.hash_uniform(7, 64 * 256).reshape(64, 256).astype(np.float32)).cuda()
+    (y * proj).sum().backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    n_par, n_zero = 0, []
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        assert torch.isfinite(p.grad).all(), name
+        n_par += 1
+        if p.grad.abs().max().item() == 0.0:
+            n_zero.append(name)
+    print('cs-wild-places B=64: points %d..%d (sum %d), tokens/depth %s, %d parameter tensors, peak memory %.1f GiB'
+          % (min(sizes), max(sizes), sum(sizes), octree.nnum_nempty.tolist(), n_par, peak))
+    assert n_par >= 725
+    assert not n_zero, 'parameters with an all-zero gradient: %s' % n_zero[:8]
+
+
+# --------------------------------------------------------------- config 5 (per-rank workload): Oxford, B=64
+def test_oxford_b64_forward_properties():
+    model, params, depth = _model('oxford')
+    clouds = syn.make_clouds(5, 64, 4096, params.coordinates)
+    with torch.inference_mode():
+        octree = build_batch_octree(clouds, depth, 2, 'cuda')
+        y = model({'octree': octree})['global']
+        again = model({'octree': octree})['global']
+        solo = model({'octree': build_batch_octree(clouds[:1], depth, 2, 'cuda')})['global']
+    assert y.shape == (64, 256) and torch.isfinite(y).all()
+    assert torch.allclose(y.norm(dim=1), torch.ones(64, device='cuda'), atol=1e-5)
+    assert torch.equal(y, again)
+    assert ((solo[0] - y[0]).norm() / y[0].norm()).item() < 1e-4
+
+
+# ------------------------------------------------------ configs 4 / 5: the RCCL legs, in-process at world size 1
+def test_rccl_all_gather_of_encoder_descriptors(rccl_world1):
+    from hotformerloc_amd.distributed import all_gather_descriptors
+    model, params, depth = _model('wild-places')
+    clouds = syn.make_clouds(4, 8, 4096, params.coordinates)
+    with torch.inference_mode():
+        y = model({'octree': build_batch_octree(clouds, depth, 2, 'cuda')})['global']
+        g = all_gather_descriptors(y, 8, group=rccl_world1, force=True)     # dist.all_gather_into_tensor over RCCL
+    torch.cuda.synchronize()
+    assert g.data_ptr() != y.data_ptr(), 'the collective must have produced a new buffer'
+    assert torch.equal(g, y)
+    # with autograd: the backward keeps this rank's rows
+    y2 = y.clone().requires_grad_()
+    g2 = all_gather_descriptors(y2, 8, group=rccl_world1, force=True)
+    w = torch.arange(8, dtype=torch.float32, device='cuda')[:, None]
+    (g2 * w).sum().backward()
+    assert torch.equal(y2.grad, w.expand(8, 256))
+
+
+def test_rccl_multistaged_step_equals_no_group_step(rccl_world1):
+    """One multi-staged training step (stage 1 encode, RCCL all-gather, TruncatedSmoothAP, stage 3 backward, RCCL
+    gradient all-reduce) against the same step without any collective: identical loss and gradients."""
+    from hotformerloc_amd.losses import TruncatedSmoothAP
+    from hotformerloc_amd.training import multistaged_training_step
+    n = 8
+    lab = torch.arange(n) // 4
+    pos = ((lab[:, None] == lab[None, :]) & ~torch.eye(n, dtype=torch.bool)).cuda()
+    neg = (lab[:, None] != lab[None, :]).cuda()
+    loss_fn = TruncatedSmoothAP(tau1=0.01, positives_per_query=2)
+    grads, losses = [], []
+    for force in (False, True):
+        model, params, depth = _model('wild-places', profile='stress', train=True, drop_path=0.0)
+        clouds = syn.make_clouds(6, n, 1500, params.coordinates)
+        mbs = [{'octree': build_batch_octree(clouds[:4], depth, 2, 'cuda')},
+               {'octree': build_batch_octree(clouds[4:], depth, 2, 'cuda')}]
+        stats = multistaged_training_step(model, mbs, pos, neg, loss_fn, None, n_total=n,
+                                          group=rccl_world1, force_collectives=force)
+        torch.cuda.synchronize()
+        losses.append(stats['loss'])
+        grads.append({k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()})
+    assert losses[0] == losses[1], losses
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert torch.equal(a, b), (k, (a - b).abs().max().item())

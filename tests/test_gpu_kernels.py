@@ -129,6 +129,47 @@ def test_octree_large_cloud_multi_chunk_sort():
     _compare_octree(build_batch_octree(clouds, 8, 2, DEV), oracle_octree(clouds, 8))
 
 
+@pytest.mark.parametrize('rows,taps', [(1, 27), (1023, 27), (1024, 8), (70001, 27), (5000, 3)])
+def test_tap_lists_match_tap_major_compaction(rows, taps):
+    """hfl_tap_lists (the live (row, tap) pairs of an octree-conv table, tap-major, rows ascending inside a tap)
+    against the plain definition; integer work -> bit-exact.  Includes an all-dead tap and an all-live tap."""
+    g = torch.Generator().manual_seed(rows * 31 + taps)
+    table = torch.randint(0, max(rows, 2), (rows, taps), generator=g, dtype=torch.int32)
+    dead = torch.rand((rows, taps), generator=g) < 0.7
+    dead[:, 0] = True                      # tap 0 has no neighbour anywhere
+    dead[:, taps - 1] = False              # the last tap is live everywhere
+    table[dead] = -1
+    src, slot, edges = ops.tap_lists(table.to(DEV))
+    edges = edges.cpu()
+    live_t = (table >= 0).t()
+    counts = live_t.sum(1)
+    want_edges = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)]).to(torch.int32)
+    assert torch.equal(edges, want_edges)
+    want_src = table.t()[live_t]
+    assert torch.equal(src[:int(edges[-1])].cpu(), want_src)
+    rank = torch.cumsum(live_t.reshape(-1).to(torch.int64), 0) - 1
+    want_slot = torch.where(live_t, rank.view(taps, rows), torch.full((taps, rows), -1)).t().to(torch.int32)
+    assert torch.equal(slot.cpu(), want_slot)
+
+
+def test_octree_sparse_taps_built_with_the_neighbour_tables():
+    """construct_all_neigh() prepares the live-tap lists of the octree convolutions (one host read for all of them);
+    nothing is left to build -- and no device->host sync -- inside model(batch)."""
+    clouds = syn.make_clouds(9, 3, 3000, 'cartesian')
+    o = build_batch_octree(clouds, 7, 2, DEV, construct_neigh=True)
+    cache = o.__dict__['_sparse_taps']
+    for key in [(6, '333', 1), (5, '333', 1), (7, '222', 2), (6, '222', 2), (5, '222', 2), (4, '222', 2), (3, '222', 2)]:
+        assert key in cache, key
+        src, slot, edges = cache[key]
+        table = o.get_neigh(key[0], key[1], key[2], nempty=True)
+        live = table >= 0
+        assert edges[-1] == int(live.sum()) == src.shape[0] and len(edges) == table.shape[1] + 1
+        # every live pair points at its own source row
+        r, k = torch.nonzero(live, as_tuple=True)
+        assert torch.equal(src[slot[r, k].long(), 0], table[r, k])
+        assert bool((slot[~live] == -1).all())
+
+
 # ------------------------------------------------------------------------- dwconv
 def test_dwconv_matches_ocnn_semantics(golden_dir):
     """Port of the reference's own test (`libs/dwconv/test/test_octree_dwconv.py:13-68`):

@@ -45,6 +45,16 @@ def _rel(a, b):
     return np.linalg.norm(a - b, axis=-1) / np.maximum(np.linalg.norm(b, axis=-1), 1e-12)
 
 
+def _stage_err(got, want) -> float:
+    """Error of an intermediate tensor, every stage held to the same 1e-3 bar as the descriptor: largest
+    element difference relative to the largest reference magnitude (the stages are LayerNorm-fed feature maps;
+    a per-element relative error would be dominated by values that cancel to ~0)."""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else np.asarray(want)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.abs(got.astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-12))
+
+
 @pytest.fixture(params=['bf16x3', 'fp32'])
 def gemm_mode(request):
     """Linear layers as one split-bf16 GEMM (default) or as hipBLASLt fp32 GEMMs."""
@@ -73,18 +83,20 @@ def test_descriptors_match_reference_golden(golden_dir, case, gemm_mode):
     report = {'descriptor': float(_rel(y, g['descriptors']).max())}
     for name in ('patch_embed', 'octf_out'):
         head = g[name + '_head']
-        report[name] = float(np.abs(cap[name][:head.shape[0]].cpu().numpy() - head).max())
+        report[name] = _stage_err(cap[name][:head.shape[0]], head)
         s = cap[name].double()
-        report[name + '_sum'] = abs(s.sum().item() - g[name + '_sum'][0])
+        # checksum over the whole tensor (the head covers the first rows only): relative to the sum of magnitudes
+        report[name + '_sum'] = abs(s.sum().item() - g[name + '_sum'][0]) / max(s.abs().sum().item(), 1e-12)
     feats, rts = cap['hotf']
     for d in feats:
         head = g['feat_final_%d_head' % d]
-        report['feat_final_%d' % d] = float(np.abs(feats[d][:head.shape[0]].cpu().numpy() - head).max())
+        report['feat_final_%d' % d] = _stage_err(feats[d][:head.shape[0]], head)
         head = g['rt_final_%d_head' % d]
         nreal = min(head.shape[0], -(-feats[d].shape[0] // params.patch_size))   # skip padding windows
-        report['rt_final_%d' % d] = float(np.abs(rts[d][:nreal].cpu().numpy() - head[:nreal]).max())
+        report['rt_final_%d' % d] = _stage_err(rts[d][:nreal], head[:nreal])
     print(case, gemm_mode, report)
-    assert report['descriptor'] <= REL_TOL, report
+    bad = {k: v for k, v in report.items() if not v <= REL_TOL}
+    assert not bad, (bad, report)
     assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
 
 
@@ -112,16 +124,17 @@ def test_stage_by_stage_against_oracle(cfg, octree_depth, sizes, gemm_mode):
         model = _device_model(params, profile)
         octree = build_batch_octree(clouds, octree_depth, 2, 'cuda')
         y, cap = _run_with_capture(model, octree)
-        errs = {'patch_embed': (cap['patch_embed'].cpu() - ocap['patch_embed']).abs().max().item(),
-                'octf_out': (cap['octf_out'].cpu() - ocap['octf_out']).abs().max().item()}
+        errs = {'patch_embed': _stage_err(cap['patch_embed'], ocap['patch_embed']),
+                'octf_out': _stage_err(cap['octf_out'], ocap['octf_out'])}
         feats, rts = cap['hotf']
         for d in feats:
-            errs['feat_final.%d' % d] = (feats[d].cpu() - ocap['feat_final.%d' % d]).abs().max().item()
+            errs['feat_final.%d' % d] = _stage_err(feats[d], ocap['feat_final.%d' % d])
             nreal = -(-feats[d].shape[0] // params.patch_size)                  # skip padding windows
-            errs['rt_final.%d' % d] = (rts[d].cpu()[:nreal] - ocap['rt_final.%d' % d][:nreal]).abs().max().item()
+            errs['rt_final.%d' % d] = _stage_err(rts[d][:nreal], ocap['rt_final.%d' % d][:nreal])
         errs['descriptor'] = float(_rel(y.cpu().numpy(), want).max())
         print(cfg, profile, gemm_mode, errs)
-        assert errs['descriptor'] <= REL_TOL, errs
+        bad = {k: v for k, v in errs.items() if not v <= REL_TOL}
+        assert not bad, (bad, errs)
 
 
 def test_batch_composition_semantics():
