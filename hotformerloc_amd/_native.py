@@ -50,6 +50,7 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     'hfl_token_meta': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     'hfl_octree_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    'hfl_prepare_clouds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'hfl_tap_lists_workspace': (c_int64, [c_int64, c_int]),
     'hfl_tap_lists': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,

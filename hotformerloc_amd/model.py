@@ -29,6 +29,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
 
 from . import autograd as ag
 from . import dwconv as hdw
@@ -151,6 +152,12 @@ def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm
     x, h3 = ops.add_layer_norm_split3(x, p, norm2.weight, norm2.bias, norm2.eps, add_bias=attn.proj.bias)
     g3 = ops.bias_gelu_split3(ops.split_mm(h3, _w3(mlp.fc1)), mlp.fc1.bias)
     return ops.add_bias(x, ops.split_mm(g3, _w3(mlp.fc2)), mlp.fc2.bias)
+
+
+def _use_checkpoint(stage) -> bool:
+    """The reference checkpoints every transformer block `if self.grad_checkpoint and self.training`
+    (models/octformer_backbone.py:415-416, models/hotformerloc_backbone.py:596-618)."""
+    return bool(stage.grad_checkpoint) and stage.training and torch.is_grad_enabled()
 
 
 def _require_layernorm(conv_norm: str):
@@ -397,16 +404,19 @@ class OctFormerStage(nn.Module):
     """models/octformer_backbone.py:363-421"""
 
     def __init__(self, dim, num_heads, patch_size, dilation, num_blocks, disable_RPE=False,
-                 conv_norm='layernorm', drop_path=0.0):
+                 conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False):
         super().__init__()
         dp = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * num_blocks
+        self.grad_checkpoint = grad_checkpoint
         self.blocks = nn.ModuleList([
             OctFormerBlock(dim, num_heads, patch_size, 1 if i % 2 == 0 else dilation, disable_RPE,
                            conv_norm, dp[i]) for i in range(num_blocks)])
 
     def forward(self, x, plan, depth):
+        ckpt = _use_checkpoint(self)
         for blk in self.blocks:
-            x = blk(x, plan, depth)
+            # activation checkpointing per block, non-reentrant, as octformer_backbone.py:415-416
+            x = checkpoint(blk, x, plan, depth, use_reentrant=False) if ckpt else blk(x, plan, depth)
         return x
 
 
@@ -517,8 +527,9 @@ class HOTFormerStage(nn.Module):
     """models/hotformerloc_backbone.py:366-635 (one channel width for all levels)."""
 
     def __init__(self, channels, num_heads, num_blocks, num_pyramid_levels, patch_size,
-                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm', drop_path=0.0):
+                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False):
         super().__init__()
+        self.grad_checkpoint = grad_checkpoint
         if len(channels) != 1 or len(num_heads) != 1:
             raise NotImplementedError('per-level channel widths (projection layers) are not used '
                                       'by any shipped config')
@@ -557,9 +568,13 @@ class HOTFormerStage(nn.Module):
             if j < self.num_pyramid_levels - 1:
                 feats[d - 1] = self.downsamples[j](feats[d], octree, d)
         nts = [plan.n_tokens[d] for d in depths]
+        ckpt = _use_checkpoint(self)
         for i in range(self.num_blocks):                                # 593-633
             rt_all = torch.cat([bufs[d][nt:] for d, nt in zip(depths, nts)], 0)
-            rt_all = self.rtsa_blocks[i](rt_all, plan)
+            if ckpt:                                                    # 596-601
+                rt_all = checkpoint(self.rtsa_blocks[i], rt_all, plan, use_reentrant=False)
+            else:
+                rt_all = self.rtsa_blocks[i](rt_all, plan)
             for d, nt in zip(depths, nts):
                 off = plan.rt_offset[d]
                 new_rt = rt_all[off:off + plan.n_windows[d]]
@@ -595,7 +610,10 @@ class HOTFormerStage(nn.Module):
                 del keep
             else:
                 for j, d in enumerate(depths):
-                    bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+                    if ckpt:                                            # 610-618
+                        bufs[d] = checkpoint(self.hosa_blocks[j][i], bufs[d], plan, d, use_reentrant=False)
+                    else:
+                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
         local = {d: bufs[d][:nt] for d, nt in zip(depths, nts)}
         relay = {d: bufs[d][nt:] for d, nt in zip(depths, nts)}
         return local, relay
@@ -606,7 +624,7 @@ class HOTFormerBase(nn.Module):
 
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels,
                  num_octf_levels, patch_size, dilation, stem_down, ADaPE_mode, disable_RPE, conv_norm,
-                 drop_path=0.0):
+                 drop_path=0.0, grad_checkpoint=False):
         super().__init__()
         # stochastic depth per block (hotformerloc_backbone.py:669-700)
         drop_ratio = torch.linspace(0, drop_path, sum(num_blocks)).tolist()
@@ -620,14 +638,15 @@ class HOTFormerBase(nn.Module):
         self.patch_embed = PatchEmbed(in_channels, channels[0], stem_down, conv_norm)
         self.octf_stage = nn.ModuleList([
             OctFormerStage(channels[i], num_heads[i], patch_size, dilation, num_blocks[i], disable_RPE,
-                           conv_norm, drop_ratio[sum(num_blocks[:i]):sum(num_blocks[:i + 1])])
+                           conv_norm, drop_ratio[sum(num_blocks[:i]):sum(num_blocks[:i + 1])], grad_checkpoint)
             for i in range(num_octf_levels)])
         self.downsample = nn.ModuleList([Downsample(channels[i], channels[i + 1], conv_norm)
                                          for i in range(num_octf_levels)])
         self.hotf_stage = HOTFormerStage(list(channels[num_octf_levels:]),
                                          list(num_heads[num_octf_levels:]), num_blocks[-1],
                                          num_pyramid_levels, patch_size, disable_RPE, ADaPE_mode,
-                                         conv_norm, drop_ratio[sum(num_blocks[:-1]):sum(num_blocks)])
+                                         conv_norm, drop_ratio[sum(num_blocks[:-1]):sum(num_blocks)],
+                                         grad_checkpoint)
 
     def forward(self, data, octree, depth):
         data = self.patch_embed(data, octree, depth)
@@ -650,12 +669,12 @@ class HOTFormer(nn.Module):
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels=3,
                  num_octf_levels=1, patch_size=32, dilation=4, drop_path=0.5, stem_down=2,
                  ADaPE_mode=None, disable_RPE=False, conv_norm='layernorm',
-                 qkv_init=('trunc_normal', 0.02)):
+                 qkv_init=('trunc_normal', 0.02), grad_checkpoint=False):
         super().__init__()
         self.backbone = HOTFormerBase(in_channels, list(channels), list(num_blocks),
                                       None if num_heads is None else list(num_heads),
                                       num_pyramid_levels, num_octf_levels, patch_size, dilation,
-                                      stem_down, ADaPE_mode, disable_RPE, conv_norm, drop_path)
+                                      stem_down, ADaPE_mode, disable_RPE, conv_norm, drop_path, grad_checkpoint)
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=0.02)

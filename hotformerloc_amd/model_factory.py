@@ -44,7 +44,7 @@ _BACKBONE_ARGS = {
     'num_pyramid_levels': 'num_pyramid_levels', 'num_octf_levels': 'num_octf_levels',
     'patch_size': 'patch_size', 'dilation': 'dilation', 'drop_path': 'drop_path',
     'stem_down': 'num_input_downsamples', 'ADaPE_mode': 'ADaPE_mode', 'disable_RPE': 'disable_RPE',
-    'conv_norm': 'conv_norm', 'qkv_init': 'qkv_init',
+    'conv_norm': 'conv_norm', 'qkv_init': 'qkv_init', 'grad_checkpoint': 'grad_checkpoint',
 }
 _POOLING_ARGS = {
     'pool_method': 'pooling', 'in_dim': 'feature_size', 'output_dim': 'output_dim',

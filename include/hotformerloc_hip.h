@@ -136,6 +136,19 @@ int hfl_octree_neigh(int32_t* neigh_out, const int32_t* neigh_parent, const int3
 int hfl_token_meta(uint32_t* tok_meta, const int64_t* nkeys, int64_t n, int depth,
                    hfl_stream_t stream);
 
+/* Raw-cloud pre-steps in front of the octree build, for a whole batch (eval/pnv_evaluate.py:158-171,
+ * datasets/dataset_utils.py:84-90): bounding-box normalisation into [-1,1] (datasets/augmentation.py:213-223,
+ * scale_factor=None, unit_sphere_norm=False, zero_mean=True) when `normalize`, the |coordinate| <= 1 mask, the
+ * |xy| <= 1 mask when `cylindrical_mask`, and -- when `cylindrical_transform` -- (x,y,z) -> (rho,phi,z) rescaled
+ * to [-1,1] (datasets/coordinate_utils.py:68-116).  points (P,3) with cloud b at rows
+ * [cloud_offsets[b], cloud_offsets[b+1]); the kept points of cloud b are written, in order, from row
+ * cloud_offsets[b] of out_points (P,3) on, and out_counts[b] says how many.  Normalisation and masks are
+ * bit-exact with the reference's fp32 torch sequence; the transform's atan2f is the device library's (see
+ * csrc/preprocess.hip).  out_points must not alias points. */
+int hfl_prepare_clouds(float* out_points, int32_t* out_counts, const float* points,
+                       const int64_t* cloud_offsets, int batch, int normalize, int cylindrical_mask,
+                       int cylindrical_transform, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 3. Octree convolution gather  (ocnn.nn.OctreeConv's octree2col; call sites
  *    models/layers/octformer_layers.py:89-95, models/octformer_backbone.py:470-475)

@@ -160,5 +160,10 @@ def test_rccl_multistaged_step_equals_no_group_step(rccl_world1):
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert (a is None) == (b is None), k
-        if a is not None:
+        if a is None:
+            continue
+        if k.endswith('rpe_table'):
+            # the table gradient is flushed with float atomics (one per workgroup): run-to-run order noise
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(a.abs().max().item(), 1e-30)), k
+        else:
             assert torch.equal(a, b), (k, (a - b).abs().max().item())

@@ -1,0 +1,41 @@
+"""Pins of the raw-cloud pre-steps against goldens produced by the reference's own
+`Normalize` / `CylindricalCoordinates` in the sequence of `eval/pnv_evaluate.py:158-171`
+(`oracle/gen_golden_coords.py`).  Bit-exact: the masks decide which points exist, the transform which octree cell
+they fall in."""
+
+import os
+
+import numpy as np
+import torch
+
+from hotformerloc_amd import synthetic as syn
+from oracle import preprocess_ref
+from oracle.gen_golden_coords import CASES, raw_cloud
+
+
+def _golden(golden_dir):
+    return np.load(os.path.join(golden_dir, 'preprocess.npz'))
+
+
+def test_oracle_presteps_match_reference_golden(golden_dir):
+    g = _golden(golden_dir)
+    for name, (seed, n, kind, extent, offset, normalize, coords) in CASES.items():
+        raw = torch.from_numpy(raw_cloud(seed, n, kind, extent, offset))
+        stages = {}
+        out = preprocess_ref.prepare_cloud(raw, normalize, coords, stages)
+        assert np.array_equal(stages['normalized'].numpy(), g[name + '_normalized']), name
+        assert np.array_equal(stages['masked'].numpy(), g[name + '_masked']), name
+        assert np.array_equal(out.numpy(), g[name + '_out']), name
+    # the boundary case must actually exercise both masks
+    assert g['boundary_cyl_masked'].shape[0] < 2048 * 0.7
+
+
+def test_product_cylindrical_matches_reference_transform(golden_dir):
+    """a3: `hotformerloc_amd.synthetic.cylindrical` (what the bench / fixtures apply, and what
+    `ModelParams.quantizer` calls) == the reference's `CylindricalCoordinates(use_octree=True)`, bit for bit."""
+    g = _golden(golden_dir)
+    for i in range(2):
+        pc = syn.unit_ball_cloud(2000 + i, 4096)
+        assert np.array_equal(syn.cylindrical(pc), g['a3_ball_%d' % i])
+    for name in ('wp_forest', 'boundary_cyl'):
+        assert np.array_equal(syn.cylindrical(g[name + '_masked']), g[name + '_out']), name
