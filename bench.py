@@ -15,7 +15,8 @@ N > 1, by the RCCL all-gather of the (B_local,256) descriptors.  Weak scaling: e
 encodes its own contiguous slice of the global batch.
 
 What one default run times (all with the same W-warm-up / K-step / barrier protocol, on rank 0 at N = 1):
-  value          Linear layers as 3-term split-bf16 products with fp32 accumulation (`--gemm bf16x3`)
+  value          Linear layers as 3-term split-bf16 products with fp32 accumulation on the hand-written MFMA GEMM
+                 (`--gemm x3`; `--gemm bf16x3` = the same arithmetic through hipBLASLt)
   fp32_linear    the same forward with every Linear as an fp32 GEMM -- the reference's arithmetic
   e2e            a FRESH octree per step: device build + neighbour tables + tap lists + window plan + forward
                  (SURVEY 8d "report separately the end-to-end rate including device octree build")
@@ -53,9 +54,10 @@ def parse():
     ap.add_argument('--points-max', type=int, default=None,
                     help='variable density: per-cloud point count ~ U{points..points_max}, forest / unit-ball mix '
                          '(default for cs-wild-places: 32768, BASELINE config 3)')
-    ap.add_argument('--gemm', default='bf16x3', choices=['bf16x3', 'fp32'],
-                    help="Linear layers of the headline `value`: 'bf16x3' = one bf16 GEMM over (hi|hi|lo)x(hi|lo|hi) "
-                         "operands, fp32 accumulate/output (default); 'fp32' = hipBLASLt fp32 GEMMs")
+    ap.add_argument('--gemm', default='x3', choices=['x3', 'bf16x3', 'fp32'],
+                    help="Linear layers of the headline `value`: 'x3' = hand-written split-bf16 MFMA GEMM with fused "
+                         "bias/GELU/residual epilogues (default); 'bf16x3' = the same three-term split as one hipBLASLt bf16 "
+                         "GEMM over K-concatenated operands; 'fp32' = hipBLASLt fp32 GEMMs")
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
     ap.add_argument('--attn-variant', type=int, default=0, help='A/B: window attention kernel variant (0 = default)')
     ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
@@ -245,7 +247,7 @@ def main():
         kern = timer.summary() if timer is not None else {}
         log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
         if extras:
-            other = 'fp32' if args.gemm == 'bf16x3' else 'bf16x3'
+            other = 'fp32' if args.gemm != 'fp32' else 'x3'
             set_gemm_mode(other)
             dt = timed(step, args.steps, args.warmup)
             set_gemm_mode(args.gemm)
@@ -326,8 +328,8 @@ def main():
             others[name] = {'launches_per_step': kn // args.steps,
                             'ms_per_step': round(kms / args.steps, 4),
                             'GBps': round(kb / (kms * 1e-3) / 1e9, 1) if kms > 0 else None}
-        mode_txt = {'fp32': 'f32',
-                    'bf16x3': 'f32 (Linear products as 3-term bf16 split, f32 accumulate; fp32_linear = all-f32 rate)'}
+        split_txt = 'f32 (Linear products as 3-term bf16 split, f32 accumulate; fp32_linear = all-f32 rate)'
+        mode_txt = {'fp32': 'f32', 'bf16x3': split_txt, 'x3': split_txt}
         line = {
             'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)', 'value': round(total_clouds / elapsed, 2),
             'unit': 'clouds/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -348,7 +350,7 @@ def main():
             'roofline': roof,
         }
         if fp32_line:
-            line['fp32_linear' if fp32_line['gemm'] == 'fp32' else 'bf16x3_linear'] = fp32_line
+            line['fp32_linear' if fp32_line['gemm'] == 'fp32' else 'split_linear'] = fp32_line
         if e2e_line:
             line['e2e'] = e2e_line
         if others:

@@ -74,6 +74,10 @@ SIGNATURES = {
                                          c_int64, c_void_p]),
     'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_void_p]),
+    'hfl_linear_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'hfl_layer_norm_split2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                      c_float, c_void_p]),
+    'hfl_split2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),
     'hfl_smoothap_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_float, c_void_p]),

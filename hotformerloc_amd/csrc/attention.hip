@@ -46,7 +46,8 @@ struct WinParams {
   int clamp;      // 1 when a coordinate difference can exceed pos_bnd
   float scale;
   const float* qkv_bias;   // (3*H*16) added to q,k,v on load (bias-free GEMM upstream), or null
-  int out_split;           // 1: out is bf16 [hi|hi|lo] rows of 3*H*16 (A operand of the split GEMM)
+  int out_split;           // 1: out is bf16 [hi|hi|lo] rows of 3*H*16 (A operand of the K-concatenated split GEMM);
+                           // 2: bf16 split2 rows of 2*H*16 (operand of hfl_linear_x3)
   const float* rpe2;       // (H, TS) expanded table of hfl_window_rpe_expand (v4), or null
   int depth;               // octree depth of the tokens (0 = unknown)
   int dbg;                 // ablation bits (tools/kbench.py): 1 no softmax/MFMA, 2 no stores, 4 cached rows
@@ -63,6 +64,22 @@ __device__ __forceinline__ uint16_t att_bf16_rne(float v) {
   uint32_t u = __float_as_uint(v);
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
+}
+// one channel of a split-precision output row: mode 1 = [hi | hi | lo] planes of C (row of 3C bf16), mode 2 = split2,
+// per 32-channel block [32 x hi | 32 x lo] (row of 2C bf16, csrc/gemm_x3.hip)
+__device__ __forceinline__ void att_store_split(uint16_t* out16, int64_t orow, int C, int ch, float v, int mode) {
+  const uint16_t hi = att_bf16_rne(v);
+  const uint16_t lo = att_bf16_rne(v - __uint_as_float((uint32_t)hi << 16));
+  if (mode == 2) {
+    uint16_t* o = out16 + orow * (2 * (int64_t)C) + (ch >> 5) * 64 + (ch & 31);
+    o[0] = hi;
+    o[32] = lo;
+  } else {
+    uint16_t* o = out16 + orow * (3 * (int64_t)C) + ch;
+    o[0] = hi;
+    o[C] = hi;
+    o[2 * C] = lo;
+  }
 }
 
 // T = number of 16-wide tiles of the padded sequence (K/16 + G), G = relay tokens
@@ -409,11 +426,7 @@ window_attn_kernel_v2(const WinParams p) {
         const int orow = s_row[qt * 16 + 4 * g + r];
         if (orow >= 0) {
           if (p.out_split) {
-            uint16_t* orow16 = reinterpret_cast<uint16_t*>(p.out) + (int64_t)orow * 3 * C + h * 16 + c;
-            const uint16_t hi = att_bf16_rne(o[r]);
-            orow16[0] = hi;
-            orow16[C] = hi;
-            orow16[2 * C] = att_bf16_rne(o[r] - __uint_as_float((uint32_t)hi << 16));
+            att_store_split(reinterpret_cast<uint16_t*>(p.out), orow, C, h * 16 + c, o[r], p.out_split);
           } else {
             p.out[(int64_t)orow * C + h * 16 + c] = o[r];
           }
@@ -473,11 +486,7 @@ window_attn_kernel_v2(const WinParams p) {
       const int orow = s_row[K];
       if (g == 0 && orow >= 0) {
         if (p.out_split) {
-          uint16_t* orow16 = reinterpret_cast<uint16_t*>(p.out) + (int64_t)orow * 3 * C + h * 16 + c;
-          const uint16_t hi = att_bf16_rne(acc);
-          orow16[0] = hi;
-          orow16[C] = hi;
-          orow16[2 * C] = att_bf16_rne(acc - __uint_as_float((uint32_t)hi << 16));
+          att_store_split(reinterpret_cast<uint16_t*>(p.out), orow, C, h * 16 + c, acc, p.out_split);
         } else {
           p.out[(int64_t)orow * C + h * 16 + c] = acc;
         }
@@ -546,7 +555,7 @@ window_attn_kernel_v4(const WinParams p) {
   const float mask2 = kMaskValue * kLog2e;
   const float rt_add = (g == 0) ? 0.f : kDeadValue;   // the relay key lives in the g == 0 lanes only
   const uint32_t row_q = (uint32_t)(3 * C) * 4u;       // bytes per qkv row
-  const uint32_t row_o = p.out_split ? (uint32_t)(3 * C) * 2u : (uint32_t)C * 4u;
+  const uint32_t row_o = p.out_split == 1 ? (uint32_t)(3 * C) * 2u : (uint32_t)C * 4u;   // split2 rows: 2C bf16 = 4C B
   const char* qkv_b = reinterpret_cast<const char*>(p.qkv);
   char* out_b = reinterpret_cast<char*>(p.out);
 
@@ -756,11 +765,7 @@ window_attn_kernel_v4(const WinParams p) {
           if ((!MASKED || orow >= 0) && (!(p.dbg & 2) || o[r] == 1234.5f)) {
             char* ob = out_b + ((uint32_t)orow * row_o);
             if (p.out_split) {
-              uint16_t* o16 = reinterpret_cast<uint16_t*>(ob) + h * 16 + c;
-              const uint16_t hi = att_bf16_rne(o[r]);
-              o16[0] = hi;
-              o16[C] = hi;
-              o16[2 * C] = att_bf16_rne(o[r] - __uint_as_float((uint32_t)hi << 16));
+              att_store_split(reinterpret_cast<uint16_t*>(out_b), orow, C, h * 16 + c, o[r], p.out_split);
             } else {
               reinterpret_cast<float*>(ob)[h * 16 + c] = o[r];
             }
@@ -819,11 +824,7 @@ window_attn_kernel_v4(const WinParams p) {
         if (g == 0 && orow >= 0) {
           char* ob = out_b + ((uint32_t)orow * row_o);
           if (p.out_split) {
-            uint16_t* o16 = reinterpret_cast<uint16_t*>(ob) + h * 16 + c;
-            const uint16_t hi = att_bf16_rne(acc);
-            o16[0] = hi;
-            o16[C] = hi;
-            o16[2 * C] = att_bf16_rne(acc - __uint_as_float((uint32_t)hi << 16));
+            att_store_split(reinterpret_cast<uint16_t*>(out_b), orow, C, h * 16 + c, acc, p.out_split);
           } else {
             reinterpret_cast<float*>(ob)[h * 16 + c] = acc;
           }
@@ -840,8 +841,7 @@ window_attn_kernel_v4(const WinParams p) {
             const float v = qf[qt].x + kf[qt].y + vf[qt][r];
             char* ob = out_b + ((uint32_t)orow * row_o);
             if (p.out_split) {
-              uint16_t* o16 = reinterpret_cast<uint16_t*>(ob) + h * 16 + c;
-              o16[0] = att_bf16_rne(v); o16[C] = o16[0]; o16[2 * C] = 0;
+              att_store_split(reinterpret_cast<uint16_t*>(out_b), orow, C, h * 16 + c, v, p.out_split);
             } else {
               reinterpret_cast<float*>(ob)[h * 16 + c] = v;
             }
@@ -1023,6 +1023,7 @@ extern "C" void hfl_internal_set_cpe_chunk(int rows);
 extern "C" void hfl_internal_set_cpe_variant(int v, int wgs);
 extern "C" void hfl_internal_set_linear_ablate(int v);
 /* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
+void hfl_internal_set_x3_dbg(int v);
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
   const char* k = "window_attention";
@@ -1037,6 +1038,13 @@ int hfl_set_variant(const char* key, int value) {
   while (k4[i] != 0 && key[i] == k4[i]) ++i;
   if (k4[i] == 0 && key[i] == 0) {
     hfl_internal_set_linear_ablate(value);
+    return HFL_OK;
+  }
+  const char* kx = "x3_dbg";
+  i = 0;
+  while (kx[i] != 0 && key[i] == kx[i]) ++i;
+  if (kx[i] == 0 && key[i] == 0) {
+    hfl_internal_set_x3_dbg(value);
     return HFL_OK;
   }
   const char* k9 = "cpe_variant";

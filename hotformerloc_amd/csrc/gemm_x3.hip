@@ -1,0 +1,313 @@
+// fp32-equivalent Linear on the bf16 matrix cores of gfx950, hand-written (no library):
+//
+//     y (M,N) = x (M,K) . W (N,K)^T  [+ bias]  [GELU]  [+ residual]
+//
+// Replaces torch.nn.Linear + the element-wise op that follows it in every transformer block of the reference
+// (qkv / proj: models/octformer_backbone.py:70,91; fc1 -> GELU -> fc2: models/layers/octformer_layers.py:53-59;
+// residual adds: models/octformer_backbone.py:275-278, models/hotformerloc_backbone.py:213-216).
+//
+// Arithmetic: every fp32 operand is split into bf16 (hi, lo), hi = RNE(v), lo = RNE(v - hi) (v = hi + lo to 2^-17) and
+// the product is x_lo w_hi + x_hi w_lo + x_hi w_hi in that order with fp32 accumulation (v_mfma_f32_16x16x32_bf16):
+// 4e-6 relative per GEMM against fp64.  Both operands arrive PRE-SPLIT in the "split2" layout
+//
+//     (rows, K/32, 2, 32) bf16  =  per 32-wide k-block: [32 x hi | 32 x lo]  = one 128-B line per (row, k-block)
+//
+// so a row's k-block is fetched once (4 B per element, not the 6 B of a K-concatenated [hi|hi|lo] operand) and used
+// by three MFMAs.  Producers write that layout directly (LayerNorm, the attention kernel, this kernel's own GELU
+// epilogue), weights are laid out once per parameter on the host.
+//
+// Kernel: 128 (rows) x 128 (features) tile per 256-lane workgroup, 2 x 2 waves of 64 x 64, K step 32.
+//  * global -> LDS by `global_load_lds_dwordx4` (no registers, no VALU): one wave-instruction moves 8 rows x 128 B.
+//    LDS image per operand tile: 128 rows x 8 slots of 16 B, slot (t ^ ((row >> 1) & 7)): ds_read_b128 of an MFMA
+//    fragment (16 rows x one 16-B chunk per 16-lane group) then touches 16 distinct bank slots.  LDS-DMA writes are
+//    lane-linear, so the permutation is applied on the SOURCE address (lane -> which 16-B chunk of the line it fetches)
+//    and again on the read.
+//  * ONE 32-KiB LDS stage, 3 workgroups per CU: a k-step first pulls its 16 fragments into registers, then (second
+//    barrier) the DMA of step t+1 is issued and lands while the 48 MFMAs of step t run.  Co-resident workgroups sit in
+//    different phases (load / MFMA / store), which is what keeps HBM reads, the matrix pipe and HBM writes busy together.
+//  * the MFMA takes W as its A operand and x as its B operand, so the accumulator holds 4 CONSECUTIVE FEATURES of one
+//    row per lane; the epilogue transposes through LDS so that every store instruction writes whole 128-B lines
+//    (bias / GELU / residual / re-split fused).
+//  * 1-D grid, XCD-aware: the N/128 feature tiles of one row tile get consecutive slots on ONE XCD (blocks b and b+8
+//    share an XCD), so the row tile's activations are fetched from HBM once and re-read from that XCD's L2.
+#include "hfl_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XT = 128;                  // tile edge (rows and features)
+constexpr int TILE_B = XT * 128;         // one operand tile per stage: 128 rows x 128 B (32 hi + 32 lo bf16)
+constexpr int STAGE_B = 2 * TILE_B;      // x tile | w tile
+
+struct X3Params {
+  void* out;                // EPI 0: float (M, N); EPI 1: bf16 split2 (M, N/32, 2, 32)
+  const uint16_t* x;        // (M, K/32, 2, 32) bf16
+  const uint16_t* w;        // (N, K/32, 2, 32) bf16
+  const float* bias;        // (N) or null
+  const float* residual;    // (M, N) or null (EPI 0 only; may alias out)
+  int64_t M;
+  int N, K;
+  int tiles_n;
+  int64_t n_wg;
+  int dbg;                  // ablation bits (tools/x3_probe.py): 1 no in-loop DMA, 2 no MFMA, 4 no stores, 8 no LDS reads
+};
+
+static int g_x3_dbg = 0;
+
+__device__ __forceinline__ uint32_t x3_bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+// exact (erf) GELU, erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, below the 2^-17 relative error of the
+// split that follows): one v_rcp, one v_exp, 7 fma -- a third of the library erff's instruction count
+__device__ __forceinline__ float x3_gelu(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);               // erf(|v| / sqrt 2)
+  const float erf_v = copysignf(erf_abs, v);
+  return 0.5f * v * (1.0f + erf_v);
+}
+
+// EPI 0: out f32 = acc + bias [+ residual];  EPI 1: out split2 = split(gelu(acc + bias))
+template <int EPI>
+__global__ void __launch_bounds__(256, 3)
+gemm_x3_kernel(const X3Params p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // one stage: x tile | w tile (32 KiB)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1;
+
+  // ---- XCD-aware tile assignment (bijective remap: consecutive new ids share an XCD) -------------------------
+  int64_t wg = blockIdx.x;
+  {
+    const int64_t q = p.n_wg >> 3, r = p.n_wg & 7;
+    const int64_t xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int64_t m0 = (wg / p.tiles_n) * XT;
+  const int n0 = (int)(wg % p.tiles_n) * XT;
+  const int K = p.K;
+  const int nk = K >> 5;
+  const int64_t row_b = (int64_t)K * 4;                       // bytes per split2 row (2K bf16)
+
+  // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per instruction ------------------------
+  // lane -> (row within the 8, physical slot); the slot it fills holds logical chunk t = slot ^ ((row >> 1) & 7)
+  const int srow = lane >> 3, sslot = lane & 7;
+  // uniform tile bases (SGPRs) + 32-bit per-lane offsets: tail rows fetch the last valid row, never stored
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
+  const int rows_valid = (int)((p.M - m0) < XT ? (p.M - m0) : XT);
+  uint32_t xoff[4], woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + srow;
+    const int t = sslot ^ ((row >> 1) & 7);
+    const int xr = row < rows_valid ? row : rows_valid - 1;
+    xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
+    woff[i] = (uint32_t)row * (uint32_t)row_b + t * 16;
+  }
+  auto stage = [&](int kt) {
+    unsigned char* sb = smem + (wave * 32) * 128;
+    const unsigned char* xk = xbase + (int64_t)kt * 128;
+    const unsigned char* wk = wbase + (int64_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
+                                       (__attribute__((address_space(3))) void*)(sb + TILE_B + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses (bytes inside the stage): row = base + 16 i + (lane & 15), chunk q = lane >> 4 --------
+  const int frow = lane & 15, fq = lane >> 4;
+  int offw_hi[4], offx_hi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rn = wn * 64 + i * 16 + frow;
+    const int rm = wm * 64 + i * 16 + frow;
+    offw_hi[i] = TILE_B + rn * 128 + ((fq ^ ((rn >> 1) & 7)) << 4);
+    offx_hi[i] = rm * 128 + ((fq ^ ((rm >> 1) & 7)) << 4);
+  }
+  // the lo chunk is logical slot 4 + q: physical slot differs from the hi one in bit 2 only -> byte offset ^ 64
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // One LDS stage, two barriers per k-step: once every wave holds the step's 16 fragments in registers the stage is
+  // free again, so the DMA of step t+1 is issued BEFORE the 48 MFMAs of step t and lands while they run.
+  stage(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                       // drains this wave's LDS-DMA (vmcnt) and publishes the stage
+    bf16x8 wh[4], wl[4], xh[4], xl[4];
+    if (p.dbg & 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wh[i] = wl[i] = xh[i] = xl[i] = (bf16x8){(short)kt, 1, 2, 3, 4, 5, 6, (short)lane};
+        asm volatile("" : "+v"(wh[i]), "+v"(wl[i]), "+v"(xh[i]), "+v"(xl[i]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wh[i] = *reinterpret_cast<const bf16x8*>(smem + offw_hi[i]);
+        wl[i] = *reinterpret_cast<const bf16x8*>(smem + (offw_hi[i] ^ 64));
+        xh[i] = *reinterpret_cast<const bf16x8*>(smem + offx_hi[i]);
+        xl[i] = *reinterpret_cast<const bf16x8*>(smem + (offx_hi[i] ^ 64));
+      }
+    }
+    __syncthreads();                       // every wave has its fragments (lgkmcnt(0) precedes the barrier)
+    if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1);
+    if (p.dbg & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(wh[i]), "v"(wl[i]), "v"(xh[i]), "v"(xl[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  // The accumulator holds features n..n+3 (registers) of row m = lane & 15: stored as is, a 128-B line would be
+  // written in two halves by different instructions.  Each wave transposes its 64 x 64 tile through a private 8 KiB
+  // LDS region, 32 rows at a time (16-B chunks XOR-swizzled by the row: conflict-free both ways), and reads it back so
+  // that 16 consecutive lanes hold 256 contiguous bytes of one output row: every store instruction writes whole lines.
+  const int N = p.N;
+  unsigned char* ep = smem + wave * 8192;                                     // the stage is free after the last barrier
+  const int ecol = lane & 15;                                                 // 16-B chunk (4 features) inside the row
+  const int nbase = n0 + wn * 64 + ecol * 4;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + nbase);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = jj * 16 + frow;
+        *reinterpret_cast<f32x4*>(ep + r * 256 + (((i * 4 + fq) ^ frow) << 4)) = acc[i][2 * h + jj];
+      }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 4 + fq;                                              // row inside the 32
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ (r & 15)) << 4));
+      const int64_t m = m0 + wm * 64 + h * 32 + r;
+      if (m >= p.M) continue;
+      if ((p.dbg & 4) && a[0] != 1234.5f) continue;
+      float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+      if (EPI == 0) {
+        if (p.residual != nullptr) {
+          const float4 rs = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * N + nbase) = v;
+      } else {
+        v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
+        const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
+        const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
+        const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
+        const uint32_t l2 = x3_bf16_rne(v.z - __uint_as_float(h2 << 16));
+        const uint32_t l3 = x3_bf16_rne(v.w - __uint_as_float(h3 << 16));
+        // lane pair (2k, 2k+1) holds 8 consecutive features: the even lane stores their 8 hi values (16 B), the odd
+        // lane their 8 lo values, so one instruction writes both halves of every [32 x hi | 32 x lo] line
+        const uint32_t mine0 = (lane & 1) ? h0 | (h1 << 16) : l0 | (l1 << 16);   // what the partner needs from me
+        const uint32_t mine1 = (lane & 1) ? h2 | (h3 << 16) : l2 | (l3 << 16);
+        const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
+        uint4 q;
+        if (lane & 1) q = make_uint4(got0, got1, l0 | (l1 << 16), l2 | (l3 << 16));        // lo of (partner, me)
+        else          q = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), got0, got1);        // hi of (me, partner)
+        const int nfeat = n0 + wn * 64 + (ecol & ~1) * 4;                      // first of the pair's 8 features
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + m * (2 * (int64_t)N) + (nfeat >> 5) * 64 + (nfeat & 31) +
+                      ((lane & 1) ? 32 : 0);
+        *reinterpret_cast<uint4*>(o) = q;
+      }
+    }
+  }
+}
+
+// fp32 (rows, C) -> split2 (rows, C/32, 2, 32) bf16
+__global__ void __launch_bounds__(256)
+split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, int64_t n_rows, int C) {
+  const int cv = C / 4;
+  const int64_t total = n_rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
+    const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
+    const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
+    const uint32_t l2 = x3_bf16_rne(v.z - __uint_as_float(h2 << 16));
+    const uint32_t l3 = x3_bf16_rne(v.w - __uint_as_float(h3 << 16));
+    uint16_t* o = out + r * (2 * (int64_t)C) + (c >> 5) * 64 + (c & 31);
+    *reinterpret_cast<uint2*>(o) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    *reinterpret_cast<uint2*>(o + 32) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void hfl_internal_set_x3_dbg(int v) { g_x3_dbg = v; }
+
+int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                  const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
+                  hfl_stream_t stream) {
+  if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
+  if (in_features % 32 != 0 || out_features % XT != 0) return HFL_EINVAL;
+  if (out == nullptr || x_split2 == nullptr || w_split2 == nullptr) return HFL_EINVAL;
+  if (gelu_split_out && residual != nullptr) return HFL_EINVAL;
+  if (n_rows == 0) return HFL_OK;
+  X3Params p;
+  p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual;
+  p.M = n_rows; p.N = out_features; p.K = in_features;
+  p.tiles_n = out_features / XT;
+  p.n_wg = hfl_cdiv(n_rows, XT) * p.tiles_n;
+  p.dbg = g_x3_dbg;
+  if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
+  const size_t lds = (size_t)STAGE_B;              // 32 KiB: 3 workgroups per CU
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (gelu_split_out) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    gemm_x3_kernel<1><<<(unsigned)p.n_wg, 256, lds, s>>>(p);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<0>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    gemm_x3_kernel<0><<<(unsigned)p.n_wg, 256, lds, s>>>(p);
+  }
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream) {
+  if (n_rows < 0 || channels <= 0 || channels % 32 != 0) return HFL_EINVAL;
+  if (n_rows == 0) return HFL_OK;
+  const int64_t need = hfl_cdiv(n_rows * (channels / 4), 256);
+  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  split2_kernel<<<(int)(need < cap ? need : cap), 256, 0, static_cast<hipStream_t>(stream)>>>(out, x, n_rows,
+                                                                                              (int)channels);
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // extern "C"

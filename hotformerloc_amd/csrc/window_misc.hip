@@ -251,7 +251,17 @@ __device__ __forceinline__ void hfl_store_split3(uint16_t* row, int C, int c4, c
   reinterpret_cast<uint2*>(row + 2 * C)[c4] = lo;
 }
 
-template <int TPR, int VPL, bool ADD, bool SPLIT>
+// row of the hand-written split GEMM's operand (csrc/gemm_x3.hip): per 32-channel block [32 x hi | 32 x lo]
+__device__ __forceinline__ void hfl_store_split2(uint16_t* row, int c4, const float4 v) {
+  uint2 hi, lo;
+  hfl_split4(v, hi, lo);
+  uint16_t* o = row + (c4 >> 3) * 64 + (c4 & 7) * 4;
+  *reinterpret_cast<uint2*>(o) = hi;
+  *reinterpret_cast<uint2*>(o + 32) = lo;
+}
+
+// SPLIT: 0 = fp32 output, 1 = bf16 [hi|hi|lo] (K-concatenated, hipBLASLt route), 2 = bf16 split2 (gemm_x3 route)
+template <int TPR, int VPL, bool ADD, int SPLIT>
 __global__ void __launch_bounds__(256)
 layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const float* __restrict__ y,
                   const float* __restrict__ bias, const float* __restrict__ gamma,
@@ -303,8 +313,10 @@ layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const
         o.y = fmaf(a[v].y * rstd, gm[v].y, bt[v].y);
         o.z = fmaf(a[v].z * rstd, gm[v].z, bt[v].z);
         o.w = fmaf(a[v].w * rstd, gm[v].w, bt[v].w);
-        if (SPLIT)
+        if (SPLIT == 1)
           hfl_store_split3(reinterpret_cast<uint16_t*>(h_out) + r * 3 * C, C, v * TPR + tx, o);
+        else if (SPLIT == 2)
+          hfl_store_split2(reinterpret_cast<uint16_t*>(h_out) + r * 2 * C, v * TPR + tx, o);
         else
           reinterpret_cast<float4*>(h_out + r * C)[v * TPR + tx] = o;
       }
@@ -321,15 +333,19 @@ static int launch_ln(float* h_out, float* x_out, const float* x, const float* y,
   const int64_t cap = (int64_t)hfl_num_cus() * 16;
   const int blocks = (int)(need < cap ? need : cap);
   if (y != nullptr) {
-    if (split)
-      layer_norm_kernel<TPR, VPL, true, true><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+    if (split == 2)
+      layer_norm_kernel<TPR, VPL, true, 2><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+    else if (split)
+      layer_norm_kernel<TPR, VPL, true, 1><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
     else
-      layer_norm_kernel<TPR, VPL, true, false><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, true, 0><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
   } else {
-    if (split)
-      layer_norm_kernel<TPR, VPL, false, true><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+    if (split == 2)
+      layer_norm_kernel<TPR, VPL, false, 2><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+    else if (split)
+      layer_norm_kernel<TPR, VPL, false, 1><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
     else
-      layer_norm_kernel<TPR, VPL, false, false><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, false, 0><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
   }
   HFL_RETURN_LAST_ERROR();
 }
@@ -470,6 +486,13 @@ int hfl_layer_norm_split3(uint16_t* out, const float* x, const float* gamma, con
   if (n_rows < 0) return HFL_EINVAL;
   return dispatch_ln(reinterpret_cast<float*>(out), nullptr, x, nullptr, nullptr, gamma, beta, n_rows,
                      channels, eps, 1, static_cast<hipStream_t>(stream));
+}
+
+int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, const float* beta,
+                          int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream) {
+  if (n_rows < 0 || channels % 32 != 0) return HFL_EINVAL;
+  return dispatch_ln(reinterpret_cast<float*>(out), nullptr, x, nullptr, nullptr, gamma, beta, n_rows,
+                     channels, eps, 2, static_cast<hipStream_t>(stream));
 }
 
 int hfl_add_layer_norm_split3(float* x_out, uint16_t* h_out, const float* x, const float* y,

@@ -76,7 +76,9 @@ def _add_ln(x, y, m: nn.LayerNorm):
 
 # ---- Linear layers: 'fp32' = hipBLASLt fp32 GEMM; 'bf16x3' = one bf16 GEMM over K-concatenated
 # (hi|hi|lo) x (hi|lo|hi) operands with fp32 accumulation/output (include/hotformerloc_hip.h section 9).
-_GEMM_MODE = os.environ.get('HFL_GEMM', 'bf16x3')
+# 'x3' = the same split arithmetic on the hand-written kernel (csrc/gemm_x3.hip: pre-split "split2" operands, bias /
+# GELU / residual / re-split fused into the epilogue) for the Linear layers of the transformer blocks.
+_GEMM_MODE = os.environ.get('HFL_GEMM', 'x3')
 _PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
 _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 # training-path Linear layers on split-bf16 GEMMs (autograd.LinearSplitFn).  Off by default: parity-tested, but
@@ -103,7 +105,7 @@ _W3_CACHE = {}          # id(weight) -> (weakref to weight, version, W3)
 
 def set_gemm_mode(mode: str):
     global _GEMM_MODE
-    assert mode in ('fp32', 'bf16x3')
+    assert mode in ('fp32', 'bf16x3', 'x3')
     _GEMM_MODE = mode
 
 
@@ -112,7 +114,27 @@ def get_gemm_mode() -> str:
 
 
 def _split_path(x) -> bool:
-    return _GEMM_MODE == 'bf16x3' and x.is_cuda and not _grad_path()
+    return _GEMM_MODE in ('bf16x3', 'x3') and x.is_cuda and not _grad_path()
+
+
+def _w2(lin: nn.Linear):
+    """split2 layout of a Linear weight for `ops.linear_x3`, cached like `_w3`."""
+    w = lin.weight
+    key = ('x3', id(w))
+    hit = _W3_CACHE.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[3] != w.data_ptr():
+        hit = (weakref.ref(w), w._version, ops.split2_weight(w), w.data_ptr())
+        _W3_CACHE[key] = hit
+    return hit[2]
+
+
+def _block_tail_x3(x, attn_out2, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
+    """proj (+bias +residual) -> LN2 -> fc1 (+bias, GELU, re-split) -> fc2 (+bias +residual): four launches of the
+    hand-written GEMM and one LayerNorm; the M x 4C hidden activation crosses HBM once each way as 4 B per element."""
+    x = ops.linear_x3(attn_out2, _w2(attn.proj), bias=attn.proj.bias, residual=x)
+    h2 = ops.layer_norm_split2(x, norm2.weight, norm2.bias, norm2.eps)
+    g2 = ops.linear_x3(h2, _w2(mlp.fc1), bias=mlp.fc1.bias, gelu_split_out=True)
+    return ops.linear_x3(g2, _w2(mlp.fc2), bias=mlp.fc2.bias, residual=x)
 
 
 def _w3(lin: nn.Linear):
@@ -142,6 +164,8 @@ class SplitLinear(nn.Linear):
 def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
     """proj -> +residual -> LN2 -> fc1 -> GELU -> fc2 -> +residual with every bias folded into
     the element-wise kernel that follows its GEMM."""
+    if _GEMM_MODE == 'x3':
+        return _block_tail_x3(x, attn_out3, attn, norm2, mlp)
     if _LT_EPILOGUE:
         # bias + residual ride in the GEMM launch (hfl_gemm_bf16): no pass over the residual stream
         x = ops.gemm_bf16(attn_out3, _w3(attn.proj), bias=attn.proj.bias, residual=x)
@@ -369,6 +393,10 @@ class OctreeAttention(nn.Module):
 
     def forward_split(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
         """LN1 -> qkv -> attention, split-precision path; returns the bf16 operand of `proj`."""
+        if _GEMM_MODE == 'x3':         # qkv bias folded into the GEMM epilogue, attention writes split2 rows
+            a2 = ops.layer_norm_split2(x, norm1.weight, norm1.bias, norm1.eps)
+            qkv = ops.linear_x3(a2, _w2(self.qkv), bias=self.qkv.bias)
+            return self.core(qkv, plan, depth, out_split=2)
         a3 = ops.layer_norm_split3(x, norm1.weight, norm1.bias, norm1.eps)
         return self.core(ops.split_mm(a3, _w3(self.qkv)), plan, depth, qkv_bias=self.qkv.bias,
                          out_split=True)

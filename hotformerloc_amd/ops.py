@@ -329,6 +329,69 @@ def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, out=
     return out
 
 
+# ------------------------------------------- hand-written split-precision Linear (csrc/gemm_x3.hip)
+def split2(x):
+    """fp32 (rows, C) -> split2 bf16 (rows, 2C): per 32-channel block [32 x hi | 32 x lo] (hfl_split2)."""
+    _dev(x)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    out = torch.empty((x2.shape[0], 2 * c), dtype=torch.bfloat16, device=x.device)
+    check(_native.load().hfl_split2(out.data_ptr(), x2.data_ptr(), x2.shape[0], c, _stream()), 'hfl_split2')
+    return out
+
+
+def layer_norm_split2(x, weight, bias, eps: float = 1e-5):
+    """split2(LN(x)): the operand of `linear_x3` (hfl_layer_norm_split2)."""
+    _dev(x, weight, bias)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    out = torch.empty((x2.shape[0], 2 * c), dtype=torch.bfloat16, device=x.device)
+    with _timed('hfl_layer_norm_split2', x2.numel() * 8):
+        check(_native.load().hfl_layer_norm_split2(out.data_ptr(), x2.data_ptr(), weight.data_ptr(),
+                                                   bias.data_ptr(), x2.shape[0], c, float(eps),
+                                                   _stream()), 'hfl_layer_norm_split2')
+    return out
+
+
+def split2_weight(w: torch.Tensor) -> torch.Tensor:
+    """(N, K) fp32 Linear weight -> split2 bf16 (N, 2K) (host-side layout, once per parameter)."""
+    w = w.detach().float()
+    n, k = w.shape
+    assert k % 32 == 0
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.view(n, k // 32, 32), lo.view(n, k // 32, 32)], dim=2).reshape(n, 2 * k).contiguous()
+
+
+def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu_split_out: bool = False,
+              out=None) -> torch.Tensor:
+    """y = x W^T [+ bias] [+ residual] (fp32), or with gelu_split_out the split2 bf16 operand of the next Linear,
+    split2(gelu(x W^T + bias)); x2 / w2 are split2 operands (hfl_linear_x3)."""
+    _dev(x2, w2, bias, residual)
+    assert x2.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x2.is_contiguous() and w2.is_contiguous()
+    m, k2 = x2.shape
+    n = w2.shape[0]
+    assert w2.shape[1] == k2 and k2 % 64 == 0
+    k = k2 // 2
+    if gelu_split_out:
+        assert residual is None
+        if out is None:
+            out = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=x2.device)
+    else:
+        if out is None:
+            out = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+        if residual is not None:
+            residual = _f32c(residual)
+            assert tuple(residual.shape) == (m, n)
+    # algorithmic bytes: x once (4 B/elt), out once (4 B/elt either form), residual once; 2 M K N flop (fp32-equivalent)
+    with _timed('hfl_linear_x3', m * k * 4 + m * n * (8 if residual is not None else 4), 2 * m * k * n):
+        check(_native.load().hfl_linear_x3(out.data_ptr(), x2.data_ptr(), w2.data_ptr(),
+                                           None if bias is None else _f32c(bias).data_ptr(),
+                                           None if residual is None else residual.data_ptr(), m, k, n,
+                                           int(bool(gelu_split_out)), _stream()), 'hfl_linear_x3')
+    return out
+
+
 def stack3(x: torch.Tensor, order: str) -> torch.Tensor:
     """(M, C) fp32 -> (3M, C) bf16 planes stacked along the rows: 'hhl' = [hi; hi; lo], 'hlh' = [hi; lo; hi]
     (operands of `gemm_bf16_tn`, the contraction runs over the rows)."""
@@ -422,10 +485,12 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     rows = qkv.shape[0]
     c = n_heads * 16
     assert qkv.shape[1] == 3 * c
+    out_split = int(out_split)          # 0: fp32 out; 1: bf16 [hi|hi|lo] (rows, 3c); 2: bf16 split2 (rows, 2c)
     if out_split:
+        width = 3 * c if out_split == 1 else 2 * c
         # rows the kernel does not own (none today) must not hold NaN bit patterns
-        out = torch.zeros((rows, 3 * c), dtype=torch.bfloat16, device=qkv.device) if rows > n_tokens + \
-            (n_windows if n_relay else 0) else torch.empty((rows, 3 * c), dtype=torch.bfloat16, device=qkv.device)
+        out = torch.zeros((rows, width), dtype=torch.bfloat16, device=qkv.device) if rows > n_tokens + \
+            (n_windows if n_relay else 0) else torch.empty((rows, width), dtype=torch.bfloat16, device=qkv.device)
     else:
         out = torch.empty((rows, c), dtype=torch.float32, device=qkv.device)
     desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=rt_row0, n_windows=n_windows,
@@ -446,10 +511,10 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     # algorithmic work: read q,k,v + write out = 16 B per (row, channel); QK^T + PV = 4 L^2 C per
     # window.  Moved: the bf16 [hi|hi|lo] output is 6 B instead of 4 B per channel, plus 8 B of metadata per token
     with _timed('hfl_window_attention_fwd', used * c * 16, 4 * seq * seq * c * real_windows,
-                moved=used * c * (18 if out_split else 16) + n_tokens * 8):
+                moved=used * c * (18 if out_split == 1 else 16) + n_tokens * 8):
         check(_native.load().hfl_window_attention_fwd_ex(
             out.data_ptr(), qkv.data_ptr(), None if qkv_bias is None else _f32c(qkv_bias).data_ptr(),
-            tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), int(bool(out_split)), _stream()),
+            tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), out_split, _stream()),
             'hfl_window_attention_fwd')
     return out
 

@@ -18,8 +18,6 @@ Formulas: SURVEY.md Appendix E (restating `models/octree.py:73-75,130-184,229-26
 
 from typing import Dict, List, Optional
 
-import weakref
-
 import numpy as np
 import torch
 
@@ -91,7 +89,9 @@ class WindowPlan:
     def __init__(self, octree, patch_size: int, dilation: int, max_depth: int, start_depth: int,
                  num_pyramid_levels: int, num_octf_levels: int, adape_mode: Optional[str] = None):
         assert start_depth >= 1, 'Octree not deep enough for model depth'    # octree.py:71
-        self._octree = weakref.ref(octree)       # the octree caches its plans (WindowPlan.for_octree): no cycle
+        # strong reference: a checkpointed backward re-runs blocks after the caller's batch dict is gone.  The octree
+        # caches its plans (WindowPlan.for_octree), so octree <-> plan is a reference cycle the garbage collector frees.
+        self.octree = octree
         self.K, self.D = patch_size, dilation
         self.B = octree.batch_size
         self.max_depth, self.start_depth = max_depth, start_depth
@@ -127,13 +127,6 @@ class WindowPlan:
             for d in self.pyramid_depths:
                 self.window_stats[d] = ops.window_stats(self.meta[d], self.n_tokens[d],
                                                         self.n_windows[d], self.K, d)
-
-    @property
-    def octree(self):
-        o = self._octree()
-        if o is None:
-            raise RuntimeError('the octree of this WindowPlan is gone')
-        return o
 
     @classmethod
     def for_octree(cls, octree, patch_size, dilation, max_depth, start_depth, num_pyramid_levels,

@@ -334,6 +334,23 @@ int hfl_linear_bf16x3(float* out, const float* x, const uint16_t* w_hi, const ui
                       const float* bias, const float* residual, int64_t n_rows, int in_features,
                       int out_features, int gelu, hfl_stream_t stream);
 
+/* 9b. Hand-written split-precision Linear (csrc/gemm_x3.hip): y = x W^T [+ bias] [GELU] [+ residual] with
+ * fp32-equivalent accuracy on the bf16 matrix cores (x_lo w_hi + x_hi w_lo + x_hi w_hi, fp32 accumulation).
+ * Replaces torch.nn.Linear and the element-wise op after it (models/octformer_backbone.py:70,91,275-278;
+ * models/layers/octformer_layers.py:53-59; models/hotformerloc_backbone.py:213-216).
+ * Operands are PRE-SPLIT in the "split2" layout (rows, K/32, 2, 32) bf16: per 32-wide k-block [32 x hi | 32 x lo]
+ * (hi = RNE(v), lo = RNE(v - hi)); hfl_split2 converts an fp32 matrix, hfl_layer_norm_split2 and the attention
+ * kernel (out_split = 2) write it directly.  in_features % 32 == 0, out_features % 128 == 0.
+ *   gelu_split_out = 0: out is float (n_rows, out_features) = acc + bias [+ residual]  (residual may alias out)
+ *   gelu_split_out = 1: out is split2 bf16 (n_rows, out_features/32, 2, 32) of gelu(acc + bias), exact erf GELU */
+int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                  const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
+                  hfl_stream_t stream);
+int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* split2(LayerNorm(x)) in one pass (the LayerNorm in front of qkv / fc1: models/octformer_backbone.py:275-278) */
+int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, const float* beta,
+                          int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 10. Backward kernels (training path; autograd glue in hotformerloc_amd/autograd.py).
  *     The reference gets these from PyTorch autograd over its materialised formulation and from

@@ -472,6 +472,69 @@ def test_window_attention_fused_bias_and_split_output():
         assert torch.equal(got3[:, :C], got3[:, C:2 * C])
         got = got3[:, :C] + got3[:, 2 * C:]
         assert (got - want).abs().max() < 1e-4 * want.abs().max() + 1e-6
+        # split2 rows (operand of hfl_linear_x3): the same hi / lo values, laid out per 32-channel block
+        got2 = ops.window_attention(qkv, plan.meta[depth], table, nt, W, K, 1, G, H, 2, rt_row0=nt,
+                                    depth=depth, qkv_bias=bias, out_split=2).float().view(rows, C // 32, 2, 32)
+        assert torch.equal(got2[:, :, 0].reshape(rows, C), got3[:, :C])
+        assert torch.equal(got2[:, :, 1].reshape(rows, C), got3[:, 2 * C:])
+
+
+def _unsplit2(a2, c):
+    a2 = a2.float().cpu().view(a2.shape[0], c // 32, 2, 32)
+    return (a2[:, :, 0] + a2[:, :, 1]).reshape(-1, c)
+
+
+def test_linear_x3_exact_on_small_integers():
+    """Layout check of the hand-written split GEMM with exactly representable data (asymmetric operands, M tail,
+    every epilogue): integer-valued inputs make x W^T exact in fp32, so any mis-placed fragment shows up as a wrong
+    integer, not as rounding noise."""
+    g = torch.Generator().manual_seed(21)
+    for n, cin, cout in ((300, 64, 128), (129, 32, 256), (1, 96, 128), (515, 256, 384)):
+        x = torch.randint(-8, 9, (n, cin), generator=g).float()
+        w = torch.randint(-8, 9, (cout, cin), generator=g).float()
+        b = torch.randint(-20, 21, (cout,), generator=g).float()
+        r = torch.randint(-50, 51, (n, cout), generator=g).float()
+        x2, w2 = ops.split2(x.to(DEV)), ops.split2_weight(w.to(DEV))
+        assert torch.equal(_unsplit2(x2, cin), x)
+        ref = x @ w.t()
+        assert torch.equal(ops.linear_x3(x2, w2).cpu(), ref)
+        assert torch.equal(ops.linear_x3(x2, w2, bias=b.to(DEV)).cpu(), ref + b)
+        assert torch.equal(ops.linear_x3(x2, w2, bias=b.to(DEV), residual=r.to(DEV)).cpu(), ref + b + r)
+        buf = r.to(DEV).clone()                                     # residual aliasing the output
+        ops.linear_x3(x2, w2, bias=b.to(DEV), residual=buf, out=buf)
+        assert torch.equal(buf.cpu(), ref + b + r)
+        gl = torch.nn.functional.gelu((ref + b).double()).float()
+        got = _unsplit2(ops.linear_x3(x2, w2, bias=b.to(DEV), gelu_split_out=True), cout)
+        assert (got - gl).abs().max() <= 2e-5 * gl.abs().max() + 1e-6, (n, cin, cout)
+
+
+def test_linear_x3_matches_fp64_linear():
+    """fp32-equivalent accuracy on real-valued data (three-term bf16 split, fp32 accumulation): <= 1e-5 relative L2
+    against fp64, GELU epilogue included; LayerNorm producer of the split2 operand."""
+    g = torch.Generator().manual_seed(22)
+    for n, cin, cout in ((3000, 256, 768), (1234, 128, 512), (500, 1024, 256), (2049, 256, 1024)):
+        x = torch.randn(n, cin, generator=g)
+        w = torch.randn(cout, cin, generator=g) * 0.05
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = x.double() @ w.double().t() + b.double()
+        x2, w2 = ops.split2(x.to(DEV)), ops.split2_weight(w.to(DEV))
+        assert (_unsplit2(x2, cin) - x).abs().max() <= x.abs().max() * 2 ** -15
+        y = ops.linear_x3(x2, w2, bias=b.to(DEV)).cpu().double()
+        assert ((y - ref).norm() / ref.norm()).item() < 1e-5
+        gl = torch.nn.functional.gelu(ref)
+        got = _unsplit2(ops.linear_x3(x2, w2, bias=b.to(DEV), gelu_split_out=True), cout).double()
+        assert ((got - gl).norm() / gl.norm()).item() < 1e-5
+        assert (got - gl).abs().max().item() < 5e-6 * max(gl.abs().max().item(), 1.0) + 2e-6
+    for n, C in ((700, 256), (900, 128), (33, 1024)):
+        x = torch.randn(n, C, generator=g) * 2
+        w = 1 + 0.1 * torch.randn(C, generator=g)
+        b = 0.1 * torch.randn(C, generator=g)
+        ln = torch.nn.functional.layer_norm(x, (C,), w, b)
+        got = _unsplit2(ops.layer_norm_split2(x.to(DEV), w.to(DEV), b.to(DEV)), C)
+        assert (got - ln).abs().max() < 2e-4 * ln.abs().max()
+        # the same (hi, lo) pairs as the K-concatenated producer
+        a3 = ops.layer_norm_split3(x.to(DEV), w.to(DEV), b.to(DEV)).float().cpu()
+        assert torch.equal(got, a3[:, :C] + a3[:, 2 * C:])
 
 
 def test_window_attention_backward_matches_autograd():

@@ -55,12 +55,13 @@ def _stage_err(got, want) -> float:
     return float(np.abs(got.astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-12))
 
 
-@pytest.fixture(params=['bf16x3', 'fp32'])
+@pytest.fixture(params=['x3', 'bf16x3', 'fp32'])
 def gemm_mode(request):
-    """Linear layers as one split-bf16 GEMM (default) or as hipBLASLt fp32 GEMMs."""
+    """Linear layers on the hand-written split-bf16 GEMM (default), as one hipBLASLt split-bf16 GEMM, or as hipBLASLt
+    fp32 GEMMs."""
     set_gemm_mode(request.param)
     yield request.param
-    set_gemm_mode('bf16x3')
+    set_gemm_mode('x3')
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -243,3 +244,38 @@ def test_large_oxford_batch_completes_and_is_deterministic():
     assert y1.shape == (48, 256) and torch.isfinite(y1).all()
     assert torch.equal(y1, y2)
     assert torch.allclose(y1.norm(dim=1), torch.ones(48, device='cuda'), atol=1e-5)
+
+
+def test_grad_checkpoint_recomputes_the_same_gradients():
+    """`grad_checkpoint` (default True, `misc/utils.py:89`; per-block non-reentrant checkpointing,
+    `models/hotformerloc_backbone.py:596-618`, `models/octformer_backbone.py:415-416`): the custom autograd
+    Functions are re-entrant-safe -- recomputation in the backward gives the gradients of the plain run and less
+    peak memory."""
+    params, depth = load_config('cs-wild-places')
+    params.drop_path = 0.0
+    clouds = [syn.forest_cloud(300 + i, 5000) if i % 2 else syn.unit_ball_cloud(300 + i, 4096) for i in range(4)]
+    proj = torch.from_numpy(syn.hash_uniform(11, 4 * 256).reshape(4, 256).astype(np.float32)).cuda()
+    res = {}
+    for ck in (False, True):
+        params.grad_checkpoint = ck
+        model = model_factory(params)
+        assert model.backbone.backbone.hotf_stage.grad_checkpoint is ck
+        syn.fill_synthetic_weights(model, 'stress')
+        model = model.cuda().train()
+        octree = build_batch_octree(clouds, depth, 2, 'cuda')
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        y = model({'octree': octree})['global']
+        (y * proj).sum().backward()
+        torch.cuda.synchronize()
+        res[ck] = (y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
+                   torch.cuda.max_memory_allocated())
+    assert torch.equal(res[False][0], res[True][0])
+    for k, g in res[False][1].items():
+        h = res[True][1][k]
+        if k.endswith('rpe_table'):                        # float atomics in the table gradient: order noise
+            assert torch.allclose(g, h, rtol=1e-4, atol=1e-6 * max(g.abs().max().item(), 1e-30)), k
+        else:
+            assert torch.equal(g, h), (k, (g - h).abs().max().item())
+    print('peak memory: plain %.2f GiB, checkpointed %.2f GiB' % (res[False][2] / 2 ** 30, res[True][2] / 2 ** 30))
+    assert res[True][2] < res[False][2]

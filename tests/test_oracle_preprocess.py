@@ -1,7 +1,9 @@
 """Pins of the raw-cloud pre-steps against goldens produced by the reference's own
 `Normalize` / `CylindricalCoordinates` in the sequence of `eval/pnv_evaluate.py:158-171`
 (`oracle/gen_golden_coords.py`).  Bit-exact: the masks decide which points exist, the transform which octree cell
-they fall in."""
+they fall in.  Normalisation and masks are IEEE-exact everywhere; the transform's `x**2 + y**2` and `atan2` are torch CPU
+kernels whose last bit depends on the CPU (measured: 5-6 % of rho values differ by 1 ulp between the build container and
+the GPU box, for the reference's own code), so transform outputs are held to 1 ulp here."""
 
 import os
 
@@ -11,6 +13,16 @@ import torch
 from hotformerloc_amd import synthetic as syn
 from oracle import preprocess_ref
 from oracle.gen_golden_coords import CASES, raw_cloud
+
+
+ULP = 2.0 ** -24          # one ulp of a float32 in [0.5, 1)
+
+
+def _circ(a, b):
+    """|a - b| with the phi column compared on the circle (atan2(+-0, -x) = +-pi maps to +-1)."""
+    d = np.abs(a.astype(np.float64) - b)
+    d[:, 1] = np.minimum(d[:, 1], 2.0 - d[:, 1])
+    return d
 
 
 def _golden(golden_dir):
@@ -25,7 +37,10 @@ def test_oracle_presteps_match_reference_golden(golden_dir):
         out = preprocess_ref.prepare_cloud(raw, normalize, coords, stages)
         assert np.array_equal(stages['normalized'].numpy(), g[name + '_normalized']), name
         assert np.array_equal(stages['masked'].numpy(), g[name + '_masked']), name
-        assert np.array_equal(out.numpy(), g[name + '_out']), name
+        if coords == 'cylindrical':
+            assert out.shape == g[name + '_out'].shape and _circ(out.numpy(), g[name + '_out']).max() <= ULP, name
+        else:
+            assert np.array_equal(out.numpy(), g[name + '_out']), name
     # the boundary case must actually exercise both masks
     assert g['boundary_cyl_masked'].shape[0] < 2048 * 0.7
 
@@ -36,6 +51,6 @@ def test_product_cylindrical_matches_reference_transform(golden_dir):
     g = _golden(golden_dir)
     for i in range(2):
         pc = syn.unit_ball_cloud(2000 + i, 4096)
-        assert np.array_equal(syn.cylindrical(pc), g['a3_ball_%d' % i])
+        assert _circ(syn.cylindrical(pc), g['a3_ball_%d' % i]).max() <= ULP
     for name in ('wp_forest', 'boundary_cyl'):
-        assert np.array_equal(syn.cylindrical(g[name + '_masked']), g[name + '_out']), name
+        assert _circ(syn.cylindrical(g[name + '_masked']), g[name + '_out']).max() <= ULP, name
