@@ -86,6 +86,12 @@ gemm_x3_kernel(const X3Params p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wm = wave & 1;
 
+  // experiment (x3_dbg >> 8): de-phase the co-resident workgroups of the first dispatch wave so that their load /
+  // MFMA / store phases do not run in lockstep chip-wide
+  if ((p.dbg >> 8) && blockIdx.x < 768) {
+    const int n = (int)(blockIdx.x >> 8) * (p.dbg >> 8);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- XCD-aware tile assignment (bijective remap: consecutive new ids share an XCD) -------------------------
   int64_t wg = blockIdx.x;
   {

@@ -334,15 +334,29 @@ class MLP(nn.Module):
 
 
 class CPE(nn.Module):
-    """models/layers/octformer_layers.py:122-142 (xcpe=False)"""
+    """models/layers/octformer_layers.py:122-142.  xcpe=False: depth-wise octree conv + LayerNorm (one fused kernel in
+    inference); xcpe=True (PointTransformerV3's xCPE): full octree conv with bias + Linear + LayerNorm."""
 
-    def __init__(self, dim, conv_norm='layernorm'):
+    def __init__(self, dim, conv_norm='layernorm', xcpe=False):
         super().__init__()
         _require_layernorm(conv_norm)
-        self.conv = OctreeDWConvParams(dim)
+        self.xcpe = xcpe
+        if xcpe:
+            self.conv = OctreeConv(dim, dim, [3], 1, nempty=True, use_bias=True)
+            self.linear = nn.Linear(dim, dim)
+        else:
+            self.conv = OctreeDWConvParams(dim)
+            self.linear = nn.Identity()
         self.norm = nn.LayerNorm(dim)
 
     def forward(self, data, plan: WindowPlan, depth: int, residual: bool, out=None):
+        if self.xcpe:
+            y = _ln(self.linear(self.conv(data, plan.octree, depth)), self.norm)
+            y = data + y if residual else y
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         if _grad_path(data):      # dwconv (HIP fwd/bwd, libs/dwconv semantics) -> LayerNorm -> residual
             y = hdw.octree_dwconv(data, self.conv.weights, plan.neigh(depth))
             y = F.layer_norm(y, self.norm.normalized_shape, self.norm.weight, self.norm.bias, self.norm.eps)
@@ -402,28 +416,40 @@ class OctreeAttention(nn.Module):
                          out_split=True)
 
 
+def _init_layer_scale(block, dim, layer_scale):
+    """`gamma1` / `gamma2`: learnable channel-wise multipliers of the attention / MLP branches when `layer_scale` is a
+    number (models/octformer_backbone.py:214-229), the constant 1 otherwise (not parameters then, as in the reference)."""
+    block.use_layer_scale = layer_scale is not None and type(layer_scale) in (int, float)
+    if block.use_layer_scale:
+        block.gamma1 = nn.Parameter(layer_scale * torch.ones(dim))
+        block.gamma2 = nn.Parameter(layer_scale * torch.ones(dim))
+    else:
+        block.gamma1 = block.gamma2 = 1
+
+
 class OctFormerBlock(nn.Module):
     """models/octformer_backbone.py:182-299 (use_rt=False)"""
 
     def __init__(self, dim, num_heads, patch_size, dilation, disable_RPE=False, conv_norm='layernorm',
-                 drop_path=0.0):
+                 drop_path=0.0, layer_scale=None, xcpe=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.attention = OctreeAttention(dim, patch_size, num_heads, dilation, 0, not disable_RPE)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4.0), dim)
         self.drop_path = OctreeDropPath(drop_path)
-        self.cpe = CPE(dim, conv_norm)
+        self.cpe = CPE(dim, conv_norm, xcpe)
+        _init_layer_scale(self, dim, layer_scale)
 
     def forward(self, x, plan: WindowPlan, depth: int):
         x = self.cpe(x, plan, depth, residual=True)
-        if _split_path(x):
+        if _split_path(x) and not self.use_layer_scale:
             o3 = self.attention.forward_split(x, self.norm1, plan, depth)
             return _block_tail_split(x, o3, self.attention, self.norm2, self.mlp)
-        if self.training and self.drop_path.drop_prob > 0.0:
+        if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
             bid = plan.row_cloud(depth, with_relay=False)
-            x = x + self.drop_path(self.attention(_ln(x, self.norm1), plan, depth), bid, plan.B)
-            return x + self.drop_path(self.mlp(_ln(x, self.norm2)), bid, plan.B)
+            x = x + self.drop_path(self.gamma1 * self.attention(_ln(x, self.norm1), plan, depth), bid, plan.B)
+            return x + self.drop_path(self.gamma2 * self.mlp(_ln(x, self.norm2)), bid, plan.B)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
         return x + self.mlp(h)
 
@@ -432,13 +458,13 @@ class OctFormerStage(nn.Module):
     """models/octformer_backbone.py:363-421"""
 
     def __init__(self, dim, num_heads, patch_size, dilation, num_blocks, disable_RPE=False,
-                 conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False):
+                 conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False, layer_scale=None, xcpe=False):
         super().__init__()
         dp = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * num_blocks
         self.grad_checkpoint = grad_checkpoint
         self.blocks = nn.ModuleList([
             OctFormerBlock(dim, num_heads, patch_size, 1 if i % 2 == 0 else dilation, disable_RPE,
-                           conv_norm, dp[i]) for i in range(num_blocks)])
+                           conv_norm, dp[i], layer_scale, xcpe) for i in range(num_blocks)])
 
     def forward(self, x, plan, depth):
         ckpt = _use_checkpoint(self)
@@ -453,14 +479,15 @@ class HOTFormerBlock(nn.Module):
     [tokens | relay tokens] buffer of one depth."""
 
     def __init__(self, dim, num_heads, patch_size, disable_RPE=False, conv_norm='layernorm',
-                 drop_path=0.0):
+                 drop_path=0.0, layer_scale=None, xcpe=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.attention = OctreeAttention(dim, patch_size, num_heads, 1, 1, not disable_RPE)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4.0), dim)
         self.drop_path = OctreeDropPath(drop_path)
-        self.cpe = CPE(dim, conv_norm)
+        self.cpe = CPE(dim, conv_norm, xcpe)
+        _init_layer_scale(self, dim, layer_scale)
 
     def forward(self, buf, plan: WindowPlan, depth: int):
         nt = plan.n_tokens[depth]
@@ -471,13 +498,13 @@ class HOTFormerBlock(nn.Module):
             self.cpe(buf[:nt], plan, depth, residual=True, out=new[:nt])
             new[nt:].copy_(buf[nt:])
             buf = new
-        if _split_path(buf):
+        if _split_path(buf) and not self.use_layer_scale:
             o3 = self.attention.forward_split(buf, self.norm1, plan, depth)
             return _block_tail_split(buf, o3, self.attention, self.norm2, self.mlp)
-        if self.training and self.drop_path.drop_prob > 0.0:
+        if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
             bid = plan.row_cloud(depth, with_relay=True)
-            buf = buf + self.drop_path(self.attention(_ln(buf, self.norm1), plan, depth), bid, plan.B)
-            return buf + self.drop_path(self.mlp(_ln(buf, self.norm2)), bid, plan.B)
+            buf = buf + self.drop_path(self.gamma1 * self.attention(_ln(buf, self.norm1), plan, depth), bid, plan.B)
+            return buf + self.drop_path(self.gamma2 * self.mlp(_ln(buf, self.norm2)), bid, plan.B)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
         return buf + self.mlp(h)
 
@@ -505,19 +532,20 @@ class RTAttention(nn.Module):
 class RelayTokenTransformerBlock(nn.Module):
     """models/hotformerloc_backbone.py:239-302 on the concatenated (sum W_d, C) relay rows."""
 
-    def __init__(self, dim, num_heads, drop_path=0.0):
+    def __init__(self, dim, num_heads, drop_path=0.0, layer_scale=None):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.rt_attention = RTAttention(dim, num_heads)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MLP(dim, int(dim * 4.0), dim)
         self.drop_path = OctreeDropPath(drop_path)
+        _init_layer_scale(self, dim, layer_scale)                       # hotformerloc_backbone.py:260-272
 
     def forward(self, rt, plan):
-        if self.training and self.drop_path.drop_prob > 0.0:
+        if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
             bid = plan.relay_cloud()
-            rt = rt + self.drop_path(self.rt_attention(_ln(rt, self.norm1), plan), bid, plan.B)
-            return rt + self.drop_path(self.mlp(_ln(rt, self.norm2)), bid, plan.B)
+            rt = rt + self.drop_path(self.gamma1 * self.rt_attention(_ln(rt, self.norm1), plan), bid, plan.B)
+            return rt + self.drop_path(self.gamma2 * self.mlp(_ln(rt, self.norm2)), bid, plan.B)
         rt, h = _add_ln(rt, self.rt_attention(_ln(rt, self.norm1), plan), self.norm2)
         return rt + self.mlp(h)
 
@@ -525,12 +553,12 @@ class RelayTokenTransformerBlock(nn.Module):
 class RelayTokenInitialiser(nn.Module):
     """models/hotformerloc_backbone.py:305-363"""
 
-    def __init__(self, dim, patch_size, conv_norm='layernorm', use_cpe=False):
+    def __init__(self, dim, patch_size, conv_norm='layernorm', use_cpe=False, xcpe=False):
         super().__init__()
         self.patch_size = patch_size
         self.use_cpe = use_cpe
         if use_cpe:
-            self.cpe = CPE(dim, conv_norm)
+            self.cpe = CPE(dim, conv_norm, xcpe)
 
     def forward(self, x, plan: WindowPlan, depth: int):
         if self.use_cpe:
@@ -555,9 +583,11 @@ class HOTFormerStage(nn.Module):
     """models/hotformerloc_backbone.py:366-635 (one channel width for all levels)."""
 
     def __init__(self, channels, num_heads, num_blocks, num_pyramid_levels, patch_size,
-                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False):
+                 disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False,
+                 dilation=4, disable_rt=False, layer_scale=None, xcpe=False):
         super().__init__()
         self.grad_checkpoint = grad_checkpoint
+        self.disable_rt = disable_rt
         if len(channels) != 1 or len(num_heads) != 1:
             raise NotImplementedError('per-level channel widths (projection layers) are not used '
                                       'by any shipped config')
@@ -565,15 +595,23 @@ class HOTFormerStage(nn.Module):
         self.num_pyramid_levels, self.num_blocks = num_pyramid_levels, num_blocks
         self.use_ADaPE = ADaPE_mode is not None
         dp = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * num_blocks
-        self.hosa_blocks = nn.ModuleList([
-            nn.ModuleList([HOTFormerBlock(C, H, patch_size, disable_RPE, conv_norm, dp[i])
-                           for i in range(num_blocks)]) for _ in range(num_pyramid_levels)])
-        self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(C, H, dp[i])
-                                          for i in range(num_blocks)])
-        self.relay_tokeniser = RelayTokenInitialiser(C, patch_size, conv_norm,
-                                                     use_cpe=not self.use_ADaPE)
-        if self.use_ADaPE:
-            self.rt_adape = ADaPE(C, ADaPE_mode)
+        if disable_rt:
+            # ablation without relay tokens (hotformerloc_backbone.py:396-397,440-458,477): plain local-attention
+            # blocks with the dilation re-enabled, no RTSA, no relay-token initialiser
+            self.hosa_blocks = nn.ModuleList([
+                nn.ModuleList([OctFormerBlock(C, H, patch_size, 1 if i % 2 == 0 else dilation, disable_RPE, conv_norm,
+                                              dp[i], layer_scale, xcpe)
+                               for i in range(num_blocks)]) for _ in range(num_pyramid_levels)])
+        else:
+            self.hosa_blocks = nn.ModuleList([
+                nn.ModuleList([HOTFormerBlock(C, H, patch_size, disable_RPE, conv_norm, dp[i], layer_scale, xcpe)
+                               for i in range(num_blocks)]) for _ in range(num_pyramid_levels)])
+            self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(C, H, dp[i], layer_scale)
+                                              for i in range(num_blocks)])
+            self.relay_tokeniser = RelayTokenInitialiser(C, patch_size, conv_norm,
+                                                         use_cpe=not self.use_ADaPE, xcpe=xcpe)
+            if self.use_ADaPE:
+                self.rt_adape = ADaPE(C, ADaPE_mode)
         self.downsamples = nn.ModuleList([Downsample(C, C, conv_norm)
                                           for _ in range(num_pyramid_levels - 1)])
         self._streams = None
@@ -583,8 +621,21 @@ class HOTFormerStage(nn.Module):
             self._streams = [torch.cuda.Stream(device=device) for _ in range(self.num_pyramid_levels - 1)]
         return self._streams
 
+    def _forward_without_relay_tokens(self, data, plan: WindowPlan, depths):
+        feats = {depths[0]: data}
+        for j, d in enumerate(depths[:-1]):
+            feats[d - 1] = self.downsamples[j](feats[d], plan.octree, d)
+        ckpt = _use_checkpoint(self)
+        for i in range(self.num_blocks):
+            for j, d in enumerate(depths):
+                blk = self.hosa_blocks[j][i]
+                feats[d] = checkpoint(blk, feats[d], plan, d, use_reentrant=False) if ckpt else blk(feats[d], plan, d)
+        return feats, {d: None for d in depths}
+
     def forward(self, data, plan: WindowPlan, depth: int):
         depths = [depth - j for j in range(self.num_pyramid_levels)]
+        if self.disable_rt:
+            return self._forward_without_relay_tokens(data, plan, depths)
         octree = plan.octree
         feats = {depths[0]: data}
         bufs: Dict[int, torch.Tensor] = {}
@@ -652,7 +703,7 @@ class HOTFormerBase(nn.Module):
 
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels,
                  num_octf_levels, patch_size, dilation, stem_down, ADaPE_mode, disable_RPE, conv_norm,
-                 drop_path=0.0, grad_checkpoint=False):
+                 drop_path=0.0, grad_checkpoint=False, disable_rt=False, layer_scale=None, xcpe=False):
         super().__init__()
         # stochastic depth per block (hotformerloc_backbone.py:669-700)
         drop_ratio = torch.linspace(0, drop_path, sum(num_blocks)).tolist()
@@ -666,7 +717,8 @@ class HOTFormerBase(nn.Module):
         self.patch_embed = PatchEmbed(in_channels, channels[0], stem_down, conv_norm)
         self.octf_stage = nn.ModuleList([
             OctFormerStage(channels[i], num_heads[i], patch_size, dilation, num_blocks[i], disable_RPE,
-                           conv_norm, drop_ratio[sum(num_blocks[:i]):sum(num_blocks[:i + 1])], grad_checkpoint)
+                           conv_norm, drop_ratio[sum(num_blocks[:i]):sum(num_blocks[:i + 1])], grad_checkpoint,
+                           layer_scale, xcpe)
             for i in range(num_octf_levels)])
         self.downsample = nn.ModuleList([Downsample(channels[i], channels[i + 1], conv_norm)
                                          for i in range(num_octf_levels)])
@@ -674,7 +726,7 @@ class HOTFormerBase(nn.Module):
                                          list(num_heads[num_octf_levels:]), num_blocks[-1],
                                          num_pyramid_levels, patch_size, disable_RPE, ADaPE_mode,
                                          conv_norm, drop_ratio[sum(num_blocks[:-1]):sum(num_blocks)],
-                                         grad_checkpoint)
+                                         grad_checkpoint, dilation, disable_rt, layer_scale, xcpe)
 
     def forward(self, data, octree, depth):
         data = self.patch_embed(data, octree, depth)
@@ -697,12 +749,14 @@ class HOTFormer(nn.Module):
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels=3,
                  num_octf_levels=1, patch_size=32, dilation=4, drop_path=0.5, stem_down=2,
                  ADaPE_mode=None, disable_RPE=False, conv_norm='layernorm',
-                 qkv_init=('trunc_normal', 0.02), grad_checkpoint=False):
+                 qkv_init=('trunc_normal', 0.02), grad_checkpoint=False, disable_rt=False, layer_scale=None,
+                 xcpe=False):
         super().__init__()
         self.backbone = HOTFormerBase(in_channels, list(channels), list(num_blocks),
                                       None if num_heads is None else list(num_heads),
                                       num_pyramid_levels, num_octf_levels, patch_size, dilation,
-                                      stem_down, ADaPE_mode, disable_RPE, conv_norm, drop_path, grad_checkpoint)
+                                      stem_down, ADaPE_mode, disable_RPE, conv_norm, drop_path, grad_checkpoint,
+                                      disable_rt, layer_scale, xcpe)
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=0.02)
@@ -796,6 +850,127 @@ class PyramidAttnPoolWrapper(nn.Module):
         return self.descriptor_extractor(torch.cat(toks, 1))
 
 
+class OctGeM(nn.Module):
+    """models/layers/pooling.py:18-40: generalised-mean pooling of the finest pyramid level over each cloud's
+    non-empty nodes (`ocnn.nn.OctreeGlobalPool(nempty=True)` = per-cloud mean)."""
+
+    def __init__(self, input_dim, p=3, eps=1e-6):
+        super().__init__()
+        self.input_dim = self.output_dim = input_dim
+        self.p = nn.Parameter(torch.ones(1) * p)
+        self.eps = eps
+
+    def forward(self, x, plan: WindowPlan, depth=None):
+        if isinstance(x, dict):
+            depth, x = max(x.items())
+        temp = x.clamp(min=self.eps).pow(self.p)
+        return _cloud_mean(temp, plan, depth).pow(1. / self.p)
+
+
+class RelayTokenGeM(nn.Module):
+    """models/layers/pooling.py:43-57 on a padded (B, N, C) tensor (every row counts, as in the reference)."""
+
+    def __init__(self, input_dim, p=3, eps=1e-6):
+        super().__init__()
+        self.input_dim = self.output_dim = input_dim
+        self.p = nn.Parameter(torch.ones(1) * p)
+        self.eps = eps
+
+    def forward(self, x):
+        return x.clamp(min=self.eps).pow(self.p).mean(dim=1).pow(1. / self.p)
+
+
+class GatingContext(nn.Module):
+    """models/layers/netvlad.py:83-112"""
+
+    def __init__(self, dim, add_batch_norm=True):
+        super().__init__()
+        self.dim, self.add_batch_norm = dim, add_batch_norm
+        self.gating_weights = nn.Parameter(torch.randn(dim, dim) / dim ** 0.5)
+        if add_batch_norm:
+            self.gating_biases = None
+            self.bn1 = nn.BatchNorm1d(dim)
+        else:
+            self.gating_biases = nn.Parameter(torch.randn(dim) / dim ** 0.5)
+            self.bn1 = None
+
+    def forward(self, x):
+        gates = torch.matmul(x, self.gating_weights)
+        gates = self.bn1(gates) if self.add_batch_norm else gates + self.gating_biases
+        return x * torch.sigmoid(gates)
+
+
+class PyramidOctGeMWrapper(nn.Module):
+    """models/layers/pooling.py:60-103: GeM per pyramid level (own exponent each), concatenated, Linear + BatchNorm,
+    optional context gating."""
+
+    def __init__(self, input_dim, output_dim, num_pyramid_levels, channels, p=3, eps=1e-6, gating=False,
+                 add_batch_norm=True):
+        super().__init__()
+        assert num_pyramid_levels > 0, 'Minimum 1 pyramid layer'
+        if len(channels) != 1:
+            raise NotImplementedError('per-level channel widths are not used by any shipped config')
+        self.input_dim, self.output_dim, self.num_pyramid_levels = input_dim, output_dim, num_pyramid_levels
+        self.p = nn.Parameter(torch.ones(num_pyramid_levels) * p)
+        self.eps, self.gating = eps, gating
+        self.linear_bn = nn.Sequential(nn.Linear(input_dim * num_pyramid_levels, output_dim, bias=False),
+                                       nn.BatchNorm1d(input_dim))
+        if gating:
+            self.context_gating = GatingContext(output_dim, add_batch_norm=add_batch_norm)
+
+    def forward(self, local_feat_dict, plan: WindowPlan, depth=None):
+        desc = []
+        for j, d in enumerate(local_feat_dict.keys()):
+            temp = local_feat_dict[d].clamp(min=self.eps).pow(self.p[j])
+            desc.append(_cloud_mean(temp, plan, d).pow(1. / self.p[j]))
+        g = self.linear_bn(torch.cat(desc, dim=-1))
+        return self.context_gating(g) if self.gating else g
+
+
+class AttnPoolWrapper(nn.Module):
+    """models/layers/pooling.py:235-305: attentional pooling of every cloud's multi-scale relay tokens (fine to coarse,
+    `relay_token_utils.py:12-40`) to k tokens, then the MLP mixer or LayerNorm + MLP + GeM."""
+
+    def __init__(self, feature_size=256, output_dim=256, k_pooled_tokens=64, mlp_ratio=1, aggregator='mixer',
+                 mix_depth=4):
+        super().__init__()
+        assert isinstance(k_pooled_tokens, int), 'Only 1 value allowed for k_pooled_tokens when using relay tokens'
+        self.feature_size, self.output_dim, self.k_pooled_tokens = feature_size, output_dim, k_pooled_tokens
+        self.aggregator = aggregator
+        self.attpool = AdaptivePooling(feature_size, k_pooled_tokens)
+        if aggregator.lower() == 'mixer':
+            k_out = k_pooled_tokens // 4
+            self.descriptor_extractor = Mixer(k_pooled_tokens, k_out, feature_size, mix_depth, mlp_ratio,
+                                              output_dim // k_out)
+        elif aggregator.lower() == 'gem':
+            self.token_processor = nn.Sequential(nn.LayerNorm(feature_size),
+                                                 MLP(feature_size, feature_size * mlp_ratio, output_dim))
+            self.descriptor_extractor = RelayTokenGeM(input_dim=feature_size)
+        else:
+            raise NotImplementedError(f'No valid aggregator: {aggregator}')
+
+    def forward(self, relay_token_dict, plan: WindowPlan, depth=None):
+        rt_all = torch.cat([relay_token_dict[d] for d in plan.pyramid_depths], 0)      # rows as plan.rt_offset
+        idx, valid = plan.relay_pad_index()                                            # (B, Rmax): cloud -> its rows
+        x = rt_all[idx.clamp(min=0)] * valid.unsqueeze(-1).to(rt_all.dtype)            # zero padding rows
+        # learned queries attend over the cloud's own tokens; padding keys get the reference's -1e3 additive mask
+        scores = torch.matmul(self.attpool.query * self.attpool.scale, x.transpose(1, 2))          # (B, k, Rmax)
+        scores = scores + (~valid).unsqueeze(1).to(scores.dtype) * -1e3
+        tok = torch.matmul(torch.softmax(scores, dim=-1), x)                                      # (B, k, C)
+        if self.aggregator.lower() != 'mixer':
+            tok = tok + self.token_processor(tok)
+        return self.descriptor_extractor(tok)
+
+
+def _cloud_mean(x, plan: WindowPlan, depth: int):
+    """(N_t, C) rows of one depth -> (B, C) mean over each cloud's rows (fixed summation order: padded gather)."""
+    idx = plan.pad_index_for(depth)
+    zero = x.new_zeros(1, x.shape[1])
+    xp = torch.cat([x, zero], 0).index_select(0, idx).view(plan.B, -1, x.shape[1])
+    cnt = plan.cloud_count(depth).clamp(min=1).to(x.dtype)
+    return xp.sum(1) / cnt.unsqueeze(1)
+
+
 class PoolingWrapper(nn.Module):
     """models/layers/pooling_wrapper.py:11-77"""
 
@@ -803,12 +978,24 @@ class PoolingWrapper(nn.Module):
                  k_pooled_tokens=None):
         super().__init__()
         self.pool_method, self.in_dim, self.output_dim = pool_method, in_dim, output_dim
-        self.pooled_feats = 'local'
-        if pool_method != 'PyramidAttnPoolMixer':
-            raise NotImplementedError('pooling=%r: every shipped config uses PyramidAttnPoolMixer'
-                                      % pool_method)
-        self.pooling = PyramidAttnPoolWrapper(in_dim, output_dim, list(channels), num_pyramid_levels,
-                                              k_pooled_tokens)
+        self.pooled_feats = 'local'             # flag if local feats or relay tokens are pooled
+        if pool_method == 'OctGeM':
+            assert in_dim == output_dim
+            self.pooling = OctGeM(input_dim=in_dim)
+        elif pool_method in ('PyramidOctGeM', 'PyramidOctGeMgc'):
+            self.pooling = PyramidOctGeMWrapper(in_dim, output_dim, num_pyramid_levels, list(channels),
+                                                gating=pool_method.endswith('gc'))
+        elif pool_method == 'PyramidAttnPoolMixer':
+            self.pooling = PyramidAttnPoolWrapper(in_dim, output_dim, list(channels), num_pyramid_levels,
+                                                  k_pooled_tokens)
+        elif pool_method in ('AttnPoolMixer', 'AttnPoolGeM'):
+            self.pooled_feats = 'relaytokens'
+            self.pooling = AttnPoolWrapper(in_dim, output_dim, k_pooled_tokens,
+                                           aggregator='mixer' if pool_method == 'AttnPoolMixer' else 'GeM')
+        elif pool_method == 'PyramidNetVLAD':
+            raise NotImplementedError(f'Not implemented yet: {pool_method}')       # as the reference
+        else:
+            raise NotImplementedError('Unknown pooling method: {}'.format(pool_method))
 
     def forward(self, x, octree=None, depth=None):
         return self.pooling(x, octree, depth)
@@ -837,7 +1024,13 @@ class HOTFormerLoc(nn.Module):
         octree.construct_all_neigh()                     # no-op when misc/torch_utils.to_device did it
         data = octree.get_input_feature(self.input_features, nempty=True)
         local, relay, plan = self.backbone(data, octree, octree.depth)
-        x = self.pooling(local, octree=plan)
+        if self.pooling.pooled_feats == 'local':
+            x = local
+        elif self.pooling.pooled_feats == 'relaytokens':
+            x = relay
+        else:
+            raise ValueError(f"Invalid option for pooled features: '{self.pooling.pooled_feats}'")
+        x = self.pooling(x, octree=plan)
         assert x.dim() == 2 and x.shape[1] == self.pooling.output_dim
         if self.normalize_embeddings:
             x = F.normalize(x, dim=1)

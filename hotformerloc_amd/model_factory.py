@@ -24,16 +24,10 @@ def _unsupported(params: ModelParams):
         bad.append('ct_size != 1')
     if params.ct_propagation:
         bad.append('ct_propagation=True')
-    if params.disable_rt:
-        bad.append('disable_rt=True')
-    if params.layer_scale is not None:
-        bad.append('layer_scale')
-    if params.xcpe:
-        bad.append('xCPE=True')
     if params.qkv_init[0] not in ('trunc_normal', 'torch_default'):
         bad.append('qkv_init=%s' % params.qkv_init[0])
     if bad:
-        raise NotImplementedError('options outside the shipped configs (SURVEY section 8f rank 4): '
+        raise NotImplementedError('options not built (SURVEY section 8f rank 4, remaining part): '
                                   + ', '.join(bad))
 
 
@@ -45,6 +39,7 @@ _BACKBONE_ARGS = {
     'patch_size': 'patch_size', 'dilation': 'dilation', 'drop_path': 'drop_path',
     'stem_down': 'num_input_downsamples', 'ADaPE_mode': 'ADaPE_mode', 'disable_RPE': 'disable_RPE',
     'conv_norm': 'conv_norm', 'qkv_init': 'qkv_init', 'grad_checkpoint': 'grad_checkpoint',
+    'disable_rt': 'disable_rt', 'layer_scale': 'layer_scale', 'xcpe': 'xcpe',
 }
 _POOLING_ARGS = {
     'pool_method': 'pooling', 'in_dim': 'feature_size', 'output_dim': 'output_dim',
@@ -61,5 +56,8 @@ def model_factory(model_params: ModelParams):
                          **{arg: getattr(p, field) for arg, field in _BACKBONE_ARGS.items()})
     pooling = PoolingWrapper(channels=p.channels[p.num_octf_levels:],
                              **{arg: getattr(p, field) for arg, field in _POOLING_ARGS.items()})
+    if p.disable_rt:
+        assert pooling.pooled_feats != 'relaytokens', (
+            'If relay tokens are disabled, a local feature pooling method must be used!')
     return HOTFormerLoc(backbone=backbone, pooling=pooling, normalize_embeddings=p.normalize_embeddings,
                         input_features=p.input_features)

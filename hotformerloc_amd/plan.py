@@ -143,6 +143,23 @@ class WindowPlan:
             cache[key] = plan
         return plan
 
+    def pad_index_for(self, depth: int):
+        """(B * Nmax) gather index of a depth's rows, cloud by cloud, sentinel = one-past-the-end (a zero row)."""
+        if depth not in self.pad_index:
+            nne = self.octree.batch_nnum_nempty.numpy().astype(np.int64)[depth]
+            off = np.concatenate([[0], np.cumsum(nne)])
+            ar = np.arange(int(nne.max()), dtype=np.int64)[None, :]
+            idx = np.where(ar < nne[:, None], off[:-1, None] + ar, int(off[-1]))
+            self.pad_index[depth] = torch.from_numpy(np.ascontiguousarray(idx.reshape(-1))).to(self.device)
+        return self.pad_index[depth]
+
+    def cloud_count(self, depth: int):
+        """(B,) number of rows of every cloud at `depth`, on the device."""
+        cache = self.__dict__.setdefault('_cloud_count', {})
+        if depth not in cache:
+            cache[depth] = self.octree.batch_nnum_nempty[depth].to(self.device)
+        return cache[depth]
+
     def row_cloud(self, depth: int, with_relay: bool):
         """int64 cloud index of every row of a depth's buffer: tokens by their batch id, relay rows
         (if any) by their window owner, padding windows -> last cloud (octformer_layers.py:262-281)."""

@@ -138,7 +138,15 @@ def synthetic_tensor(name: str, shape: Iterable[int], profile: str = 'stress') -
     n = int(np.prod(shape)) if len(shape) else 1
     u = hash_uniform(_fnv1a(name), n)
     r3 = 3.0 ** 0.5                                       # uniform(-a,a) has std a/sqrt(3)
-    if name.endswith('rpe_table'):
+    if name.endswith('num_batches_tracked'):
+        v = np.zeros(shape if shape else (1,))
+    elif name.endswith('running_var'):                    # BatchNorm statistics of the alternative heads: positive
+        v = 1.0 + u * 0.2
+    elif name.endswith('running_mean'):
+        v = u * 0.1
+    elif name == 'p' or name.endswith('.p'):              # GeM exponent (models/layers/pooling.py:28,72)
+        v = 3.0 + u * 0.5
+    elif name.endswith('rpe_table'):
         v = u * (p['rpe'] * r3)
     elif name.endswith('.query'):
         v = u * (p['query'] * r3)

@@ -524,7 +524,8 @@ def test_linear_x3_matches_fp64_linear():
         gl = torch.nn.functional.gelu(ref)
         got = _unsplit2(ops.linear_x3(x2, w2, bias=b.to(DEV), gelu_split_out=True), cout).double()
         assert ((got - gl).norm() / gl.norm()).item() < 1e-5
-        assert (got - gl).abs().max().item() < 5e-6 * max(gl.abs().max().item(), 1.0) + 2e-6
+        # the split2 output itself is a (hi, lo) bf16 pair: representable to 2^-16 of the value
+        assert (got - gl).abs().max().item() < 2 ** -15 * max(gl.abs().max().item(), 1.0) + 2e-6
     for n, C in ((700, 256), (900, 128), (33, 1024)):
         x = torch.randn(n, C, generator=g) * 2
         w = 1 + 0.1 * torch.randn(C, generator=g)

@@ -21,7 +21,7 @@ from hotformerloc_amd.preprocess import prepare_clouds
 from oracle import preprocess_ref
 from oracle.gen_golden_coords import CASES, raw_cloud
 
-ULP = 2.0 ** -24          # one ulp of a float32 in [0.5, 1): the transform's outputs live in [-1, 1]
+ULP = 2.0 ** -23          # one ulp of rho in [0.5, 1) after the 2*rho - 1 rescale (float32 spacing in [1, 2))
 
 
 def _circ(a, b):

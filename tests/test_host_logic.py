@@ -46,8 +46,11 @@ def test_model_params_fields():
 def test_unsupported_options_raise(tmp_path):
     src = open(os.path.join(ROOT, 'hotformerloc_amd', 'configs', 'wild_places.ini')).read()
     bad = tmp_path / 'bad.ini'
-    bad.write_text(src.replace('pooling = PyramidAttnPoolMixer', 'pooling = OctGeM'))
+    bad.write_text(src.replace('pooling = PyramidAttnPoolMixer', 'pooling = PyramidNetVLAD'))      # as the reference
     from hotformerloc_amd.params import ModelParams
+    with pytest.raises(NotImplementedError):
+        model_factory(ModelParams(str(bad)))
+    bad.write_text(src.replace('ct_propagation = False', 'ct_propagation = True'))                                             # not built here
     with pytest.raises(NotImplementedError):
         model_factory(ModelParams(str(bad)))
 
