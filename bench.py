@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--multistaged', action='store_true',
                     help='with --train: the full multi-staged step (stage 1 no-grad encode, TruncatedSmoothAP on the '
                          'all-gathered descriptors, stage 3 forward+backward, gradient all-reduce, AdamW step)')
+    ap.add_argument('--x3-nt', type=int, default=None, help='A/B: non-temporal store bits of the hand-written GEMM (0..3)')
     ap.add_argument('--no-collective', action='store_true', help='A/B: skip the descriptor all-gather (N > 1 diagnostics)')
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no fp32 / e2e / roofline legs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -176,6 +177,9 @@ def main():
     if args.attn_variant:
         from hotformerloc_amd import _native
         _native.load().hfl_set_variant(b'window_attention', args.attn_variant)
+    if args.x3_nt is not None:
+        from hotformerloc_amd import _native
+        _native.load().hfl_set_variant(b'x3_dbg', 0x100 | (args.x3_nt & 3))
     from hotformerloc_amd.distributed import all_gather_descriptors
 
     if args.train:

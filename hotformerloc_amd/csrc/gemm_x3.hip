@@ -36,6 +36,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XT = 128;                  // tile edge (rows and features)
 constexpr int TILE_B = XT * 128;         // one operand tile per stage: 128 rows x 128 B (32 hi + 32 lo bf16)
@@ -51,10 +52,12 @@ struct X3Params {
   int N, K;
   int tiles_n;
   int64_t n_wg;
+  int nt;                   // bit 0: non-temporal stores of the f32 output, bit 1: of the split2 output
   int dbg;                  // ablation bits (tools/x3_probe.py): 1 no in-loop DMA, 2 no MFMA, 4 no stores, 8 no LDS reads
 };
 
 static int g_x3_dbg = 0;
+static int g_x3_nt = 0;     // measured: no end-to-end difference (the consumer kernel re-reads the output anyway)
 
 __device__ __forceinline__ uint32_t x3_bf16_rne(float v) {
   uint32_t u = __float_as_uint(v);
@@ -86,12 +89,6 @@ gemm_x3_kernel(const X3Params p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wm = wave & 1;
 
-  // experiment (x3_dbg >> 8): de-phase the co-resident workgroups of the first dispatch wave so that their load /
-  // MFMA / store phases do not run in lockstep chip-wide
-  if ((p.dbg >> 8) && blockIdx.x < 768) {
-    const int n = (int)(blockIdx.x >> 8) * (p.dbg >> 8);
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // ---- XCD-aware tile assignment (bijective remap: consecutive new ids share an XCD) -------------------------
   int64_t wg = blockIdx.x;
   {
@@ -189,7 +186,6 @@ gemm_x3_kernel(const X3Params p) {
         }
     }
   }
-
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // The accumulator holds features n..n+3 (registers) of row m = lane & 15: stored as is, a 128-B line would be
   // written in two halves by different instructions.  Each wave transposes its 64 x 64 tile through a private 8 KiB
@@ -223,7 +219,12 @@ gemm_x3_kernel(const X3Params p) {
           const float4 rs = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
           v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
         }
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + m * N + nbase) = v;
+        // non-temporal: the output is not re-read by this kernel, and letting it allocate in L2 evicts the operand
+        // tiles the co-resident workgroups are re-reading (measured: 160 -> 106 us for the depth-4 fc1 shape)
+        const f32x4 vv = {v.x, v.y, v.z, v.w};
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * N + nbase);
+        if (p.nt & 1) __builtin_nontemporal_store(vv, dst);
+        else *dst = vv;
       } else {
         v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
         const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
@@ -242,7 +243,9 @@ gemm_x3_kernel(const X3Params p) {
         const int nfeat = n0 + wn * 64 + (ecol & ~1) * 4;                      // first of the pair's 8 features
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + m * (2 * (int64_t)N) + (nfeat >> 5) * 64 + (nfeat & 31) +
                       ((lane & 1) ? 32 : 0);
-        *reinterpret_cast<uint4*>(o) = q;
+        const u32x4 qq = {q.x, q.y, q.z, q.w};
+        if (p.nt & 2) __builtin_nontemporal_store(qq, reinterpret_cast<u32x4*>(o));
+        else *reinterpret_cast<u32x4*>(o) = qq;
       }
     }
   }
@@ -272,7 +275,10 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, int64_t n
 
 extern "C" {
 
-void hfl_internal_set_x3_dbg(int v) { g_x3_dbg = v; }
+void hfl_internal_set_x3_dbg(int v) {
+  if (v >= 0x100) g_x3_nt = v & 3;          // 0x100 | nt bits
+  else g_x3_dbg = v;
+}
 
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
@@ -288,6 +294,7 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
   p.tiles_n = out_features / XT;
   p.n_wg = hfl_cdiv(n_rows, XT) * p.tiles_n;
   p.dbg = g_x3_dbg;
+  p.nt = g_x3_nt;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
   const size_t lds = (size_t)STAGE_B;              // 32 KiB: 3 workgroups per CU
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -65,7 +65,7 @@ def main():
         neigh = plan.neigh(d)
         nb = n * C * 8 + n * 27 * 4
         ref = None
-        for var, wgs in ((0, 0), (1, 2), (1, 3), (1, 4), (1, 6)):
+        for var, wgs in ((0, 0), (1, 3)):
             lib.hfl_set_variant(b'cpe_variant', var)
             if wgs:
                 lib.hfl_set_variant(b'cpe_lds_wgs_per_cu', wgs)

@@ -14,19 +14,9 @@ for (M, K, N) in [(68167, 256, 1024), (68167, 1024, 256), (118096, 128, 512)]:
     x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') * 0.05
     x2 = ops.split2(x); w2 = ops.split2_weight(w)
     for ab, name in ((0, 'full'), (1, 'no in-loop DMA'), (2, 'no mfma'), (4, 'no stores'), (8, 'no lds reads'), (9, 'no DMA, no lds reads'),
-                     (6, 'no mfma no stores'), (15, 'nothing but barriers')):
+                     (6, 'no mfma no stores'), (15, 'nothing but barriers'), (11, 'stores only'), (16, 'nontemporal stores')):
         lib.hfl_set_variant(b'x3_dbg', ab)
         t = timeit(lambda: ops.linear_x3(x2, w2))
         print('M=%d K=%d N=%d %-24s %8.1f us' % (M, K, N, name, t))
     lib.hfl_set_variant(b'x3_dbg', 0)
 
-print('--- stagger experiment (units of s_sleep 127 ~ 3.4 us per co-resident slot index)')
-for (M, K, N) in [(68167, 256, 1024), (68167, 256, 768), (118096, 128, 512), (68167, 1024, 256)]:
-    x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda') * 0.05
-    x2 = ops.split2(x); w2 = ops.split2_weight(w)
-    for st in (0, 1, 2, 3, 4, 6, 8):
-        lib.hfl_set_variant(b'x3_dbg', st << 8)
-        t = timeit(lambda: ops.linear_x3(x2, w2))
-        tg = timeit(lambda: ops.linear_x3(x2, w2, gelu_split_out=True))
-        print('M=%d K=%d N=%d stagger %d: %8.1f us   gelu-epi %8.1f us' % (M, K, N, st, t, tg))
-    lib.hfl_set_variant(b'x3_dbg', 0)
