@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--multistaged', action='store_true',
                     help='with --train: the full multi-staged step (stage 1 no-grad encode, TruncatedSmoothAP on the '
                          'all-gathered descriptors, stage 3 forward+backward, gradient all-reduce, AdamW step)')
+    ap.add_argument('--no-train-x3', action='store_true', help='A/B with --train: Linear layers as fp32 torch GEMMs')
     ap.add_argument('--x3-nt', type=int, default=None, help='A/B: non-temporal store bits of the hand-written GEMM (0..3)')
     ap.add_argument('--no-collective', action='store_true', help='A/B: skip the descriptor all-gather (N > 1 diagnostics)')
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no fp32 / e2e / roofline legs)')
@@ -133,6 +134,9 @@ def main():
     from hotformerloc_amd.model import set_gemm_mode, set_pyramid_streams
     set_gemm_mode(args.gemm)
     set_pyramid_streams(not args.no_streams)
+    if args.no_train_x3:
+        from hotformerloc_amd.model import set_train_x3
+        set_train_x3(False)
     if args.batch is None:
         args.batch = 64 if (args.config == 'cs-wild-places' and args.train) else 32
     if args.points_max is None and args.config == 'cs-wild-places':
@@ -335,7 +339,10 @@ def main():
         split_txt = 'f32 (Linear products as 3-term bf16 split, f32 accumulate; fp32_linear = all-f32 rate)'
         mode_txt = {'fp32': 'f32', 'bf16x3': split_txt, 'x3': split_txt}
         line = {
-            'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)', 'value': round(total_clouds / elapsed, 2),
+            'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)' if (args.config == 'wild-places' and not args.points_max
+                                                                         and args.points == 4096)
+                      else 'point-clouds/sec (%s cfg)' % args.config,
+            'value': round(total_clouds / elapsed, 2),
             'unit': 'clouds/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,

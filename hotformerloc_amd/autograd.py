@@ -217,3 +217,61 @@ class LinearSplitFn(torch.autograd.Function):
 
 def linear_split(x, weight, bias=None):
     return LinearSplitFn.apply(x, weight, bias)
+
+
+# ------------------------------------------------ split-precision Linear on the hand-written GEMM (csrc/gemm_x3.hip)
+def _w2_cached(weight, transposed: bool):
+    """split2 layout of a Linear weight (or of its transpose, for dx = dy W), rebuilt when the optimizer updates it."""
+    import weakref
+    key = (id(weight), transposed, 'x3')
+    hit = _WSPLIT_CACHE.get(key)
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version or hit[3] != weight.data_ptr():
+        w = weight.detach().t().contiguous() if transposed else weight.detach()
+        if len(_WSPLIT_CACHE) > 4096:
+            _WSPLIT_CACHE.clear()
+        hit = (weakref.ref(weight), weight._version, ops.split2(w), weight.data_ptr())
+        _WSPLIT_CACHE[key] = hit
+    return hit[2]
+
+
+def linear_x3_ok(in_features: int, out_features: int) -> bool:
+    """Shapes the hand-written GEMM takes in both directions (forward: K % 32, N % 128; dx: N % 32, K % 128)."""
+    return in_features % 128 == 0 and out_features % 128 == 0
+
+
+class LinearX3Fn(torch.autograd.Function):
+    """y = x W^T + b on `hfl_linear_x3` (three-term bf16 split, fp32 accumulation, 4e-6 per GEMM): the forward and
+    dx = dy W run on the hand-written kernel (2.5-3x the fp32 hipBLASLt rate), dW = dy^T x stays an fp32 GEMM (its
+    contraction runs over the ~10^5 rows: a different kernel shape)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.shape = shape
+        if x2.shape[0] == 0:
+            return x.new_zeros(*shape[:-1], weight.shape[0])
+        y = ops.linear_x3(ops.split2(x2), _w2_cached(weight, False), bias=bias)
+        return y.view(*shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, weight.shape[0]).contiguous()
+        dx = dw = db = None
+        if x2.shape[0] == 0:
+            return (torch.zeros(ctx.shape, device=dy.device), torch.zeros_like(weight),
+                    torch.zeros(weight.shape[0], device=dy.device) if ctx.has_bias else None)
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear_x3(ops.split2(dy2), _w2_cached(weight, True)).view(ctx.shape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(dy2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def linear_x3(x, weight, bias=None):
+    return LinearX3Fn.apply(x, weight, bias)

@@ -81,6 +81,29 @@ __device__ __forceinline__ void att_store_split(uint16_t* out16, int64_t orow, i
     o[2 * C] = lo;
   }
 }
+// FOUR consecutive channels ch .. ch+3 (ch % 4 == 0) of output row `orow`: one 16-B store (fp32) or 8-B stores of the
+// packed hi / lo halves (split modes)
+__device__ __forceinline__ void att_store_row4(char* out_b, uint32_t orow, int C, int ch, const f32x4 o, int mode) {
+  if (mode == 0) {
+    *reinterpret_cast<f32x4*>(out_b + ((size_t)orow * (uint32_t)C + (uint32_t)ch) * 4u) = o;
+    return;
+  }
+  const uint32_t h0 = att_bf16_rne(o[0]), h1 = att_bf16_rne(o[1]), h2 = att_bf16_rne(o[2]), h3 = att_bf16_rne(o[3]);
+  const uint32_t l0 = att_bf16_rne(o[0] - __uint_as_float(h0 << 16)), l1 = att_bf16_rne(o[1] - __uint_as_float(h1 << 16));
+  const uint32_t l2 = att_bf16_rne(o[2] - __uint_as_float(h2 << 16)), l3 = att_bf16_rne(o[3] - __uint_as_float(h3 << 16));
+  const uint2 hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16)), lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  uint16_t* out16 = reinterpret_cast<uint16_t*>(out_b);
+  if (mode == 2) {
+    uint16_t* d = out16 + (size_t)orow * (uint32_t)(2 * C) + (uint32_t)((ch >> 5) * 64 + (ch & 31));
+    *reinterpret_cast<uint2*>(d) = hi;
+    *reinterpret_cast<uint2*>(d + 32) = lo;
+  } else {
+    uint16_t* d = out16 + (size_t)orow * (uint32_t)(3 * C) + (uint32_t)ch;
+    *reinterpret_cast<uint2*>(d) = hi;
+    *reinterpret_cast<uint2*>(d + C) = hi;
+    *reinterpret_cast<uint2*>(d + 2 * C) = lo;
+  }
+}
 
 // T = number of 16-wide tiles of the padded sequence (K/16 + G), G = relay tokens
 template <int T, int G>
@@ -418,20 +441,11 @@ window_attn_kernel_v2(const WinParams p) {
       for (int kt = 0; kt < TW; ++kt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r] * inv, vf[kt][r], o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r], s[kt][r] * inv, o, 0, 0, 0);   // O^T: see v4
       }
-      if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[T - 1][0] * inv, vf[T - 1][0], o, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int orow = s_row[qt * 16 + 4 * g + r];
-        if (orow >= 0) {
-          if (p.out_split) {
-            att_store_split(reinterpret_cast<uint16_t*>(p.out), orow, C, h * 16 + c, o[r], p.out_split);
-          } else {
-            p.out[(int64_t)orow * C + h * 16 + c] = o[r];
-          }
-        }
-      }
+      if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[T - 1][0], s[T - 1][0] * inv, o, 0, 0, 0);
+      const int orow = s_row[qt * 16 + c];          // the lane's accumulator: channels 4g .. 4g+3 of query c
+      if (orow >= 0) att_store_row4(reinterpret_cast<char*>(p.out), (uint32_t)orow, C, h * 16 + 4 * g, o, p.out_split);
     }
 
     if (G > 0) {
@@ -749,28 +763,20 @@ window_attn_kernel_v4(const WinParams p) {
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
 
+        // O^T = V^T P^T: with V as the A operand the accumulator holds 4 CONSECUTIVE CHANNELS (4g .. 4g+3) of query c,
+        // whose 1/sum sits in this very lane: one wide store per lane, no shuffles
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < TW; ++kt) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r], vf[kt][r], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][r], s[kt][r], o, 0, 0, 0);
         }
-        if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(ert, vf[T - 1][0], o, 0, 0, 0);
-        // O rows are queries 4g+r of this tile; their 1/sum sits in lane (any group, c = 4g+r)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] *= __shfl(inv, (lane & 48) + 4 * g + r, 64);
-          const int orow = s_qry[qt * 16 + 4 * g + r].w;
-          if ((!MASKED || orow >= 0) && (!(p.dbg & 2) || o[r] == 1234.5f)) {
-            char* ob = out_b + ((uint32_t)orow * row_o);
-            if (p.out_split) {
-              att_store_split(reinterpret_cast<uint16_t*>(out_b), orow, C, h * 16 + c, o[r], p.out_split);
-            } else {
-              reinterpret_cast<float*>(ob)[h * 16 + c] = o[r];
-            }
-          }
-        }
+        if (G > 0) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[T - 1][0], ert, o, 0, 0, 0);
+        o *= inv;
+        const int orow = qm.w;
+        if ((!MASKED || orow >= 0) && (!(p.dbg & 2) || o[0] == 1234.5f))
+          att_store_row4(out_b, (uint32_t)orow, C, h * 16 + 4 * g, o, p.out_split);
       }
 
       if (G > 0) {

@@ -85,6 +85,8 @@ _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 # at 191 ms/step (B=32, Wild-Places) still slower than the fp32 hipBLASLt route (145 ms) because the operand
 # splits of the backward are torch element-wise passes; needs fused split kernels to pay off.
 _TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
+# training-path Linear layers on the hand-written split GEMM (autograd.LinearX3Fn: forward + dx; dW stays fp32)
+_TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
@@ -93,6 +95,12 @@ def set_train_split(enabled: bool):
     """Route the training-path Linear layers through the split-bf16 GEMMs (experimental, see _TRAIN_SPLIT)."""
     global _TRAIN_SPLIT
     _TRAIN_SPLIT = bool(enabled)
+
+
+def set_train_x3(enabled: bool):
+    """Training-path Linear layers through `autograd.LinearX3Fn` (default on in GEMM mode 'x3')."""
+    global _TRAIN_X3
+    _TRAIN_X3 = bool(enabled)
 
 
 def set_pyramid_streams(enabled: bool):
@@ -155,6 +163,9 @@ class SplitLinear(nn.Linear):
     GEMM mode is 'bf16x3'; parameters, names and the fp32 fallback are those of nn.Linear."""
 
     def forward(self, x):
+        if (_GEMM_MODE == 'x3' and _TRAIN_X3 and x.is_cuda and _grad_path() and x.numel() > 0
+                and ag.linear_x3_ok(self.in_features, self.out_features)):
+            return ag.linear_x3(x, self.weight, self.bias)       # hand-written split GEMM, forward and dx
         if (_GEMM_MODE == 'bf16x3' and _TRAIN_SPLIT and x.is_cuda and _grad_path()
                 and self.in_features % 8 == 0 and self.out_features % 8 == 0 and x.numel() > 0):
             return ag.linear_split(x, self.weight, self.bias)
@@ -489,14 +500,16 @@ class HOTFormerBlock(nn.Module):
         self.cpe = CPE(dim, conv_norm, xcpe)
         _init_layer_scale(self, dim, layer_scale)
 
-    def forward(self, buf, plan: WindowPlan, depth: int):
+    def forward(self, buf, plan: WindowPlan, depth: int, relay=None):
+        """buf: [tokens | relay rows] of this depth; `relay` (optional): this depth's relay rows as RTSA just produced
+        them -- they replace buf's relay rows without a separate copy into buf first."""
         nt = plan.n_tokens[depth]
         if _grad_path(buf):
-            buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:]], 0)
+            buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:] if relay is None else relay], 0)
         else:                                   # CPE writes straight into the new buffer's token rows
             new = torch.empty_like(buf)
             self.cpe(buf[:nt], plan, depth, residual=True, out=new[:nt])
-            new[nt:].copy_(buf[nt:])
+            new[nt:].copy_(buf[nt:] if relay is None else relay)
             buf = new
         if _split_path(buf) and not self.use_layer_scale:
             o3 = self.attention.forward_split(buf, self.norm1, plan, depth)
@@ -542,6 +555,12 @@ class RelayTokenTransformerBlock(nn.Module):
         _init_layer_scale(self, dim, layer_scale)                       # hotformerloc_backbone.py:260-272
 
     def forward(self, rt, plan):
+        if _GEMM_MODE == 'x3' and _split_path(rt) and not self.use_layer_scale and rt.shape[0] > 0:
+            att = self.rt_attention
+            a2 = ops.layer_norm_split2(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            qkv = ops.linear_x3(a2, _w2(att.qkv), bias=att.qkv.bias)
+            o2 = ops.split2(ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, att.num_heads, plan.max_seq_len))
+            return _block_tail_x3(rt, o2, att, self.norm2, self.mlp)
         if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
             bid = plan.relay_cloud()
             rt = rt + self.drop_path(self.gamma1 * self.rt_attention(_ln(rt, self.norm1), plan), bid, plan.B)
@@ -654,13 +673,7 @@ class HOTFormerStage(nn.Module):
                 rt_all = checkpoint(self.rtsa_blocks[i], rt_all, plan, use_reentrant=False)
             else:
                 rt_all = self.rtsa_blocks[i](rt_all, plan)
-            for d, nt in zip(depths, nts):
-                off = plan.rt_offset[d]
-                new_rt = rt_all[off:off + plan.n_windows[d]]
-                if _grad_path(new_rt):
-                    bufs[d] = torch.cat([bufs[d][:nt], new_rt], 0)
-                else:                              # only the relay rows move; tokens stay in place
-                    bufs[d][nt:].copy_(new_rt)
+            fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
             if _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda:
                 # the three depths are independent inside an iteration (the reference runs them on
                 # three CUDA streams too, hotformerloc_backbone.py:604-633): the coarse depths'
@@ -677,22 +690,22 @@ class HOTFormerStage(nn.Module):
                     if j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS:
                         continue
                     side[j - 1].wait_stream(main)
-                    keep.append(bufs[d])
+                    keep.append((bufs[d], rt_all))
                     with torch.cuda.stream(side[j - 1]):
-                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d, fresh[d])
                     used.append(j)
                 for j, d in enumerate(depths):
                     if j not in used:
-                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d, fresh[d])
                 for j in used:
                     main.wait_stream(side[j - 1])
                 del keep
             else:
                 for j, d in enumerate(depths):
                     if ckpt:                                            # 610-618
-                        bufs[d] = checkpoint(self.hosa_blocks[j][i], bufs[d], plan, d, use_reentrant=False)
+                        bufs[d] = checkpoint(self.hosa_blocks[j][i], bufs[d], plan, d, fresh[d], use_reentrant=False)
                     else:
-                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d)
+                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d, fresh[d])
         local = {d: bufs[d][:nt] for d, nt in zip(depths, nts)}
         relay = {d: bufs[d][nt:] for d, nt in zip(depths, nts)}
         return local, relay

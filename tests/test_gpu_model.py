@@ -159,8 +159,11 @@ def test_batch_composition_semantics():
     assert np.array_equal(full, again)
 
 
-@pytest.mark.parametrize('cfg,sizes', [('cs-wild-places', [2500, 1800]), ('wild-places', [1500, 900, 1200])])
-def test_forward_backward_matches_oracle_autograd(cfg, sizes):
+@pytest.mark.parametrize('cfg,sizes,linear', [('cs-wild-places', [2500, 1800], 'x3'),
+                                              ('wild-places', [1500, 900, 1200], 'x3'),
+                                              ('wild-places', [1500, 900, 1200], 'fp32'),
+                                              ('cs-wild-places', [2500, 1800], 'bf16x3-lt')])
+def test_forward_backward_matches_oracle_autograd(cfg, sizes, linear):
     """BASELINE config 3 (fwd+bwd): parameter gradients of the HIP training path against torch
     autograd through the CPU oracle, drop_path = 0 (stochastic depth is RNG-dependent)."""
     params, depth = load_config(cfg)
@@ -176,13 +179,19 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes):
     model = model_factory(params)
     syn.fill_synthetic_weights(model, 'stress')
     model = model.cuda().train()
-    from hotformerloc_amd.model import set_train_split
-    set_train_split(cfg == 'cs-wild-places')     # one case through the split-bf16 Linear backward, one through fp32
+    # training-path Linear layers: 'x3' = hand-written split GEMM (forward + dx), 'fp32' = torch fp32 GEMMs,
+    # 'bf16x3-lt' = the K-concatenated split through hipBLASLt (forward, dx and dW)
+    from hotformerloc_amd.model import set_train_split, set_train_x3
+    set_train_x3(linear == 'x3')
+    set_train_split(linear == 'bf16x3-lt')
+    set_gemm_mode('bf16x3' if linear == 'bf16x3-lt' else 'x3')
     try:
         y = model({'octree': build_batch_octree(clouds, depth, 2, 'cuda')})['global']
         (y * proj.cuda()).sum().backward()
     finally:
         set_train_split(False)
+        set_train_x3(True)
+        set_gemm_mode('x3')
     rel = _rel(y.detach().cpu().numpy(), y_ref.detach().numpy()).max()
     assert rel <= REL_TOL, rel
     worst = {}
@@ -193,7 +202,7 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes):
         kind = name.split('.')[-1] if 'rpe_table' not in name else 'rpe_table'
         worst[kind] = max(worst.get(kind, 0.0), err)
         assert err < 2e-3 or gref.norm().item() < 1e-9, (name, err, gref.norm().item())
-    print(cfg, 'forward rel', rel, 'worst grad rel-L2 per kind', worst)
+    print(cfg, linear, 'forward rel', rel, 'worst grad rel-L2 per kind', worst)
 
 
 def test_drop_path_is_per_cloud_and_off_in_eval():
