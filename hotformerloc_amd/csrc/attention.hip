@@ -48,17 +48,21 @@ struct WinParams {
   const float* qkv_bias;   // (3*H*16) added to q,k,v on load (bias-free GEMM upstream), or null
   int out_split;           // 1: out is bf16 [hi|hi|lo] rows of 3*H*16 (A operand of the K-concatenated split GEMM);
                            // 2: bf16 split2 rows of 2*H*16 (operand of hfl_linear_x3)
+  int qkv_f16;             // 1: qkv rows are the fp16 (hi, lo) attention operand layout of hfl_linear_x3_qkv (v5 kernel)
   const float* rpe2;       // (H, TS) expanded table of hfl_window_rpe_expand (v4), or null
   int depth;               // octree depth of the tokens (0 = unknown)
   int dbg;                 // ablation bits (tools/kbench.py): 1 no softmax/MFMA, 2 no stores, 4 cached rows
 };
 
-// v_max3_f32 without the canonicalising v_max(x,x) that fmaxf() costs under IEEE mode
-__device__ __forceinline__ float att_max3(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
+// compiler-visible max of three (v5): the inline-asm form below is invisible to the hazard recogniser, and right behind a
+// 16-cycle fp16 MFMA it read its operand before the matrix pipe had written it (wrong row maxima in the last query tile)
+__device__ __forceinline__ float att_max3_c(float a, float b, float c) {
+  return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
+
+// max of three for the softmax row maxima.  (An earlier inline-asm v_max3_f32 saved the canonicalising v_max(x, x) of
+// fmaxf() but hid the operands from the compiler's hazard recogniser: see att_max3_c.)
+__device__ __forceinline__ float att_max3(float a, float b, float c) { return att_max3_c(a, b, c); }
 
 __device__ __forceinline__ uint16_t att_bf16_rne(float v) {
   uint32_t u = __float_as_uint(v);
@@ -861,6 +865,283 @@ window_attn_kernel_v4(const WinParams p) {
   }
 }
 
+// v5: v4 with the two contractions on the fp16 matrix cores at fp32-equivalent accuracy.
+// v4 is bound by issue slots: 87 fp32 MFMAs (32 cycles each, dependent chains) + ~570 VALU per (window, head).  The
+// 16x16x32 fp16 MFMA does a K = 32 step in 16 cycles, and a head's 16 dims as [16 x hi | 16 x lo] halves ARE a K = 32
+// operand -- but splitting fp32 q, k, v into (hi, lo) inside this kernel would cost more VALU than the MFMAs save.
+// So the producer does it: the qkv projection (csrc/gemm_x3.hip, EPI 2) writes every row as [Q | K | V] regions, per head
+// 64 B = [16 x hi | 16 x lo] fp16 (hi = RTZ(v), lo = RTZ(v - hi): 22 significant bits), bias added, queries pre-multiplied
+// by scale * log2 e.  Same bytes per row as fp32 qkv; every fragment below is ONE 16-B load:
+//   S^T = K Q^T   A = [k_hi | k_lo] (lane group g takes chunk g of the head's 64 B), B = [q_hi | q_hi], then [q_lo | q_lo]:
+//                 two MFMAs give all four cross terms (k_hi + k_lo)(q_hi + q_lo); fp32 accumulate
+//   O^T = V^T P^T A = V columns by `ds_read_b64_tr_b16` from the rows staged in LDS as loaded (hardware transpose),
+//                 B = the un-normalised P of two key tiles, split (hi, lo) in registers; 3 MFMAs per pair of key tiles
+//                 (v_hi p_hi + v_lo p_hi + v_hi p_lo)
+// 42 fp16 MFMAs (16 cycles) instead of 87 fp32 ones, 16 vector loads per window instead of 24, and the relay token
+// as a query is simply a fourth query tile with one live column.  Everything else (index-arithmetic windows, double-
+// buffered metadata, expanded RPE table, mask-free homogeneous windows, persistent grid) is v4's.
+typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
+typedef short att_s4 __attribute__((ext_vector_type(4)));
+
+template <int T, int G, bool RPE>
+__global__ void __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(v4_waves_per_simd(T, G), v4_waves_per_simd(T, G))))
+window_attn_kernel_v5(const WinParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LP = T * 16;
+  constexpr int TW = T - G;
+  constexpr int NP = (T + 1) / 2;                      // pairs of key tiles (K = 32 per PV MFMA)
+  typedef __attribute__((address_space(3))) const float lds_f32;
+  const int H = p.H, K = p.K;
+  const int C = H * 16;
+  const int R = (1 << p.depth) - 1, W = 2 * R + 1;
+  const int TS = RPE ? ((W + W * W + 3) & ~3) : 0;
+  int4* s_qry0 = reinterpret_cast<int4*>(smem);                        // [2][LP] {4x, 4(yW+z), id, row}
+  int2* s_key0 = reinterpret_cast<int2*>(s_qry0 + 2 * LP);             // [2][LP] {4(R-x), 4(W+(R-y)W+R-z)}
+  int* s_kbid0 = reinterpret_cast<int*>(s_key0 + 2 * LP);              // [2][LP] batch id, -1 dead
+  unsigned char* s_v0 = reinterpret_cast<unsigned char*>(s_kbid0 + 2 * LP);   // [nhw][2 NP * 16 rows][64 B]  V rows
+  const int nhw = blockDim.x >> 6;
+  float* s_tab = reinterpret_cast<float*>(s_v0 + nhw * (2 * NP * 16) * 64);  // [nhw][TS] * log2e
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int hw = tid >> 6;
+  const int h = blockIdx.y * nhw + hw;
+  const int c = lane & 15, g = lane >> 4;
+
+  if (RPE) {
+    const float4* src = reinterpret_cast<const float4*>(p.rpe2 + (size_t)blockIdx.y * nhw * TS);
+    float4* dst = reinterpret_cast<float4*>(s_tab);
+    for (int i = tid; i < nhw * TS / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  const int hu = __builtin_amdgcn_readfirstlane(hw);
+  const int tabb = (int)(size_t)(s_tab + hu * TS);
+  unsigned char* s_v = s_v0 + hu * (2 * NP * 16) * 64;                 // this wave's V image
+  // rows past the real key tiles of the last pair must read as zeros (0 * garbage could be NaN)
+  for (int i = lane; i < (2 * NP * 16 - LP) * 4; i += 64)
+    reinterpret_cast<uint4*>(s_v + LP * 64)[i] = make_uint4(0u, 0u, 0u, 0u);
+  const float mask2 = kMaskValue * 1.4426950408889634f;
+  const float rt_add = (g == 0) ? 0.f : kDeadValue;   // the relay key lives in the g == 0 lanes only
+  const uint32_t row_q = (uint32_t)(3 * C) * 4u;       // bytes per qkv row (same as fp32 qkv)
+  const char* qkv_b = reinterpret_cast<const char*>(p.qkv);
+  char* out_b = reinterpret_cast<char*>(p.out);
+  const uint32_t col_k = (uint32_t)C * 4u + (uint32_t)h * 64u + (uint32_t)g * 16u;        // chunk g of [k_hi | k_lo]
+  const uint32_t col_v = (uint32_t)C * 8u + (uint32_t)h * 64u + (uint32_t)g * 16u;
+  const uint32_t col_qh = (uint32_t)h * 64u + (uint32_t)(g & 1) * 16u;                   // [q_hi | q_hi]
+  const uint32_t col_ql = col_qh + 32u;                                                   // [q_lo | q_lo]
+  // transposed V reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its 4-key block
+  const int tr_off = ((4 * g + (c >> 2)) * 64) + (c & 3) * 8;
+
+  const int n_tok = (int)p.n_tokens;
+  const bool owns = tid < LP;                          // the launcher guarantees blockDim.x >= LP
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+  int it = 0;
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
+    const int tstep = p.D;
+    const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
+    const int rt_row = (int)p.rt_row0 + w;
+    // ---- request the window: metadata word + every fragment of this wave's head (index arithmetic only) ----------
+    uint2 mt = make_uint2(0u, 0xFFFFFFFFu);
+    if (owns && tid < K) {
+      const int t = tok0 + tid * tstep;
+      if (t < n_tok) mt = *reinterpret_cast<const uint2*>(p.meta + 2 * (int64_t)t);
+    }
+    uint4 ka[T], qh[T], ql[T], vr[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      int row;
+      bool ok;
+      if (G > 0 && t == T - 1) {
+        row = rt_row;
+        ok = (c == 0);
+      } else {
+        row = tok0 + (t * 16 + c) * tstep;
+        ok = row < n_tok;
+      }
+      ka[t] = qh[t] = ql[t] = vr[t] = zero4;
+      if (ok) {
+        const char* base = qkv_b + (uint32_t)row * row_q;
+        ka[t] = *reinterpret_cast<const uint4*>(base + col_k);
+        qh[t] = *reinterpret_cast<const uint4*>(base + col_qh);
+        ql[t] = *reinterpret_cast<const uint4*>(base + col_ql);
+        vr[t] = *reinterpret_cast<const uint4*>(base + col_v);
+      }
+    }
+    int4* s_qry = s_qry0 + (it & 1) * LP;
+    int2* s_key = s_key0 + (it & 1) * LP;
+    int* s_kbid = s_kbid0 + (it & 1) * LP;
+    if (owns) {
+      const int j = tid;
+      int bid = -1, row = -1;
+      int x = 0, y = 0, z = 0;
+      if (j < K) {
+        if (mt.y != 0xFFFFFFFFu) {
+          x = (int)(mt.x & 1023u); y = (int)((mt.x >> 10) & 1023u); z = (int)(mt.x >> 20);
+          bid = (int)mt.y;
+          row = tok0 + j * tstep;
+        }
+      } else if (G > 0 && j == K) {
+        row = rt_row;
+      }
+      s_key[j] = make_int2(4 * (R - x), 4 * (W + (R - y) * W + (R - z)));
+      s_kbid[j] = bid;
+      s_qry[j] = make_int4(4 * x, 4 * (y * W + z), bid, row);
+    }
+    // stage this head's V rows exactly as loaded: row (tile, key) = 64 B [16 x hi | 16 x lo], lane (c, g) owns chunk g
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<uint4*>(s_v + (t * 16 + c) * 64 + g * 16) = vr[t];
+    __syncthreads();
+    const int bid0 = s_kbid[0], bidl = s_kbid[K - 1];
+    const int rt_bid = bid0 >= 0 ? bid0 : p.batch;     // the relay token carries the id of the window's first token
+    const bool homog = __builtin_amdgcn_readfirstlane((bidl >= 0 && bid0 == bidl) ? 1 : 0) != 0;
+
+    // V^T fragments of every key-tile pair: elements 0..3 = keys 4g..4g+3 of tile 2p, 4..7 = of tile 2p+1, column d = c
+    att_h8 vhi[NP], vlo[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      typedef __attribute__((address_space(3))) att_s4 lds_s4;
+      const unsigned char* b0 = s_v + (2 * pp) * 16 * 64 + tr_off;
+      const att_s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(b0));
+      const att_s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(b0 + 32));
+      const att_s4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(b0 + 16 * 64));
+      const att_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(b0 + 16 * 64 + 32));
+      const short __attribute__((ext_vector_type(8))) hh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const short __attribute__((ext_vector_type(8))) ll = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      vhi[pp] = __builtin_bit_cast(att_h8, hh);
+      vlo[pp] = __builtin_bit_cast(att_h8, ll);
+    }
+
+    int kxa[TW][4], kyza[TW][4];
+    if (RPE) {
+#pragma unroll
+      for (int kt = 0; kt < TW; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int2 km = s_key[kt * 16 + 4 * g + r];
+          kxa[kt][r] = km.x;
+          kyza[kt][r] = km.y;
+        }
+    }
+
+    auto body = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+      for (int qt = 0; qt < T; ++qt) {           // TW token query tiles [+ the relay token as a tile with one live column]
+        const bool is_rt = (G > 0 && qt == T - 1);
+        // the relay tile needs no metadata (no RPE, its id is rt_bid, its row rt_row): do not read slots >= K
+        const int4 qm = is_rt ? make_int4(0, 0, -1, -1) : s_qry[qt * 16 + c];
+        const int q_bid = is_rt ? rt_bid : qm.z;
+        const int qxa = qm.x + tabb, qyza = qm.y + tabb;
+        const att_h8 bqh = __builtin_bit_cast(att_h8, qh[qt]);
+        const att_h8 bql = __builtin_bit_cast(att_h8, ql[qt]);
+
+        f32x4 s[T];
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt) {
+          const att_h8 ak = __builtin_bit_cast(att_h8, ka[kt]);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak, bql, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak, bqh, acc, 0, 0, 0);
+          s[kt] = acc;
+        }
+        if (RPE && !is_rt) {                     // no RPE for the relay row / column (octformer_backbone.py:78-80)
+#pragma unroll
+          for (int kt = 0; kt < TW; ++kt) {
+            f32x4 bx, byz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bx[r] = *reinterpret_cast<lds_f32*>(kxa[kt][r] + qxa);
+              byz[r] = *reinterpret_cast<lds_f32*>(kyza[kt][r] + qyza);
+            }
+            s[kt] += bx + byz;
+          }
+        }
+        if (MASKED) {
+#pragma unroll
+          for (int kt = 0; kt < TW; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (s_kbid[kt * 16 + 4 * g + r] != q_bid) s[kt][r] += mask2;
+        }
+        float mx = kDeadValue;
+        float srt = kDeadValue;
+        if (G > 0) {   // relay key: position K = tile T-1, k-slot group 0, register 0
+          srt = s[T - 1][0] + rt_add;
+          if (MASKED && rt_bid != q_bid) srt += mask2;
+          mx = srt;
+        }
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+          mx = att_max3_c(mx, s[kt][0], s[kt][1]);
+          mx = att_max3_c(mx, s[kt][2], s[kt][3]);
+        }
+        mx = att_max3_c(mx, __shfl_xor(mx, 16, 64), mx);
+        mx = att_max3_c(mx, __shfl_xor(mx, 32, 64), mx);
+        const f32x4 nmx4 = {-mx, -mx, -mx, -mx};
+        f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < TW; ++kt) {
+          f32x4 e = s[kt] + nmx4;
+          e[0] = __builtin_amdgcn_exp2f(e[0]); e[1] = __builtin_amdgcn_exp2f(e[1]);
+          e[2] = __builtin_amdgcn_exp2f(e[2]); e[3] = __builtin_amdgcn_exp2f(e[3]);
+          s[kt] = e;
+          sum4 += e;
+        }
+        float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+        if (G > 0) {
+          const float ert = __builtin_amdgcn_exp2f(srt - mx);
+          s[T - 1] = (f32x4){ert, 0.f, 0.f, 0.f};         // zero in the lanes g != 0 (rt_add)
+          sum += ert;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+
+        // O^T = V^T P^T over pairs of key tiles; P (un-normalised, in [0, 1]) split into fp16 (hi, lo) in registers
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const f32x4 pa = s[2 * pp];
+          const f32x4 pb = (2 * pp + 1 < T) ? s[2 * pp + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
+          const auto h0 = __builtin_amdgcn_cvt_pkrtz(pa[0], pa[1]), h1 = __builtin_amdgcn_cvt_pkrtz(pa[2], pa[3]);
+          const auto h2 = __builtin_amdgcn_cvt_pkrtz(pb[0], pb[1]), h3 = __builtin_amdgcn_cvt_pkrtz(pb[2], pb[3]);
+          const auto l0 = __builtin_amdgcn_cvt_pkrtz(pa[0] - (float)h0[0], pa[1] - (float)h0[1]);
+          const auto l1 = __builtin_amdgcn_cvt_pkrtz(pa[2] - (float)h1[0], pa[3] - (float)h1[1]);
+          const auto l2 = __builtin_amdgcn_cvt_pkrtz(pb[0] - (float)h2[0], pb[1] - (float)h2[1]);
+          const auto l3 = __builtin_amdgcn_cvt_pkrtz(pb[2] - (float)h3[0], pb[3] - (float)h3[1]);
+          typedef unsigned int att_u4 __attribute__((ext_vector_type(4)));
+          const att_u4 uh = {__builtin_bit_cast(unsigned int, h0), __builtin_bit_cast(unsigned int, h1),
+                             __builtin_bit_cast(unsigned int, h2), __builtin_bit_cast(unsigned int, h3)};
+          const att_u4 ul = {__builtin_bit_cast(unsigned int, l0), __builtin_bit_cast(unsigned int, l1),
+                             __builtin_bit_cast(unsigned int, l2), __builtin_bit_cast(unsigned int, l3)};
+          const att_h8 phi = __builtin_bit_cast(att_h8, uh);
+          const att_h8 plo = __builtin_bit_cast(att_h8, ul);
+          o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi[pp], plo, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo[pp], phi, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi[pp], phi, o, 0, 0, 0);
+        }
+        if (is_rt && (p.dbg & 64) && w == 2 && h == 0) {     // debug dump of the relay tile into out rows 0..63
+          float* dr = reinterpret_cast<float*>(out_b) + (size_t)lane * C;
+          dr[0] = mx; dr[1] = sum; dr[2] = inv; dr[3] = srt; dr[4] = o[0]; dr[5] = o[1]; dr[6] = o[2]; dr[7] = o[3];
+#pragma unroll
+          for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dr[8 + kt * 4 + r] = s[kt][r];
+        }
+        o *= inv;
+        // the accumulator holds channels 4g .. 4g+3 of query c (relay tile: only the column c == 0 is a row)
+        const int orow = is_rt ? (c == 0 ? rt_row : -1) : qm.w;
+        if (orow >= 0) att_store_row4(out_b, (uint32_t)orow, C, h * 16 + 4 * g, o, p.out_split);
+      }
+    };
+    if (homog)
+      body(std::false_type{});
+    else
+      body(std::true_type{});
+  }
+}
+
 // expanded RPE table of v4: out (H, TS), TS = (W + W*W + 3) & ~3, W = 2R+1, R = 2^depth - 1 <= pos_bnd:
 //   out[h][i]             = table[(i - R + bnd), h] * log2e                       i in [0, W)   (x axis)
 //   out[h][W + iy*W + iz] = (table[nrpe + iy - R + bnd, h] + table[2 nrpe + iz - R + bnd, h]) * log2e
@@ -896,6 +1177,7 @@ static int launch_window(const WinParams& p, hipStream_t s) {
   const int cap = hfl_num_cus() * 4;
   if (blocks > cap) blocks = cap;
   if (g_window_variant == 1) {
+    if (p.qkv_f16) return HFL_EINVAL;
     const size_t lds = (p.table ? (size_t)p.H * 3 * nrpe * 4 : 0) + (size_t)LP * (4 + 4 + 8);
     window_attn_kernel<T, G><<<blocks, p.H * 64, lds, s>>>(p);
   } else {
@@ -911,7 +1193,41 @@ static int launch_window(const WinParams& p, hipStream_t s) {
     const int R4 = (1 << (p.depth > 0 && p.depth <= 5 ? p.depth : 0)) - 1, W4 = 2 * R4 + 1;
     const size_t ts4 = p.table ? (size_t)((W4 + W4 * W4 + 3) & ~3) : 0;
     const size_t lds4 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts4 * 4;
-    if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
+    if (p.qkv_f16) {
+      // fp16 (hi, lo) operand layout: only the v5 kernel reads it (callers ask hfl_window_attention_f16_ok first).
+      // Heads per workgroup: 4, or 2 when the expanded RPE tables of 4 heads do not leave room in LDS (depth 5)
+      const int np5 = (T + 1) / 2;
+      int hp5 = hpw;
+      size_t lds5 = 0;
+      for (;; hp5 >>= 1) {
+        lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hp5 * ts4 * 4 + (size_t)hp5 * (2 * np5 * 16) * 64;
+        if (lds5 <= 72 * 1024 || hp5 <= 2 || p.H % (hp5 / 2) != 0) break;
+      }
+      if (p.clamp || p.depth < 1 || p.depth > 5 || (p.table != nullptr && p.rpe2 == nullptr) ||
+          rows_total * 3 * p.H * 16 * 4 >= (int64_t)1 << 32 || lds5 > 72 * 1024 || hp5 * 64 < LP || p.qkv_bias != nullptr)
+        return HFL_EINVAL;
+      const int groups5 = p.H / hp5;
+      int resident = v4_waves_per_simd(T, G) * 4 / hp5;
+      const int lds_fit = (int)((size_t)160 * 1024 / (lds5 + 512));
+      if (resident > lds_fit) resident = lds_fit;
+      if (resident < 1) resident = 1;
+      int px = hfl_num_cus() * resident * g_window_v4_wgs_per_cu / groups5;
+      if (px < 1) px = 1;
+      if (px > p.n_windows) px = p.n_windows;
+      dim3 grid5((unsigned)px, (unsigned)groups5);
+      hipError_t e;
+      if (p.table == nullptr) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+        if (e != hipSuccess) return (int)e;
+        window_attn_kernel_v5<T, G, false><<<grid5, hp5 * 64, lds5, s>>>(p);
+      } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+        if (e != hipSuccess) return (int)e;
+        window_attn_kernel_v5<T, G, true><<<grid5, hp5 * 64, lds5, s>>>(p);
+      }
+    } else if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
         (p.table == nullptr || p.rpe2 != nullptr) && rows_total * 3 * p.H * 16 * 4 < (int64_t)1 << 32 &&
         lds4 <= 72 * 1024 && hpw * 64 >= LP) {
       // persistent grid: exactly the workgroups that are resident at once (waves-per-SIMD target of
@@ -1105,6 +1421,29 @@ int hfl_set_variant(const char* key, int value) {
   return HFL_EINVAL;
 }
 
+/* 1 when hfl_window_attention_fwd_ex accepts the fp16 (hi, lo) qkv operand layout (flag 0x100) for this launch
+ * configuration: the v5 kernel needs the expanded RPE table (depth <= 5, no clamp) and <= 72 KiB of LDS */
+int hfl_window_attention_f16_ok(const hfl_window_attn_desc* d, int64_t n_rows_total) {
+  if (d == nullptr || d->n_heads <= 0 || d->patch_size % 16 != 0) return 0;
+  if (d->depth < 1 || d->depth > 5 || ((1 << d->depth) - 1) > d->pos_bnd) return 0;
+  if (g_window_variant != 4) return 0;
+  const int T = d->patch_size / 16 + d->n_relay;
+  if (T < 1 || T > 5) return 0;
+  int hpw = g_window_heads_per_wg;
+  if (hpw < 1 || hpw > 4 || d->n_heads % hpw != 0) hpw = (d->n_heads % 4 == 0) ? 4 : (d->n_heads % 2 == 0) ? 2 : 1;
+  const int LP = T * 16;
+  const int R4 = (1 << d->depth) - 1, W4 = 2 * R4 + 1;
+  const size_t ts4 = (size_t)((W4 + W4 * W4 + 3) & ~3);
+  size_t lds5 = 0;
+  for (;; hpw >>= 1) {        // as the launcher: 4 heads per workgroup, or 2 when their tables crowd the LDS
+    lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts4 * 4 + (size_t)hpw * (2 * ((T + 1) / 2) * 16) * 64;
+    if (lds5 <= 72 * 1024 || hpw <= 2 || d->n_heads % (hpw / 2) != 0) break;
+  }
+  if (lds5 > 72 * 1024 || hpw * 64 < LP) return 0;
+  if (n_rows_total * 3 * d->n_heads * 16 * 4 >= (int64_t)1 << 32) return 0;
+  return 1;
+}
+
 int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_meta,
                              const float* rpe_table, const hfl_window_attn_desc* d,
                              hfl_stream_t stream) {
@@ -1116,12 +1455,14 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
                                 const hfl_window_attn_desc* d, int out_split3, hfl_stream_t stream) {
   if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
   if ((qkv_bias != nullptr || out_split3) && g_window_variant < 2) return HFL_EINVAL;
+  if ((out_split3 & 3) == 3 || (out_split3 & ~0x103)) return HFL_EINVAL;
   if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
   if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
   if (d->n_windows == 0) return HFL_OK;
   WinParams p;
   p.out = static_cast<float*>(out); p.qkv = qkv; p.meta = tok_meta; p.table = rpe_table;
-  p.qkv_bias = qkv_bias; p.out_split = out_split3;
+  p.qkv_bias = qkv_bias; p.out_split = out_split3 & 3;
+  p.qkv_f16 = (out_split3 >> 8) & 1;
   p.rpe2 = rpe_table != nullptr ? d->rpe_expanded : nullptr;
   p.depth = d->depth;
   p.dbg = g_window_dbg;

@@ -52,6 +52,8 @@ struct X3Params {
   int N, K;
   int tiles_n;
   int64_t n_wg;
+  int qk_channels;          // EPI 2: C (= out_features / 3); features < C are queries
+  float q_scale;            // EPI 2: factor folded into the queries (softmax scale * log2 e)
   int nt;                   // bit 0: non-temporal stores of the f32 output, bit 1: of the split2 output
   int dbg;                  // ablation bits (tools/x3_probe.py): 1 no in-loop DMA, 2 no MFMA, 4 no stores, 8 no LDS reads
 };
@@ -80,7 +82,10 @@ __device__ __forceinline__ float x3_gelu(float v) {
   return 0.5f * v * (1.0f + erf_v);
 }
 
-// EPI 0: out f32 = acc + bias [+ residual];  EPI 1: out split2 = split(gelu(acc + bias))
+// EPI 0: out f32 = acc + bias [+ residual];  EPI 1: out split2 = split(gelu(acc + bias));
+// EPI 2: out = the window-attention operand layout of acc + bias (qkv projection): per row [Q | K | V] regions of C
+//        features, per head 16 dims as [16 x hi | 16 x lo] fp16 (hi = RTZ(v), lo = RTZ(v - hi): 22 significant bits), the
+//        queries pre-multiplied by q_scale -- csrc/attention.hip, window_attn_kernel_v5 loads these as MFMA fragments
 template <int EPI>
 __global__ void __launch_bounds__(256, 3)
 gemm_x3_kernel(const X3Params p) {
@@ -225,6 +230,23 @@ gemm_x3_kernel(const X3Params p) {
         f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * N + nbase);
         if (p.nt & 1) __builtin_nontemporal_store(vv, dst);
         else *dst = vv;
+      } else if (EPI == 2) {
+        if (nbase < p.qk_channels) { v.x *= p.q_scale; v.y *= p.q_scale; v.z *= p.q_scale; v.w *= p.q_scale; }
+        const auto h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+        const auto l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01[0], v.y - (float)h01[1]);
+        const auto l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23[0], v.w - (float)h23[1]);
+        const uint32_t uh0 = __builtin_bit_cast(uint32_t, h01), uh1 = __builtin_bit_cast(uint32_t, h23);
+        const uint32_t ul0 = __builtin_bit_cast(uint32_t, l01), ul1 = __builtin_bit_cast(uint32_t, l23);
+        // lane pair (2k, 2k+1) holds 8 consecutive dims of one head: the even lane stores their hi halves (16 B), the
+        // odd lane their lo halves
+        const uint32_t mine0 = (lane & 1) ? uh0 : ul0, mine1 = (lane & 1) ? uh1 : ul1;
+        const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
+        const u32x4 qq = (lane & 1) ? (u32x4){got0, got1, ul0, ul1} : (u32x4){uh0, uh1, got0, got1};
+        const int n8 = n0 + wn * 64 + (ecol & ~1) * 4;                       // first of the pair's 8 features
+        const int dim0 = n8 & 15;                                              // 0 or 8
+        unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + m * (int64_t)N * 4 + n8 * 4 - dim0 * 2 +
+                           ((lane & 1) ? 32 : 0);
+        *reinterpret_cast<u32x4*>(o) = qq;
       } else {
         v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
         const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
@@ -280,9 +302,27 @@ void hfl_internal_set_x3_dbg(int v) {
   else g_x3_dbg = v;
 }
 
+static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                     const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
+                     float q_scale, hfl_stream_t stream);
+
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream) {
+  return x3_launch(out, x_split2, w_split2, bias, residual, n_rows, in_features, out_features,
+                   gelu_split_out ? 1 : 0, 1.0f, stream);
+}
+
+int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                      int64_t n_rows, int in_features, int out_features, float q_scale, hfl_stream_t stream) {
+  if (out_features % 3 != 0 || (out_features / 3) % 128 != 0) return HFL_EINVAL;
+  return x3_launch(out, x_split2, w_split2, bias, nullptr, n_rows, in_features, out_features, 2, q_scale, stream);
+}
+
+static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                     const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
+                     float q_scale, hfl_stream_t stream) {
+  const int gelu_split_out = epi == 1;
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
   if (in_features % 32 != 0 || out_features % XT != 0) return HFL_EINVAL;
   if (out == nullptr || x_split2 == nullptr || w_split2 == nullptr) return HFL_EINVAL;
@@ -295,11 +335,18 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
   p.n_wg = hfl_cdiv(n_rows, XT) * p.tiles_n;
   p.dbg = g_x3_dbg;
   p.nt = g_x3_nt;
+  p.qk_channels = out_features / 3;
+  p.q_scale = q_scale;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
   const size_t lds = (size_t)STAGE_B;              // 32 KiB: 3 workgroups per CU
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e;
-  if (gelu_split_out) {
+  if (epi == 2) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    gemm_x3_kernel<2><<<(unsigned)p.n_wg, 256, lds, s>>>(p);
+  } else if (gelu_split_out) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -87,6 +87,7 @@ _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 _TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
 # training-path Linear layers on the hand-written split GEMM (autograd.LinearX3Fn: forward + dx; dW stays fp32)
 _TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
+_ATTN_F16 = os.environ.get('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
@@ -101,6 +102,12 @@ def set_train_x3(enabled: bool):
     """Training-path Linear layers through `autograd.LinearX3Fn` (default on in GEMM mode 'x3')."""
     global _TRAIN_X3
     _TRAIN_X3 = bool(enabled)
+
+
+def set_attention_f16(enabled: bool):
+    """Window attention on the fp16 (hi, lo) MFMA kernel (qkv written as its operands by the projection GEMM)."""
+    global _ATTN_F16
+    _ATTN_F16 = bool(enabled)
 
 
 def set_pyramid_streams(enabled: bool):
@@ -401,7 +408,7 @@ class OctreeAttention(nn.Module):
         self.proj = SplitLinear(dim, dim)
         self.rpe = RPE(patch_size, num_heads, dilation) if use_rpe else None
 
-    def core(self, qkv, plan: WindowPlan, depth: int, qkv_bias=None, out_split=False):
+    def core(self, qkv, plan: WindowPlan, depth: int, qkv_bias=None, out_split=False, qkv_f16=False):
         nt = plan.n_tokens[depth]
         cfg = dict(n_tokens=nt, n_windows=plan.n_windows[depth], patch_size=self.patch_size,
                    dilation=self.dilation, n_relay=self.rt_per_window, n_heads=self.num_heads,
@@ -410,7 +417,7 @@ class OctreeAttention(nn.Module):
         if _grad_path(qkv):
             return ag.window_attention(qkv, table, plan.meta[depth], **cfg)
         return ops.window_attention(qkv, plan.meta[depth], table, qkv_bias=qkv_bias,
-                                    out_split=out_split, **cfg)
+                                    out_split=out_split, qkv_f16=qkv_f16, **cfg)
 
     def forward(self, x, plan: WindowPlan, depth: int):
         """x: (N_t [+ W], C) token rows [followed by the relay-token rows]."""
@@ -420,6 +427,11 @@ class OctreeAttention(nn.Module):
         """LN1 -> qkv -> attention, split-precision path; returns the bf16 operand of `proj`."""
         if _GEMM_MODE == 'x3':         # qkv bias folded into the GEMM epilogue, attention writes split2 rows
             a2 = ops.layer_norm_split2(x, norm1.weight, norm1.bias, norm1.eps)
+            if _ATTN_F16 and ops.window_attention_f16_ok(x.shape[0], self.patch_size, self.dilation,
+                                                         self.rt_per_window, self.num_heads, depth):
+                # the projection writes q, k, v as fp16 (hi, lo) MFMA operands (q pre-scaled): fp16-MFMA window kernel
+                qkv = ops.linear_x3_qkv(a2, _w2(self.qkv), self.qkv.bias, 16 ** -0.5 * 1.4426950408889634)
+                return self.core(qkv, plan, depth, out_split=2, qkv_f16=True)
             qkv = ops.linear_x3(a2, _w2(self.qkv), bias=self.qkv.bias)
             return self.core(qkv, plan, depth, out_split=2)
         a3 = ops.layer_norm_split3(x, norm1.weight, norm1.bias, norm1.eps)

@@ -392,6 +392,30 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
     return out
 
 
+def linear_x3_qkv(x2: torch.Tensor, w2: torch.Tensor, bias, q_scale: float) -> torch.Tensor:
+    """qkv projection into the fp16 (hi, lo) operand layout of the v5 window-attention kernel (hfl_linear_x3_qkv):
+    returns an opaque (rows, 3C) float32-sized buffer for `window_attention(..., qkv_f16=True)`."""
+    _dev(x2, w2, bias)
+    assert x2.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x2.is_contiguous() and w2.is_contiguous()
+    m, k2 = x2.shape
+    n = w2.shape[0]
+    assert w2.shape[1] == k2 and n % 3 == 0
+    out = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+    with _timed('hfl_linear_x3', m * (k2 // 2) * 4 + m * n * 4, 2 * m * (k2 // 2) * n):
+        check(_native.load().hfl_linear_x3_qkv(out.data_ptr(), x2.data_ptr(), w2.data_ptr(),
+                                               None if bias is None else _f32c(bias).data_ptr(), m, k2 // 2, n,
+                                               float(q_scale), _stream()), 'hfl_linear_x3_qkv')
+    return out
+
+
+def window_attention_f16_ok(n_rows: int, patch_size: int, dilation: int, n_relay: int, n_heads: int, depth: int) -> bool:
+    """Whether the window kernel takes the fp16 (hi, lo) qkv layout for this launch (else: fp32 qkv)."""
+    desc = WindowAttnDesc(n_tokens=n_rows, rt_row0=0, n_windows=1, patch_size=patch_size, dilation=dilation,
+                          n_relay=n_relay, n_heads=n_heads, pos_bnd=int(0.8 * patch_size * dilation ** 0.5),
+                          batch_size=1, scale=16 ** -0.5, depth=depth)
+    return bool(_native.load().hfl_window_attention_f16_ok(ctypes.byref(desc), int(n_rows)))
+
+
 def stack3(x: torch.Tensor, order: str) -> torch.Tensor:
     """(M, C) fp32 -> (3M, C) bf16 planes stacked along the rows: 'hhl' = [hi; hi; lo], 'hlh' = [hi; lo; hi]
     (operands of `gemm_bf16_tn`, the contraction runs over the rows)."""
@@ -476,9 +500,10 @@ def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int):
 
 def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, patch_size: int,
                      dilation: int, n_relay: int, n_heads: int, batch_size: int, rt_row0: int = 0,
-                     depth: int = 0, qkv_bias=None, out_split: bool = False):
+                     depth: int = 0, qkv_bias=None, out_split: bool = False, qkv_f16: bool = False):
     """qkv (rows, 3*H*16) -> out (rows, H*16) fp32, or with out_split the bf16 [hi|hi|lo]
-    (rows, 3*H*16) operand of the projection GEMM; qkv_bias is added to q,k,v on load.
+    (rows, 3*H*16) operand of the projection GEMM; qkv_bias is added to q,k,v on load.  qkv_f16: `qkv` is the
+    fp16 (hi, lo) operand buffer of `linear_x3_qkv` (bias and softmax scale already folded in).
     See hfl_window_attention_fwd(_ex)."""
     _dev(qkv, tok_meta, rpe_table, qkv_bias)
     qkv = _f32c(qkv)
@@ -514,7 +539,7 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
                 moved=used * c * (18 if out_split == 1 else 16) + n_tokens * 8):
         check(_native.load().hfl_window_attention_fwd_ex(
             out.data_ptr(), qkv.data_ptr(), None if qkv_bias is None else _f32c(qkv_bias).data_ptr(),
-            tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), out_split, _stream()),
+            tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), out_split | (0x100 if qkv_f16 else 0), _stream()),
             'hfl_window_attention_fwd')
     return out
 

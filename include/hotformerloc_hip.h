@@ -206,6 +206,9 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
 /* As hfl_window_attention_fwd, for the split-precision Linear path: qkv comes from a bias-free GEMM
  * and `qkv_bias` (3*H*16) is added to q, k, v on load (NULL = none); with out_split3 != 0 `out` is the
  * bf16 A operand [hi | hi | lo] (rows, 3*H*16) of the output projection (section 9). */
+/* 1 when hfl_window_attention_fwd_ex takes the fp16 (hi, lo) qkv layout of hfl_linear_x3_qkv for this configuration
+ * (`out_split3 | 0x100`; depth <= 5 with coordinates inside pos_bnd, <= 72 KiB of LDS), else 0: use fp32 qkv. */
+int hfl_window_attention_f16_ok(const hfl_window_attn_desc* desc, int64_t n_rows_total);
 int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
                                 const uint32_t* tok_meta, const float* rpe_table,
                                 const hfl_window_attn_desc* desc, int out_split3, hfl_stream_t stream);
@@ -347,6 +350,13 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream);
 int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* The qkv projection written straight into the operand layout of the fp16-MFMA window attention kernel
+ * (hfl_window_attention_fwd_ex with flag 0x100): out (n_rows, out_features) 4-byte cells, every row = [Q | K | V] regions
+ * of C = out_features / 3 features, per head 16 dims stored as [16 x hi | 16 x lo] fp16 (hi = RTZ(v), lo = RTZ(v - hi):
+ * 22 significant bits) = 64 B, v = acc + bias, the queries multiplied by q_scale (softmax scale * log2 e).
+ * Replaces qkv = Linear(x) + the reshape/permute of models/octformer_backbone.py:70-73.  C % 128 == 0. */
+int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                      int64_t n_rows, int in_features, int out_features, float q_scale, hfl_stream_t stream);
 /* split2(LayerNorm(x)) in one pass (the LayerNorm in front of qkv / fc1: models/octformer_backbone.py:275-278) */
 int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, const float* beta,
                           int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);

@@ -280,6 +280,39 @@ def _plans(clouds, cfg, octree_depth):
     return params, ref, dev, hotformer_ref.WindowPlan(ref, **args), WindowPlan(dev, **args)
 
 
+def _pack_qkv_f16(qkv: torch.Tensor, H: int, q_scale: float) -> torch.Tensor:
+    """fp32 (rows, 3C) [q | k | v] -> the operand layout of hfl_linear_x3_qkv (csrc/gemm_x3.hip EPI 2): per region and
+    head [16 x hi | 16 x lo] fp16 (any split with hi + lo = v to 22 bits is valid), q times q_scale; returned as an
+    opaque float32 (rows, 3C) buffer."""
+    rows, c3 = qkv.shape
+    C = c3 // 3
+    x = qkv.clone().float()
+    x[:, :C] *= q_scale
+    x = x.view(rows, 3, H, 16)
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    packed = torch.stack([hi, lo], dim=3).contiguous()            # (rows, 3, H, 2, 16) fp16 = 12 C bytes per row
+    return packed.view(rows, -1).view(torch.float32).view(rows, c3).contiguous()
+
+
+def test_linear_x3_qkv_epilogue_writes_the_attention_operand_layout():
+    """hfl_linear_x3_qkv == split(hfl_linear_x3 output) in the layout `_pack_qkv_f16` describes: hi + lo reproduces the
+    fp32 projection (queries scaled) to fp16-pair precision."""
+    g = torch.Generator().manual_seed(31)
+    for n, C, H in ((777, 128, 8), (1300, 256, 16)):
+        x = torch.randn(n, C, generator=g)
+        w = torch.randn(3 * C, C, generator=g) * 0.08
+        b = torch.randn(3 * C, generator=g) * 0.1
+        x2, w2 = ops.split2(x.to(DEV)), ops.split2_weight(w.to(DEV))
+        ref = ops.linear_x3(x2, w2, bias=b.to(DEV)).cpu()
+        ref[:, :C] *= 0.36
+        got = ops.linear_x3_qkv(x2, w2, b.to(DEV), 0.36).cpu()
+        halves = got.view(torch.float16).view(n, 3, H, 2, 16).float()
+        rec = (halves[:, :, :, 0] + halves[:, :, :, 1]).reshape(n, 3 * C)
+        assert (rec - ref).abs().max().item() <= 2 ** -20 * ref.abs().max().item() + 1e-7
+        assert (halves[:, :, :, 1].abs() <= halves[:, :, :, 0].abs() * 2 ** -9 + 1e-6).all()      # lo is the residual
+
+
 @pytest.mark.parametrize('cfg,sizes', [('wild-places', [4096, 30, 2500]), ('cs-wild-places', [5000, 3000])])
 def test_window_attention_matches_oracle(cfg, sizes):
     clouds = [syn.unit_ball_cloud(500 + i, n) for i, n in enumerate(sizes)]
@@ -332,6 +365,28 @@ def test_window_attention_matches_oracle(cfg, sizes):
             err = (got[nt:nt + real] - want[:real, 0]).abs().max().item()
             assert err < 2e-5, ('relay rows', cfg, depth, err)
             assert torch.isfinite(got).all()
+        # fp16 (hi, lo) operand layout + fp16-MFMA kernel (v5), where the launch configuration is eligible
+        rows_all = nt + W
+        if ops.window_attention_f16_ok(rows_all, K, dil, G, H, depth):
+            packed = _pack_qkv_f16(torch.cat([qkv_tok, qkv_rt]), H, 0.25 * 1.4426950408889634).to(DEV)
+            for tbl in (table.to(DEV), None):
+                got5 = ops.window_attention(packed, plan.meta[depth], tbl, nt, W, K, dil, G, H, B, rt_row0=nt,
+                                            depth=depth, qkv_f16=True).cpu()
+                ref5 = want_tok if tbl is not None else oplan.from_windows(
+                    hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(-1, K + G, C)[:, G:],
+                    depth, dil > 1)
+                err = (got5[:nt] - ref5).abs().max().item()
+                assert err < 3e-5, ('fp16 layout', cfg, depth, G, dil, tbl is None, err)
+                if G and tbl is not None:
+                    real_w = -(-nt // K)
+                    assert (got5[nt:nt + real_w] - want[:real_w, 0]).abs().max().item() < 3e-5
+                    assert torch.isfinite(got5).all()
+            got5s = ops.window_attention(packed, plan.meta[depth], table.to(DEV), nt, W, K, dil, G, H, B, rt_row0=nt,
+                                         depth=depth, qkv_f16=True, out_split=2).float().cpu().view(rows_all, C // 32, 2, 32)
+            rec5 = (got5s[:, :, 0] + got5s[:, :, 1]).reshape(rows_all, C)
+            assert (rec5[:nt] - want_tok).abs().max().item() < 4e-5
+        else:
+            assert depth == 5 or G == 0 or K == 64, 'the pyramid depths of the shipped configs must be eligible'
         # no RPE (disable_RPE=True path)
         want0 = hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(-1, K + G, C)
         for dd in (0, depth):
