@@ -39,8 +39,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int XT = 128;                  // tile edge (rows and features)
-constexpr int TILE_B = XT * 128;         // one operand tile per stage: 128 rows x 128 B (32 hi + 32 lo bf16)
-constexpr int STAGE_B = 2 * TILE_B;      // x tile | w tile
 
 struct X3Params {
   void* out;                // EPI 0: float (M, N); EPI 1: bf16 split2 (M, N/32, 2, 32)
@@ -55,10 +53,11 @@ struct X3Params {
   int qk_channels;          // EPI 2: C (= out_features / 3); features < C are queries
   float q_scale;            // EPI 2: factor folded into the queries (softmax scale * log2 e)
   int nt;                   // bit 0: non-temporal stores of the f32 output, bit 1: of the split2 output
-  int dbg;                  // ablation bits (tools/x3_probe.py): 1 no in-loop DMA, 2 no MFMA, 4 no stores, 8 no LDS reads
+  int dbg;                  // unused (kept for the probe tools)
 };
 
 static int g_x3_dbg = 0;
+static int g_x3_mt = 0;      // 8: force the 256-row tile (tools/x3_ablate.py); anything else: 128-row tile
 static int g_x3_nt = 0;     // measured: no end-to-end difference (the consumer kernel re-reads the output anyway)
 
 __device__ __forceinline__ uint32_t x3_bf16_rne(float v) {
@@ -86,10 +85,15 @@ __device__ __forceinline__ float x3_gelu(float v) {
 // EPI 2: out = the window-attention operand layout of acc + bias (qkv projection): per row [Q | K | V] regions of C
 //        features, per head 16 dims as [16 x hi | 16 x lo] fp16 (hi = RTZ(v), lo = RTZ(v - hi): 22 significant bits), the
 //        queries pre-multiplied by q_scale -- csrc/attention.hip, window_attn_kernel_v5 loads these as MFMA fragments
-template <int EPI>
-__global__ void __launch_bounds__(256, 3)
+// MT = 16-row tiles of x per wave: 4 -> 128-row workgroup tile (3 workgroups / CU), 8 -> 256-row tile (2 / CU): the
+// weight tile is then shared by twice the rows, 25 % less L2 -> LDS operand traffic per MAC -- the k-loop runs at the
+// ~70 GB/s per CU an XCD's L2 serves, not at the matrix rate
+template <int EPI, int MT>
+__global__ void __launch_bounds__(256, MT == 4 ? 3 : 2)
 gemm_x3_kernel(const X3Params p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // one stage: x tile | w tile (32 KiB)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // one stage: x tile | w tile
+  constexpr int BM = 32 * MT;                                                 // rows of x per workgroup
+  constexpr int XTILE_B = BM * 128;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wm = wave & 1;
@@ -101,99 +105,92 @@ gemm_x3_kernel(const X3Params p) {
     const int64_t xcd = wg & 7, loc = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int64_t m0 = (wg / p.tiles_n) * XT;
+  const int64_t m0 = (wg / p.tiles_n) * BM;
   const int n0 = (int)(wg % p.tiles_n) * XT;
   const int K = p.K;
   const int nk = K >> 5;
   const int64_t row_b = (int64_t)K * 4;                       // bytes per split2 row (2K bf16)
 
-  // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per instruction ------------------------
+  // ---- staging: wave w moves rows [8 MT w, 8 MT (w+1)) of the x tile and [32w, 32w+32) of the w tile, 8 rows per
+  // instruction
   // lane -> (row within the 8, physical slot); the slot it fills holds logical chunk t = slot ^ ((row >> 1) & 7)
   const int srow = lane >> 3, sslot = lane & 7;
   // uniform tile bases (SGPRs) + 32-bit per-lane offsets: tail rows fetch the last valid row, never stored
   const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
-  const int rows_valid = (int)((p.M - m0) < XT ? (p.M - m0) : XT);
-  uint32_t xoff[4], woff[4];
+  const int rows_valid = (int)((p.M - m0) < BM ? (p.M - m0) : BM);
+  uint32_t xoff[MT], woff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + srow;
+  for (int i = 0; i < MT; ++i) {
+    const int row = wave * (8 * MT) + i * 8 + srow;
     const int t = sslot ^ ((row >> 1) & 7);
     const int xr = row < rows_valid ? row : rows_valid - 1;
     xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
-    woff[i] = (uint32_t)row * (uint32_t)row_b + t * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + srow;
+    woff[i] = (uint32_t)row * (uint32_t)row_b + (sslot ^ ((row >> 1) & 7)) * 16;
   }
   auto stage = [&](int kt) {
-    unsigned char* sb = smem + (wave * 32) * 128;
     const unsigned char* xk = xbase + (int64_t)kt * 128;
     const unsigned char* wk = wbase + (int64_t)kt * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MT; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
-                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(smem + (wave * (8 * MT) + i * 8) * 128),
+                                       16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
-                                       (__attribute__((address_space(3))) void*)(sb + TILE_B + i * 1024), 16, 0, 0);
-    }
+                                       (__attribute__((address_space(3))) void*)(smem + XTILE_B + (wave * 32 + i * 8) * 128),
+                                       16, 0, 0);
   };
 
   // ---- fragment addresses (bytes inside the stage): row = base + 16 i + (lane & 15), chunk q = lane >> 4 --------
   const int frow = lane & 15, fq = lane >> 4;
-  int offw_hi[4], offx_hi[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rn = wn * 64 + i * 16 + frow;
-    const int rm = wm * 64 + i * 16 + frow;
-    offw_hi[i] = TILE_B + rn * 128 + ((fq ^ ((rn >> 1) & 7)) << 4);
-    offx_hi[i] = rm * 128 + ((fq ^ ((rm >> 1) & 7)) << 4);
-  }
+  // (16 i rows further on the swizzle term (row >> 1) & 7 is the same: one base per operand, immediates for i)
+  const int rn0 = wn * 64 + frow, rm0 = wm * (16 * MT) + frow;
+  const int offw_hi = XTILE_B + rn0 * 128 + ((fq ^ ((rn0 >> 1) & 7)) << 4), offw_lo = offw_hi ^ 64;
+  const int offx_hi = rm0 * 128 + ((fq ^ ((rm0 >> 1) & 7)) << 4), offx_lo = offx_hi ^ 64;
   // the lo chunk is logical slot 4 + q: physical slot differs from the hi one in bit 2 only -> byte offset ^ 64
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][MT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // One LDS stage, two barriers per k-step: once every wave holds the step's 16 fragments in registers the stage is
   // free again, so the DMA of step t+1 is issued BEFORE the 48 MFMAs of step t and lands while they run.
   stage(0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                       // drains this wave's LDS-DMA (vmcnt) and publishes the stage
-    bf16x8 wh[4], wl[4], xh[4], xl[4];
-    if (p.dbg & 8) {
+    bf16x8 wh[4], wl[4], xh[MT], xl[MT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wh[i] = wl[i] = xh[i] = xl[i] = (bf16x8){(short)kt, 1, 2, 3, 4, 5, 6, (short)lane};
-        asm volatile("" : "+v"(wh[i]), "+v"(wl[i]), "+v"(xh[i]), "+v"(xl[i]));
-      }
-    } else {
+    for (int i = 0; i < 4; ++i) {
+      wh[i] = *reinterpret_cast<const bf16x8*>(smem + offw_hi + i * 2048);
+      wl[i] = *reinterpret_cast<const bf16x8*>(smem + offw_lo + i * 2048);
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wh[i] = *reinterpret_cast<const bf16x8*>(smem + offw_hi[i]);
-        wl[i] = *reinterpret_cast<const bf16x8*>(smem + (offw_hi[i] ^ 64));
-        xh[i] = *reinterpret_cast<const bf16x8*>(smem + offx_hi[i]);
-        xl[i] = *reinterpret_cast<const bf16x8*>(smem + (offx_hi[i] ^ 64));
-      }
+    for (int j = 0; j < MT; ++j) {
+      xh[j] = *reinterpret_cast<const bf16x8*>(smem + offx_hi + j * 2048);
+      xl[j] = *reinterpret_cast<const bf16x8*>(smem + offx_lo + j * 2048);
     }
     __syncthreads();                       // every wave has its fragments (lgkmcnt(0) precedes the barrier)
-    if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1);
-    if (p.dbg & 2) {
+    if (kt + 1 < nk) stage(kt + 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(wh[i]), "v"(wl[i]), "v"(xh[i]), "v"(xl[i]));
-    } else {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
-        }
-    }
+      for (int j = 0; j < MT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+      }
   }
   // ---- epilogue -------------------------------------------------------------------------------------------------
   // The accumulator holds features n..n+3 (registers) of row m = lane & 15: stored as is, a 128-B line would be
-  // written in two halves by different instructions.  Each wave transposes its 64 x 64 tile through a private 8 KiB
+  // written in two halves by different instructions.  Each wave transposes its (16 MT) x 64 tile through a private 8 KiB
   // LDS region, 32 rows at a time (16-B chunks XOR-swizzled by the row: conflict-free both ways), and reads it back so
   // that 16 consecutive lanes hold 256 contiguous bytes of one output row: every store instruction writes whole lines.
   const int N = p.N;
@@ -203,7 +200,7 @@ gemm_x3_kernel(const X3Params p) {
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + nbase);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < MT / 2; ++h) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -215,9 +212,8 @@ gemm_x3_kernel(const X3Params p) {
     for (int it = 0; it < 8; ++it) {
       const int r = it * 4 + fq;                                              // row inside the 32
       const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ (r & 15)) << 4));
-      const int64_t m = m0 + wm * 64 + h * 32 + r;
+      const int64_t m = m0 + wm * (16 * MT) + h * 32 + r;
       if (m >= p.M) continue;
-      if ((p.dbg & 4) && a[0] != 1234.5f) continue;
       float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
       if (EPI == 0) {
         if (p.residual != nullptr) {
@@ -298,7 +294,8 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, int64_t n
 extern "C" {
 
 void hfl_internal_set_x3_dbg(int v) {
-  if (v >= 0x100) g_x3_nt = v & 3;          // 0x100 | nt bits
+  if (v >= 0x200) g_x3_mt = v & 15;         // 0x200 | 0 / 4 / 8
+  else if (v >= 0x100) g_x3_nt = v & 3;     // 0x100 | nt bits
   else g_x3_dbg = v;
 }
 
@@ -332,31 +329,31 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual;
   p.M = n_rows; p.N = out_features; p.K = in_features;
   p.tiles_n = out_features / XT;
-  p.n_wg = hfl_cdiv(n_rows, XT) * p.tiles_n;
+  // 128-row tiles (3 workgroups per CU).  The 256-row instantiation moves 25 % fewer operand bytes per flop but holds
+  // 256 VGPRs (2 workgroups per CU) and measured 10 - 120 % slower on every shape of the model (tools/x3_ablate.py,
+  // DESIGN.md); it is only reachable through the probe knob.
+  const int mt = g_x3_mt == 8 ? 8 : 4;
+  p.n_wg = hfl_cdiv(n_rows, 32 * mt) * p.tiles_n;
   p.dbg = g_x3_dbg;
   p.nt = g_x3_nt;
   p.qk_channels = out_features / 3;
   p.q_scale = q_scale;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
-  const size_t lds = (size_t)STAGE_B;              // 32 KiB: 3 workgroups per CU
+  const size_t lds = (size_t)(32 * mt + XT) * 128;                 // one stage: x tile | w tile (32 or 48 KiB)
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e;
-  if (epi == 2) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    gemm_x3_kernel<2><<<(unsigned)p.n_wg, 256, lds, s>>>(p);
-  } else if (gelu_split_out) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    gemm_x3_kernel<1><<<(unsigned)p.n_wg, 256, lds, s>>>(p);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<0>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    gemm_x3_kernel<0><<<(unsigned)p.n_wg, 256, lds, s>>>(p);
+#define HFL_X3_LAUNCH(E, M)                                                                              \
+  {                                                                                                      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<E, M>),              \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+    if (e != hipSuccess) return (int)e;                                                                  \
+    gemm_x3_kernel<E, M><<<(unsigned)p.n_wg, 256, lds, s>>>(p);                                          \
   }
+  if (mt == 8) {
+    if (epi == 2) HFL_X3_LAUNCH(2, 8) else if (epi == 1) HFL_X3_LAUNCH(1, 8) else HFL_X3_LAUNCH(0, 8)
+  } else {
+    if (epi == 2) HFL_X3_LAUNCH(2, 4) else if (epi == 1) HFL_X3_LAUNCH(1, 4) else HFL_X3_LAUNCH(0, 4)
+  }
+#undef HFL_X3_LAUNCH
   HFL_RETURN_LAST_ERROR();
 }
 

@@ -63,6 +63,8 @@ def _ln(x, m: nn.LayerNorm):
     """LayerNorm over channels: HIP kernel in inference, torch (autograd) when grads are needed."""
     if x.is_cuda and not _grad_path(x):
         return ops.layer_norm(x, m.weight, m.bias, m.eps)
+    if x.is_cuda and _TRAIN_LN and x.numel() > 0 and x.shape[-1] in ops._LN_CHANNELS and x.dtype == torch.float32:
+        return ag.layer_norm(x, m.weight, m.bias, m.eps)            # HIP forward + backward
     return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
 
 
@@ -71,7 +73,7 @@ def _add_ln(x, y, m: nn.LayerNorm):
     if x.is_cuda and not _grad_path(x):
         return ops.add_layer_norm(x, y, m.weight, m.bias, m.eps)
     x = x + y
-    return x, F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+    return x, _ln(x, m)
 
 
 # ---- Linear layers: 'fp32' = hipBLASLt fp32 GEMM; 'bf16x3' = one bf16 GEMM over K-concatenated
@@ -88,6 +90,7 @@ _TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
 # training-path Linear layers on the hand-written split GEMM (autograd.LinearX3Fn: forward + dx; dW stays fp32)
 _TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
 _ATTN_F16 = os.environ.get('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
+_TRAIN_LN = os.environ.get('HFL_TRAIN_LN', '1') != '0'    # training-path LayerNorm: HIP forward + backward kernels
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
@@ -177,6 +180,17 @@ class SplitLinear(nn.Linear):
                 and self.in_features % 8 == 0 and self.out_features % 8 == 0 and x.numel() > 0):
             return ag.linear_split(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)
+
+
+_TAP_STREAMS = int(os.environ.get('HFL_TAP_STREAMS', '1'))       # >1: per-tap GEMMs on a stream pool (measured neutral)
+_TAP_POOLS = {}
+
+
+def _tap_stream_pool(device):
+    key = (device.type, device.index)
+    if key not in _TAP_POOLS:
+        _TAP_POOLS[key] = [torch.cuda.Stream(device=device) for _ in range(_TAP_STREAMS)]
+    return _TAP_POOLS[key]
 
 
 def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
@@ -270,10 +284,22 @@ class OctreeConv(nn.Module):
         g = ops.octree_gather(data, src)                                  # (P, Cin)
         part = torch.empty((g.shape[0], self.out_channels), dtype=torch.float32, device=data.device)
         w = self.weights
-        for k in range(self.kdim):
-            a, b = edges[k], edges[k + 1]
-            if b > a:
-                torch.mm(g[a:b], w[k], out=part[a:b])
+        live = [k for k in range(self.kdim) if edges[k + 1] > edges[k]]
+        if _TAP_STREAMS > 1 and len(live) > 2:
+            # the per-tap GEMMs are small (thousands of rows each) and independent: deal them over a few HIP streams so
+            # that they overlap instead of running one 10-us launch after another
+            main = torch.cuda.current_stream()
+            pool = _tap_stream_pool(data.device)
+            for st in pool:
+                st.wait_stream(main)
+            for i, k in enumerate(live):
+                with torch.cuda.stream(pool[i % len(pool)]):
+                    torch.mm(g[edges[k]:edges[k + 1]], w[k], out=part[edges[k]:edges[k + 1]])
+            for st in pool:
+                main.wait_stream(st)
+        else:
+            for k in live:
+                torch.mm(g[edges[k]:edges[k + 1]], w[k], out=part[edges[k]:edges[k + 1]])
         ones = self.__dict__.get('_unit_taps')
         if ones is None or ones.device != data.device:
             ones = torch.ones((self.kdim, 1, self.out_channels), dtype=torch.float32, device=data.device)
@@ -376,8 +402,7 @@ class CPE(nn.Module):
                 return out
             return y
         if _grad_path(data):      # dwconv (HIP fwd/bwd, libs/dwconv semantics) -> LayerNorm -> residual
-            y = hdw.octree_dwconv(data, self.conv.weights, plan.neigh(depth))
-            y = F.layer_norm(y, self.norm.normalized_shape, self.norm.weight, self.norm.bias, self.norm.eps)
+            y = _ln(hdw.octree_dwconv(data, self.conv.weights, plan.neigh(depth)), self.norm)
             return data + y if residual else y
         return ops.cpe_forward(data, self.conv.weights, self.norm.weight, self.norm.bias,
                                plan.neigh(depth), residual, self.norm.eps, out=out)
@@ -439,6 +464,11 @@ class OctreeAttention(nn.Module):
                          out_split=True)
 
 
+def _drops(block) -> bool:
+    """Stochastic depth is live (train mode, non-zero probability): the fused inference paths do not apply it."""
+    return block.training and block.drop_path.drop_prob > 0.0
+
+
 def _init_layer_scale(block, dim, layer_scale):
     """`gamma1` / `gamma2`: learnable channel-wise multipliers of the attention / MLP branches when `layer_scale` is a
     number (models/octformer_backbone.py:214-229), the constant 1 otherwise (not parameters then, as in the reference)."""
@@ -466,7 +496,7 @@ class OctFormerBlock(nn.Module):
 
     def forward(self, x, plan: WindowPlan, depth: int):
         x = self.cpe(x, plan, depth, residual=True)
-        if _split_path(x) and not self.use_layer_scale:
+        if _split_path(x) and not self.use_layer_scale and not _drops(self):
             o3 = self.attention.forward_split(x, self.norm1, plan, depth)
             return _block_tail_split(x, o3, self.attention, self.norm2, self.mlp)
         if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
@@ -523,7 +553,7 @@ class HOTFormerBlock(nn.Module):
             self.cpe(buf[:nt], plan, depth, residual=True, out=new[:nt])
             new[nt:].copy_(buf[nt:] if relay is None else relay)
             buf = new
-        if _split_path(buf) and not self.use_layer_scale:
+        if _split_path(buf) and not self.use_layer_scale and not _drops(self):
             o3 = self.attention.forward_split(buf, self.norm1, plan, depth)
             return _block_tail_split(buf, o3, self.attention, self.norm2, self.mlp)
         if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
@@ -567,7 +597,7 @@ class RelayTokenTransformerBlock(nn.Module):
         _init_layer_scale(self, dim, layer_scale)                       # hotformerloc_backbone.py:260-272
 
     def forward(self, rt, plan):
-        if _GEMM_MODE == 'x3' and _split_path(rt) and not self.use_layer_scale and rt.shape[0] > 0:
+        if _GEMM_MODE == 'x3' and _split_path(rt) and not self.use_layer_scale and not _drops(self) and rt.shape[0] > 0:
             att = self.rt_attention
             a2 = ops.layer_norm_split2(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             qkv = ops.linear_x3(a2, _w2(att.qkv), bias=att.qkv.bias)

@@ -171,13 +171,30 @@ def layer_norm(x, weight, bias, eps: float = 1e-5):
     """LayerNorm over the last axis of a (..., C) fp32 tensor (HIP kernel, one pass)."""
     _dev(x, weight, bias)
     c = x.shape[-1]
-    x2 = _f32c(x).view(-1, c)
-    out = torch.empty_like(x2)
-    with _timed('hfl_layer_norm', x2.numel() * 8):
-        check(_native.load().hfl_layer_norm(out.data_ptr(), x2.data_ptr(), weight.data_ptr(),
-                                            bias.data_ptr(), x2.shape[0], c, float(eps), _stream()),
+    xc = _f32c(x)
+    out = torch.empty_like(xc)                  # not a view: autograd Functions return it as it is
+    with _timed('hfl_layer_norm', xc.numel() * 8):
+        check(_native.load().hfl_layer_norm(out.data_ptr(), xc.data_ptr(), weight.data_ptr(),
+                                            bias.data_ptr(), xc.numel() // c, c, float(eps), _stream()),
               'hfl_layer_norm')
-    return out.view(x.shape)
+    return out
+
+
+def layer_norm_bwd(dy, x, weight, eps: float = 1e-5):
+    """(dx, dgamma, dbeta) of LayerNorm over the last axis (hfl_layer_norm_bwd; statistics recomputed from x)."""
+    _dev(dy, x, weight)
+    c = x.shape[-1]
+    x2, dy2 = _f32c(x).view(-1, c), _f32c(dy).view(-1, c)
+    lib = _native.load()
+    nb = int(lib.hfl_layer_norm_bwd_blocks(x2.shape[0], c))
+    if nb <= 0:
+        raise _native.NativeLibraryError('hfl_layer_norm_bwd: unsupported channel count %d' % c)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    part = torch.empty((2, nb, c), dtype=torch.float32, device=x.device)
+    check(lib.hfl_layer_norm_bwd(dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), dy2.data_ptr(), x2.data_ptr(),
+                                 _f32c(weight).data_ptr(), x2.shape[0], c, float(eps), _stream()), 'hfl_layer_norm_bwd')
+    sums = part.sum(1)
+    return dx, sums[0], sums[1]
 
 
 def add_layer_norm(x, y, weight, bias, eps: float = 1e-5, add_bias=None, inplace: bool = False):

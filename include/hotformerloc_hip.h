@@ -391,6 +391,14 @@ int hfl_relay_token_init_bwd(float* dx, const float* drt, const uint32_t* tok_me
                              int32_t n_windows, int32_t patch_size, int64_t channels,
                              hfl_stream_t stream);
 
+/* Gradient of LayerNorm over the channel axis (training path; replaces torch's native_layer_norm_backward behind
+ * the LayerNorms of models/octformer_backbone.py:275-278 etc.): dx (n_rows, C); dgamma_partial / dbeta_partial
+ * (hfl_layer_norm_bwd_blocks(n_rows, C), C) per-workgroup partial sums the caller adds up (fixed order, no atomics).
+ * Statistics are recomputed from x. */
+int hfl_layer_norm_bwd_blocks(int64_t n_rows, int64_t channels);
+int hfl_layer_norm_bwd(float* dx, float* dgamma_partial, float* dbeta_partial, const float* dy, const float* x,
+                       const float* gamma, int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 11. TruncatedSmoothAP ranking core (replaces the (B,P,B) tensor algebra of
  *     models/losses/truncated_smoothap.py:44-93 and its autograd graph)

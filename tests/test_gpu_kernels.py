@@ -716,3 +716,30 @@ def test_relay_attention_backward():
     assert torch.allclose(out.detach(), ag.relay_attention_torch(a.detach(), plan, 16), atol=2e-5)
     scale = a.grad.abs().max().item()
     assert (a.grad - b.grad).abs().max().item() < 3e-5 * max(scale, 1.0)
+
+
+def test_layer_norm_backward_matches_torch_autograd():
+    """hfl_layer_norm_bwd (dx, dgamma, dbeta; statistics recomputed from x) against torch autograd in float64."""
+    from hotformerloc_amd import autograd as ag
+    g = torch.Generator().manual_seed(41)
+    for n, C in ((1000, 128), (777, 256), (50, 32), (300, 64), (9, 1024), (33, 512), (5, 16), (70001, 256)):
+        x = (torch.randn(n, C, generator=g) * 3 + 0.5)
+        w = 1 + 0.1 * torch.randn(C, generator=g)
+        b = 0.1 * torch.randn(C, generator=g)
+        dy = torch.randn(n, C, generator=g)
+        xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+        torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5).backward(dy.double())
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+        y = ag.layer_norm(xd, wd, bd, 1e-5)
+        assert torch.allclose(y.detach().cpu(), torch.nn.functional.layer_norm(x, (C,), w, b, 1e-5), atol=3e-6, rtol=1e-5)
+        y.backward(dy.to(DEV))
+        assert (xd.grad.cpu().double() - xr.grad).abs().max().item() < 2e-5 * max(xr.grad.abs().max().item(), 1.0), (n, C)
+        for got, want in ((wd.grad, wr.grad), (bd.grad, br.grad)):
+            err = (got.cpu().double() - want).abs().max().item()
+            assert err < 1e-5 * max(want.abs().max().item(), 1.0) * max(1.0, (n / 1000) ** 0.5), (n, C, err)
+    # determinism: fixed-order partial sums
+    xd = torch.randn(5000, 256, generator=g).to(DEV); dyd = torch.randn(5000, 256, generator=g).to(DEV)
+    wd = torch.ones(256, device=DEV)
+    a = ops.layer_norm_bwd(dyd, xd, wd)
+    b2 = ops.layer_norm_bwd(dyd, xd, wd)
+    assert all(torch.equal(u, v) for u, v in zip(a, b2))
