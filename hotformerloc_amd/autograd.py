@@ -240,36 +240,36 @@ def linear_x3_ok(in_features: int, out_features: int) -> bool:
 
 
 class LinearX3Fn(torch.autograd.Function):
-    """y = x W^T + b on `hfl_linear_x3` (three-term bf16 split, fp32 accumulation, 4e-6 per GEMM): the forward and
-    dx = dy W run on the hand-written kernel (2.5-3x the fp32 hipBLASLt rate), dW = dy^T x stays an fp32 GEMM (its
-    contraction runs over the ~10^5 rows: a different kernel shape)."""
+    """y = x W^T + b on the hand-written split-precision kernels (three-term bf16 split, fp32 accumulation, 4e-6 per
+    GEMM): forward and dx = dy W on `hfl_linear_x3`, dW = dy^T x and db on `hfl_wgrad_x3`.  What is kept for the
+    backward is the split2 operand of x (same bytes as x)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
-        ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         ctx.shape = shape
         if x2.shape[0] == 0:
+            ctx.save_for_backward(None, weight)
             return x.new_zeros(*shape[:-1], weight.shape[0])
-        y = ops.linear_x3(ops.split2(x2), _w2_cached(weight, False), bias=bias)
-        return y.view(*shape[:-1], weight.shape[0])
+        xs = ops.split2(x2)
+        ctx.save_for_backward(xs, weight)
+        return ops.linear_x3(xs, _w2_cached(weight, False), bias=bias).view(*shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight = ctx.saved_tensors
-        dy2 = dy.reshape(-1, weight.shape[0]).contiguous()
+        xs, weight = ctx.saved_tensors
         dx = dw = db = None
-        if x2.shape[0] == 0:
+        if xs is None:
             return (torch.zeros(ctx.shape, device=dy.device), torch.zeros_like(weight),
                     torch.zeros(weight.shape[0], device=dy.device) if ctx.has_bias else None)
+        dys = ops.split2(dy.reshape(-1, weight.shape[0]).contiguous())
         if ctx.needs_input_grad[0]:
-            dx = ops.linear_x3(ops.split2(dy2), _w2_cached(weight, True)).view(ctx.shape)
-        if ctx.needs_input_grad[1]:
-            dw = torch.mm(dy2.t(), x2)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            dx = ops.linear_x3(dys, _w2_cached(weight, True)).view(ctx.shape)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or need_b:
+            dw, db = ops.wgrad_x3(dys, xs, with_bias=need_b)
         return dx, dw, db
 
 

@@ -409,6 +409,27 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
     return out
 
 
+def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):
+    """(dW, db) of y = x W^T + b from split2 operands: dW (N, K) = dy^T x, db (N) = dy summed over rows (hfl_wgrad_x3;
+    fixed reduction order)."""
+    _dev(dy2, x2)
+    assert dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous() and x2.is_contiguous()
+    m = dy2.shape[0]
+    n, k = dy2.shape[1] // 2, x2.shape[1] // 2
+    assert x2.shape[0] == m and m > 0
+    lib = _native.load()
+    nbytes = int(lib.hfl_wgrad_x3_workspace(m, n, k))
+    if nbytes <= 0:
+        raise _native.NativeLibraryError('hfl_wgrad_x3: unsupported shape (%d, %d, %d)' % (m, n, k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy2.device)
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy2.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy2.device) if with_bias else None
+    with _timed('hfl_wgrad_x3', m * (n + k) * 4, 2 * m * n * k):
+        check(lib.hfl_wgrad_x3(dw.data_ptr(), None if db is None else db.data_ptr(), dy2.data_ptr(), x2.data_ptr(),
+                               m, n, k, ws.data_ptr(), _stream()), 'hfl_wgrad_x3')
+    return dw, db
+
+
 def linear_x3_qkv(x2: torch.Tensor, w2: torch.Tensor, bias, q_scale: float) -> torch.Tensor:
     """qkv projection into the fp16 (hi, lo) operand layout of the v5 window-attention kernel (hfl_linear_x3_qkv):
     returns an opaque (rows, 3C) float32-sized buffer for `window_attention(..., qkv_f16=True)`."""

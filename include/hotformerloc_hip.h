@@ -350,6 +350,14 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream);
 int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* Weight and bias gradient of the same Linear (csrc/wgrad_x3.hip): dw (N,K) = dy^T x, db (N) = column sums of dy, both
+ * operands in the split2 layout (dy (n_rows, N) and x (n_rows, K)), three-term products, fp32 accumulation, slabs of rows
+ * reduced in a fixed order (bitwise reproducible).  Replaces autograd's fp32 GEMM + bias reduction for torch.nn.Linear in
+ * loss.backward() (training/trainer.py:335-352).  N % 128 == 0, K % 128 == 0; db may be NULL;
+ * workspace >= hfl_wgrad_x3_workspace(n_rows, N, K) bytes. */
+int64_t hfl_wgrad_x3_workspace(int64_t n_rows, int64_t out_features, int64_t in_features);
+int hfl_wgrad_x3(float* dw, float* db, const uint16_t* dy_split2, const uint16_t* x_split2, int64_t n_rows,
+                 int64_t out_features, int64_t in_features, void* workspace, hfl_stream_t stream);
 /* The qkv projection written straight into the operand layout of the fp16-MFMA window attention kernel
  * (hfl_window_attention_fwd_ex with flag 0x100): out (n_rows, out_features) 4-byte cells, every row = [Q | K | V] regions
  * of C = out_features / 3 features, per head 16 dims stored as [16 x hi | 16 x lo] fp16 (hi = RTZ(v), lo = RTZ(v - hi):
