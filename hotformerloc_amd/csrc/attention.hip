@@ -1121,14 +1121,6 @@ window_attn_kernel_v5(const WinParams p) {
           o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo[pp], phi, o, 0, 0, 0);
           o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi[pp], phi, o, 0, 0, 0);
         }
-        if (is_rt && (p.dbg & 64) && w == 2 && h == 0) {     // debug dump of the relay tile into out rows 0..63
-          float* dr = reinterpret_cast<float*>(out_b) + (size_t)lane * C;
-          dr[0] = mx; dr[1] = sum; dr[2] = inv; dr[3] = srt; dr[4] = o[0]; dr[5] = o[1]; dr[6] = o[2]; dr[7] = o[3];
-#pragma unroll
-          for (int kt = 0; kt < T; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dr[8 + kt * 4 + r] = s[kt][r];
-        }
         o *= inv;
         // the accumulator holds channels 4g .. 4g+3 of query c (relay tile: only the column c == 0 is a row)
         const int orow = is_rt ? (c == 0 ? rt_row : -1) : qm.w;
