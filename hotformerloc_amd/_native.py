@@ -80,6 +80,10 @@ SIGNATURES = {
     'hfl_linear_x3_qkv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     'hfl_window_attention_f16_ok': (c_int, [ctypes.POINTER(WindowAttnDesc), c_int64]),
     'hfl_split2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'hfl_linear_x3_gelu_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'hfl_linear_x3_gelu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    'hfl_tap_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                             c_void_p]),
     'hfl_wgrad_x3_workspace': (c_int64, [c_int64, c_int64, c_int64]),
     'hfl_wgrad_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'hfl_layer_norm_bwd_blocks': (c_int, [c_int64, c_int64]),

@@ -92,6 +92,65 @@ def octree_gather(data, neigh):
     return OctreeGatherFn.apply(data, neigh)
 
 
+class LiveTapConvFn(torch.autograd.Function):
+    """Octree convolution over its LIVE (row, tap) pairs (model.OctreeConv._forward_live_taps) with its gradients in the
+    same form: the output gradient is gathered pair-major, every tap is two small GEMMs (dg_k = dpart_k W_k^T,
+    dW_k = g_k^T dpart_k) on its contiguous slice, and the input gradient is the fixed-order slot sum over the pairs that
+    read each input row.  Replaces autograd over the dense (N, 27 Cin) gather + GEMM (94 % zeros at depth 6)."""
+
+    @staticmethod
+    def forward(ctx, data, weights, octree, depth, kernel, stride):
+        src, slot, edges = octree.sparse_taps(depth, kernel, stride)
+        g = ops.octree_gather(data, src)
+        kdim, cin, cout = weights.shape
+        part = torch.empty((g.shape[0], cout), dtype=torch.float32, device=data.device)
+        for k in range(kdim):
+            if edges[k + 1] > edges[k]:
+                torch.mm(g[edges[k]:edges[k + 1]], weights[k], out=part[edges[k]:edges[k + 1]])
+        ctx.save_for_backward(g, weights)
+        ctx.octree, ctx.key, ctx.n_src = octree, (depth, kernel, stride), data.shape[0]
+        return ops.dwconv_forward_backward(part, _unit_taps(kdim, cout, data.device), slot)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, weights = ctx.saved_tensors
+        _, _, edges = ctx.octree.sparse_taps(*ctx.key)
+        rowof, inv_slot, chunks, tap_off = ctx.octree.sparse_taps_bwd(*ctx.key)
+        kdim, cin, cout = weights.shape
+        dpart = ops.octree_gather(dout.contiguous(), rowof)
+        dg = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        if cin % 64 == 0 and cout % 64 == 0:
+            dw = ops.tap_wgrad(g, dpart, chunks, tap_off, kdim)       # long contractions into small matrices: own kernel
+        else:
+            dw = torch.zeros_like(weights)
+            for k in range(kdim):
+                if edges[k + 1] > edges[k]:
+                    torch.mm(g[edges[k]:edges[k + 1]].t(), dpart[edges[k]:edges[k + 1]], out=dw[k])
+        if dg is not None:
+            for k in range(kdim):
+                a, b = edges[k], edges[k + 1]
+                if b > a:
+                    torch.mm(dpart[a:b], weights[k].t(), out=dg[a:b])
+        ddata = None
+        if dg is not None:
+            ddata = ops.dwconv_forward_backward(dg, _unit_taps(kdim, cin, dg.device), inv_slot)
+        return ddata, dw, None, None, None, None
+
+
+_UNIT_TAPS = {}
+
+
+def _unit_taps(kdim, channels, device):
+    key = (kdim, channels, device.type, device.index)
+    if key not in _UNIT_TAPS:
+        _UNIT_TAPS[key] = torch.ones((kdim, 1, channels), dtype=torch.float32, device=device)
+    return _UNIT_TAPS[key]
+
+
+def live_tap_conv(data, weights, octree, depth, kernel, stride):
+    return LiveTapConvFn.apply(data, weights, octree, depth, kernel, stride)
+
+
 class RelayTokenInitFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, tok_meta, n_windows, patch_size):
@@ -275,6 +334,35 @@ class LinearX3Fn(torch.autograd.Function):
 
 def linear_x3(x, weight, bias=None):
     return LinearX3Fn.apply(x, weight, bias)
+
+
+class MlpX3Fn(torch.autograd.Function):
+    """fc2(gelu(fc1(h))) of a transformer block (models/layers/octformer_layers.py:53-59) with no element-wise pass of its
+    own: fc1 writes split2(gelu(.)) and the pre-activation in one launch, the backward's dx GEMM of fc2 multiplies by
+    gelu'(pre-activation) in its epilogue and writes the split2 operand of fc1's gradient GEMMs directly."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2):
+        shape = h.shape
+        hs = ops.split2(h.reshape(-1, shape[-1]).contiguous())
+        gs, pre = ops.linear_x3_gelu_fwd(hs, _w2_cached(w1, False), b1)
+        ctx.save_for_backward(hs, gs, pre, w1, w2)
+        ctx.shape = shape
+        return ops.linear_x3(gs, _w2_cached(w2, False), bias=b2).view(*shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        hs, gs, pre, w1, w2 = ctx.saved_tensors
+        dys = ops.split2(dout.reshape(-1, w2.shape[0]).contiguous())
+        dps = ops.linear_x3_gelu_bwd(dys, _w2_cached(w2, True), pre)
+        dw2, db2 = ops.wgrad_x3(dys, gs, with_bias=True)
+        dh = ops.linear_x3(dps, _w2_cached(w1, True)).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dw1, db1 = ops.wgrad_x3(dps, hs, with_bias=True)
+        return dh, dw1, db1, dw2, db2
+
+
+def mlp_x3(h, w1, b1, w2, b2):
+    return MlpX3Fn.apply(h, w1, b1, w2, b2)
 
 
 # ------------------------------------------------ LayerNorm with HIP forward and backward

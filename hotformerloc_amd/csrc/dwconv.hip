@@ -190,7 +190,10 @@ __global__ void dwconv_wgrad_scalar(float* __restrict__ out, const float* __rest
 
 static int wgrad_blocks(int64_t n_rows, int rpb) {
   const int64_t need = hfl_cdiv(n_rows, (int64_t)rpb * 8);
-  int64_t b = need < 256 ? need : 256;
+  // 3 workgroups per CU: the gathers of a row are only hidden by other waves (one workgroup per CU ran at a quarter of
+  // the forward kernel's rate); the price is 3x the partial slabs for the fixed-order reduce
+  const int64_t cap = 3 * (int64_t)hfl_num_cus();
+  int64_t b = need < cap ? need : cap;
   if (b < 1) b = 1;
   return (int)b;
 }

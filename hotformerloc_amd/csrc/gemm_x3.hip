@@ -46,6 +46,7 @@ struct X3Params {
   const uint16_t* w;        // (N, K/32, 2, 32) bf16
   const float* bias;        // (N) or null
   const float* residual;    // (M, N) or null (EPI 0 only; may alias out)
+  float* aux;               // EPI 3: f32 (M, N) pre-activation written next to the split2 output; EPI 4: the same, read
   int64_t M;
   int N, K;
   int tiles_n;
@@ -81,7 +82,22 @@ __device__ __forceinline__ float x3_gelu(float v) {
   return 0.5f * v * (1.0f + erf_v);
 }
 
+// d/dv gelu(v) = Phi(v) + v phi(v), same erf approximation
+__device__ __forceinline__ float x3_gelu_grad(float v) {
+  const float z = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);         // exp(-v^2 / 2)
+  const float erf_v = copysignf(fmaf(-poly * t, e, 1.0f), v);
+  return fmaf(v * 0.3989422804014327f, e, 0.5f * (1.0f + erf_v));
+}
+
 // EPI 0: out f32 = acc + bias [+ residual];  EPI 1: out split2 = split(gelu(acc + bias));
+// EPI 3: EPI 1 + the pre-activation acc + bias also written as f32 to aux (training forward of fc1: GELU's backward needs it)
+// EPI 4: out split2 = split((acc + bias) * gelu'(aux)) (training backward: dx of fc2 straight into the operand of fc1's gradients)
 // EPI 2: out = the window-attention operand layout of acc + bias (qkv projection): per row [Q | K | V] regions of C
 //        features, per head 16 dims as [16 x hi | 16 x lo] fp16 (hi = RTZ(v), lo = RTZ(v - hi): 22 significant bits), the
 //        queries pre-multiplied by q_scale -- csrc/attention.hip, window_attn_kernel_v5 loads these as MFMA fragments
@@ -244,7 +260,13 @@ gemm_x3_kernel(const X3Params p) {
                            ((lane & 1) ? 32 : 0);
         *reinterpret_cast<u32x4*>(o) = qq;
       } else {
-        v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
+        if (EPI == 4) {
+          const float4 y = *reinterpret_cast<const float4*>(p.aux + m * N + nbase);
+          v.x *= x3_gelu_grad(y.x); v.y *= x3_gelu_grad(y.y); v.z *= x3_gelu_grad(y.z); v.w *= x3_gelu_grad(y.w);
+        } else {
+          if (EPI == 3) *reinterpret_cast<float4*>(p.aux + m * N + nbase) = v;
+          v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
+        }
         const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
         const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
         const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
@@ -301,7 +323,7 @@ void hfl_internal_set_x3_dbg(int v) {
 
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
-                     float q_scale, hfl_stream_t stream);
+                     float q_scale, hfl_stream_t stream, float* aux = nullptr);
 
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
@@ -316,17 +338,32 @@ int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_spl
   return x3_launch(out, x_split2, w_split2, bias, nullptr, n_rows, in_features, out_features, 2, q_scale, stream);
 }
 
+int hfl_linear_x3_gelu_fwd(uint16_t* out_split2, float* preact, const uint16_t* x_split2, const uint16_t* w_split2,
+                           const float* bias, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream) {
+  if (preact == nullptr) return HFL_EINVAL;
+  return x3_launch(out_split2, x_split2, w_split2, bias, nullptr, n_rows, in_features, out_features, 3, 1.0f, stream,
+                   preact);
+}
+
+int hfl_linear_x3_gelu_bwd(uint16_t* out_split2, const uint16_t* dy_split2, const uint16_t* wt_split2,
+                           const float* preact, int64_t n_rows, int in_features, int out_features,
+                           hfl_stream_t stream) {
+  if (preact == nullptr) return HFL_EINVAL;
+  return x3_launch(out_split2, dy_split2, wt_split2, nullptr, nullptr, n_rows, in_features, out_features, 4, 1.0f,
+                   stream, const_cast<float*>(preact));
+}
+
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
-                     float q_scale, hfl_stream_t stream) {
-  const int gelu_split_out = epi == 1;
+                     float q_scale, hfl_stream_t stream, float* aux) {
+  const int gelu_split_out = epi == 1 || epi == 3 || epi == 4;
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
   if (in_features % 32 != 0 || out_features % XT != 0) return HFL_EINVAL;
   if (out == nullptr || x_split2 == nullptr || w_split2 == nullptr) return HFL_EINVAL;
   if (gelu_split_out && residual != nullptr) return HFL_EINVAL;
   if (n_rows == 0) return HFL_OK;
   X3Params p;
-  p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual;
+  p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual; p.aux = aux;
   p.M = n_rows; p.N = out_features; p.K = in_features;
   p.tiles_n = out_features / XT;
   // 128-row tiles (3 workgroups per CU).  The 256-row instantiation moves 25 % fewer operand bytes per flop but holds
@@ -348,10 +385,12 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
     if (e != hipSuccess) return (int)e;                                                                  \
     gemm_x3_kernel<E, M><<<(unsigned)p.n_wg, 256, lds, s>>>(p);                                          \
   }
-  if (mt == 8) {
+  if (mt == 8 && epi <= 2) {
     if (epi == 2) HFL_X3_LAUNCH(2, 8) else if (epi == 1) HFL_X3_LAUNCH(1, 8) else HFL_X3_LAUNCH(0, 8)
   } else {
-    if (epi == 2) HFL_X3_LAUNCH(2, 4) else if (epi == 1) HFL_X3_LAUNCH(1, 4) else HFL_X3_LAUNCH(0, 4)
+    p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
+    if (epi == 4) HFL_X3_LAUNCH(4, 4) else if (epi == 3) HFL_X3_LAUNCH(3, 4) else if (epi == 2) HFL_X3_LAUNCH(2, 4)
+    else if (epi == 1) HFL_X3_LAUNCH(1, 4) else HFL_X3_LAUNCH(0, 4)
   }
 #undef HFL_X3_LAUNCH
   HFL_RETURN_LAST_ERROR();

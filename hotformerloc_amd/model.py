@@ -91,6 +91,7 @@ _TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
 _TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
 _ATTN_F16 = os.environ.get('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
 _TRAIN_LN = os.environ.get('HFL_TRAIN_LN', '1') != '0'    # training-path LayerNorm: HIP forward + backward kernels
+_TRAIN_MLP = os.environ.get('HFL_TRAIN_MLP', '1') != '0'          # fused fc1 -> GELU -> fc2 autograd Function
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
@@ -264,8 +265,12 @@ class OctreeConv(nn.Module):
 
     def forward(self, data: torch.Tensor, octree, depth: int):
         if (_SPARSE_CONV and (self.kernel, self.stride) in (('333', 1), ('222', 2)) and self.in_channels >= 32
-                and data.is_cuda and not _grad_path(data)):
-            return self._forward_live_taps(data, octree, depth)
+                and data.is_cuda):
+            if not _grad_path(data):
+                return self._forward_live_taps(data, octree, depth)
+            if self.in_channels % 64 == 0 and self.out_channels % 64 == 0:      # tile shape of hfl_tap_wgrad
+                out = ag.live_tap_conv(data, self.weights, octree, depth, self.kernel, self.stride)
+                return out if self.bias is None else out + self.bias
         neigh = octree.get_neigh(depth, self.kernel, self.stride, nempty=True)
         col = ag.octree_gather(data, neigh) if _grad_path(data) else ops.octree_gather(data, neigh)
         w = self.weights.reshape(self.kdim * self.in_channels, self.out_channels)
@@ -374,6 +379,11 @@ class MLP(nn.Module):
         self.fc2 = SplitLinear(hidden_features or in_features, out_features or in_features)
 
     def forward(self, x):
+        f1, f2 = self.fc1, self.fc2
+        if (_GEMM_MODE == 'x3' and _TRAIN_X3 and _TRAIN_MLP and x.is_cuda and _grad_path() and x.numel() > 0
+                and f1.bias is not None and f2.bias is not None
+                and ag.linear_x3_ok(f1.in_features, f1.out_features) and ag.linear_x3_ok(f2.in_features, f2.out_features)):
+            return ag.mlp_x3(x, f1.weight, f1.bias, f2.weight, f2.bias)      # GELU and its gradient inside the GEMMs
         return self.fc2(F.gelu(self.fc1(x)))
 
 

@@ -238,6 +238,36 @@ class Octree:
             self._build_tap_lists([key])
         return cache[key]
 
+    def sparse_taps_bwd(self, depth: int, kernel: str = '333', stride: int = 1):
+        """What the backward of a live-tap convolution needs besides `sparse_taps`: `rowof` (P, 1) int32, the output row
+        of every pair (to gather the output gradient pair-major), and `inv_slot` (n_src, taps) int32, for every INPUT row
+        the pairs that read it (tap k: the pair of the output row whose k-th neighbour it is), -1 where there is none --
+        the input gradient is then the same fixed-order slot sum as the forward (no atomics); plus the (chunks, tap_chunk_off)
+        tables of `ops.tap_wgrad`."""
+        cache = self.__dict__.setdefault('_sparse_taps_bwd', {})
+        key = (depth, kernel, stride)
+        if key not in cache:
+            src, slot, edges = self.sparse_taps(depth, kernel, stride)
+            neigh = self.get_neigh(depth, kernel, stride, nempty=True).contiguous()
+            n_src = int(self.nnum_nempty[depth])
+            rows = torch.arange(slot.shape[0], dtype=torch.int32, device=slot.device).view(-1, 1).expand_as(slot)
+            live = slot >= 0
+            rowof = torch.empty(max(edges[-1], 1), dtype=torch.int32, device=slot.device)
+            rowof[slot[live].long()] = rows[live]
+            inv = torch.empty((n_src, neigh.shape[1]), dtype=torch.int32, device=neigh.device)
+            ops.inverse_table(inv, neigh)
+            inv_slot = torch.where(inv >= 0, slot.gather(0, inv.clamp_min(0).long()), torch.full_like(inv, -1))
+            # pair chunks of the weight-gradient kernel: <= 2048 pairs each, never across a tap boundary
+            chunks, tap_off = [], [0]
+            for k in range(len(edges) - 1):
+                for a in range(edges[k], edges[k + 1], 2048):
+                    chunks.append((k, a, min(a + 2048, edges[k + 1])))
+                tap_off.append(len(chunks))
+            chunks_t = torch.tensor(chunks if chunks else [(0, 0, 0)], dtype=torch.int32).view(-1, 3)[:len(chunks)]
+            cache[key] = (rowof[:edges[-1]].view(-1, 1), inv_slot.contiguous(),
+                          chunks_t.to(slot.device), torch.tensor(tap_off, dtype=torch.int32, device=slot.device))
+        return cache[key]
+
     def _build_tap_lists(self, keys):
         """Tap lists for several (depth, kernel, stride) tables: all launches first, then one host read."""
         cache = self.__dict__.setdefault('_sparse_taps', {})

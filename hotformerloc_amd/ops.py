@@ -409,6 +409,36 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
     return out
 
 
+def linear_x3_gelu_fwd(x2: torch.Tensor, w2: torch.Tensor, bias):
+    """(split2(gelu(x W^T + b)), x W^T + b as f32) in one launch (hfl_linear_x3_gelu_fwd): training forward of fc1."""
+    _dev(x2, w2, bias)
+    assert x2.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x2.is_contiguous() and w2.is_contiguous()
+    m, k2 = x2.shape
+    n = w2.shape[0]
+    assert w2.shape[1] == k2
+    out = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=x2.device)
+    pre = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+    with _timed('hfl_linear_x3', m * (k2 // 2) * 4 + m * n * 8, 2 * m * (k2 // 2) * n):
+        check(_native.load().hfl_linear_x3_gelu_fwd(out.data_ptr(), pre.data_ptr(), x2.data_ptr(), w2.data_ptr(),
+                                                    None if bias is None else _f32c(bias).data_ptr(), m, k2 // 2, n,
+                                                    _stream()), 'hfl_linear_x3_gelu_fwd')
+    return out, pre
+
+
+def linear_x3_gelu_bwd(dy2: torch.Tensor, wt2: torch.Tensor, preact: torch.Tensor):
+    """split2((dy W) * gelu'(preact)) (hfl_linear_x3_gelu_bwd): wt2 = split2 of W^T, preact (rows, wt2.shape[0]) f32."""
+    _dev(dy2, wt2, preact)
+    assert dy2.dtype == torch.bfloat16 and wt2.dtype == torch.bfloat16 and dy2.is_contiguous() and wt2.is_contiguous()
+    m, k2 = dy2.shape
+    n = wt2.shape[0]
+    assert wt2.shape[1] == k2 and tuple(preact.shape) == (m, n) and preact.is_contiguous()
+    out = torch.empty((m, 2 * n), dtype=torch.bfloat16, device=dy2.device)
+    with _timed('hfl_linear_x3', m * (k2 // 2) * 4 + m * n * 8, 2 * m * (k2 // 2) * n):
+        check(_native.load().hfl_linear_x3_gelu_bwd(out.data_ptr(), dy2.data_ptr(), wt2.data_ptr(), preact.data_ptr(),
+                                                    m, k2 // 2, n, _stream()), 'hfl_linear_x3_gelu_bwd')
+    return out
+
+
 def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):
     """(dW, db) of y = x W^T + b from split2 operands: dW (N, K) = dy^T x, db (N) = dy summed over rows (hfl_wgrad_x3;
     fixed reduction order)."""
@@ -489,6 +519,32 @@ def octree_gather(data, neigh):
         check(_native.load().hfl_octree_gather(out.data_ptr(), data.data_ptr(), neigh.data_ptr(), m, k,
                                                c, _stream()), 'hfl_octree_gather')
     return out
+
+
+def inverse_table(inverse: torch.Tensor, table: torch.Tensor):
+    """inverse (n_src, K) int32 of a gather table (n_dst, K) int32: inverse[table[m, k], k] = m, -1 elsewhere
+    (hfl_inverse_table)."""
+    _dev(inverse, table)
+    assert table.dtype == torch.int32 and inverse.dtype == torch.int32 and table.is_contiguous() and inverse.is_contiguous()
+    check(_native.load().hfl_inverse_table(inverse.data_ptr(), inverse.shape[0], table.data_ptr(), table.shape[0],
+                                           table.shape[1], _stream()), 'hfl_inverse_table')
+    return inverse
+
+
+def tap_wgrad(g: torch.Tensor, dpart: torch.Tensor, chunks: torch.Tensor, tap_chunk_off: torch.Tensor, taps: int):
+    """dW (taps, Cin, Cout) of a live-tap octree convolution: dW[k] = g_k^T dpart_k over the pairs of tap k
+    (hfl_tap_wgrad; `chunks` / `tap_chunk_off` from Octree.sparse_taps_bwd)."""
+    _dev(g, dpart, chunks, tap_chunk_off)
+    g, dpart = _f32c(g), _f32c(dpart)
+    cin, cout = g.shape[1], dpart.shape[1]
+    n_chunks = chunks.shape[0]
+    dw = torch.empty((taps, cin, cout), dtype=torch.float32, device=g.device)
+    ws = torch.empty((max(n_chunks, 1), cin, cout), dtype=torch.float32, device=g.device)
+    with _timed('hfl_tap_wgrad', (g.numel() + dpart.numel()) * 4, 2 * g.shape[0] * cin * cout):
+        check(_native.load().hfl_tap_wgrad(dw.data_ptr(), g.data_ptr(), dpart.data_ptr(), chunks.data_ptr(), n_chunks,
+                                           tap_chunk_off.data_ptr(), taps, cin, cout, ws.data_ptr(), _stream()),
+              'hfl_tap_wgrad')
+    return dw
 
 
 def tap_lists(table: torch.Tensor, edges_out: torch.Tensor = None):

@@ -350,6 +350,17 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream);
 int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* Training forms of the MLP's first Linear (models/layers/octformer_layers.py:53-59 under autograd):
+ *   _gelu_fwd: out_split2 = split2(gelu(x W^T + b)) AND preact (n_rows, out_features) f32 = x W^T + b in one launch (GELU's
+ *              backward needs the pre-activation);
+ *   _gelu_bwd: out_split2 = split2((dy W) * gelu'(preact)): the input gradient of fc2 multiplied by the GELU derivative and
+ *              written as the operand of fc1's gradient GEMMs -- wt_split2 is the split2 layout of W^T (in_features x
+ *              out_features of the forward = (out_features, in_features) here). */
+int hfl_linear_x3_gelu_fwd(uint16_t* out_split2, float* preact, const uint16_t* x_split2, const uint16_t* w_split2,
+                           const float* bias, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream);
+int hfl_linear_x3_gelu_bwd(uint16_t* out_split2, const uint16_t* dy_split2, const uint16_t* wt_split2,
+                           const float* preact, int64_t n_rows, int in_features, int out_features,
+                           hfl_stream_t stream);
 /* Weight and bias gradient of the same Linear (csrc/wgrad_x3.hip): dw (N,K) = dy^T x, db (N) = column sums of dy, both
  * operands in the split2 layout (dy (n_rows, N) and x (n_rows, K)), three-term products, fp32 accumulation, slabs of rows
  * reduced in a fixed order (bitwise reproducible).  Replaces autograd's fp32 GEMM + bias reduction for torch.nn.Linear in
@@ -386,6 +397,13 @@ int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv, c
 int hfl_relay_attention_bwd(float* dqkv, const float* qkv, const float* dout, const int32_t* seq_rows,
                             const int32_t* seq_off, int batch, int n_heads, float scale,
                             int max_seq_len, hfl_stream_t stream);
+/* Weight gradient of an octree convolution over its live (row, tap) pairs (csrc/tapconv.hip; replaces autograd over
+ * ocnn's octree2col + mm, models/layers/octformer_layers.py:89-95): dw[k] (cin, cout) = g_k^T dpart_k over the pairs of tap
+ * k.  g (P, cin), dpart (P, cout) fp32 pair-major; chunks (n_chunks, 3) int32 = {tap, first pair, end pair}, ascending, no
+ * chunk straddles a tap; tap_chunk_off (taps + 1) int32 = first chunk of every tap; workspace n_chunks * cin * cout floats.
+ * cin % 64 == 0, cout % 64 == 0.  fp32 MFMA, fixed summation order. */
+int hfl_tap_wgrad(float* dw, const float* g, const float* dpart, const int32_t* chunks, int n_chunks,
+                  const int32_t* tap_chunk_off, int taps, int cin, int cout, float* workspace, hfl_stream_t stream);
 /* Inverse of a gather table whose source and destination row counts differ (stride-2 conv:
  * table (n_dst, K) with entries in [0, n_src)): inverse (n_src, K), inverse[table[m,k], k] = m, -1 else. */
 int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table, int64_t n_dst_rows,

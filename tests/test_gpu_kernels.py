@@ -170,6 +170,35 @@ def test_octree_sparse_taps_built_with_the_neighbour_tables():
         assert bool((slot[~live] == -1).all())
 
 
+def test_live_tap_conv_gradients_match_the_dense_formulation():
+    """Training path of OctreeConv over its live taps (autograd.LiveTapConvFn) against autograd over the dense
+    octree2col + GEMM formulation of the same module: output, input gradient and weight gradient, 3x3x3 stride 1 and
+    2x2x2 stride 2 (children table: source and destination depths differ)."""
+    from hotformerloc_amd import model as M
+    clouds = syn.make_clouds(13, 3, 3000, 'cartesian')
+    o = build_batch_octree(clouds, 7, 2, DEV, construct_neigh=True)
+    g = torch.Generator().manual_seed(3)
+    for depth, ks, stride, cin, cout in ((6, [3], 1, 64, 64), (5, [3], 1, 128, 128), (6, [2], 2, 64, 128)):
+        conv = M.OctreeConv(cin, cout, ks, stride, nempty=True, use_bias=stride == 2).to(DEV)
+        n_in = int(o.nnum_nempty[depth])
+        x = torch.randn(n_in, cin, generator=g).to(DEV)
+        got = {}
+        for mode in (True, False):
+            M._SPARSE_CONV = mode
+            try:
+                xi = x.clone().requires_grad_(True)
+                conv.zero_grad()
+                y = conv(xi, o, depth)
+                dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
+                y.backward(dy)
+                got[mode] = (y.detach(), xi.grad.clone(), conv.weights.grad.clone())
+            finally:
+                M._SPARSE_CONV = True
+        for a, b, what in zip(got[True], got[False], ('out', 'ddata', 'dweights')):
+            assert a.shape == b.shape
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6, (depth, ks, stride, what)
+
+
 # ------------------------------------------------------------------------- dwconv
 def test_dwconv_matches_ocnn_semantics(golden_dir):
     """Port of the reference's own test (`libs/dwconv/test/test_octree_dwconv.py:13-68`):
@@ -614,6 +643,31 @@ def test_wgrad_x3_matches_fp64_and_is_reproducible():
         assert (db.cpu().double() - dy.double().sum(0)).abs().max().item() < 1e-5 * (dy.abs().sum(0).max().item() + 1)
         dw2, none = ops.wgrad_x3(dys, xs, with_bias=False)
         assert none is None and torch.equal(dw, dw2)
+
+
+def test_mlp_x3_matches_fp64_autograd():
+    """fc2(gelu(fc1(h))) with GELU and its derivative fused into the GEMM epilogues (autograd.MlpX3Fn): output and all five
+    gradients against torch autograd in fp64 (exact erf GELU), <= 2e-5 relative L2; ragged row count."""
+    from hotformerloc_amd import autograd as ag
+    g = torch.Generator().manual_seed(41)
+    for m, c in ((1000, 128), (4133, 256)):
+        h = torch.randn(m, c, generator=g)
+        w1 = torch.randn(4 * c, c, generator=g) * 0.06
+        b1 = torch.randn(4 * c, generator=g) * 0.1
+        w2 = torch.randn(c, 4 * c, generator=g) * 0.03
+        b2 = torch.randn(c, generator=g) * 0.1
+        dy = torch.randn(m, c, generator=g)
+        ref_in = [t.double().requires_grad_(True) for t in (h, w1, b1, w2, b2)]
+        ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2])),
+                                         ref_in[3], ref_in[4])
+        ref.backward(dy.double())
+        dev_in = [t.to(DEV).requires_grad_(True) for t in (h, w1, b1, w2, b2)]
+        out = ag.mlp_x3(*dev_in)
+        out.backward(dy.to(DEV))
+        assert ((out.detach().cpu().double() - ref.detach()).norm() / ref.detach().norm()).item() < 2e-5
+        for a, b, name in zip(dev_in, ref_in, ('dh', 'dw1', 'db1', 'dw2', 'db2')):
+            err = ((a.grad.cpu().double() - b.grad).norm() / b.grad.norm()).item()
+            assert err < 2e-5, (m, c, name, err)
 
 
 def test_window_attention_backward_matches_autograd():
