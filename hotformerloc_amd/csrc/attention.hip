@@ -1338,6 +1338,7 @@ extern "C" void hfl_internal_set_cpe_variant(int v, int wgs);
 extern "C" void hfl_internal_set_linear_ablate(int v);
 /* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
 void hfl_internal_set_x3_dbg(int v);
+void hfl_internal_set_window_bwd(int v);
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
   const char* k = "window_attention";
@@ -1345,6 +1346,13 @@ int hfl_set_variant(const char* key, int value) {
   while (k[i] != 0 && key[i] == k[i]) ++i;
   if (k[i] == 0 && key[i] == 0) {
     g_window_variant = value;
+    return HFL_OK;
+  }
+  const char* kb = "window_bwd";
+  i = 0;
+  while (kb[i] != 0 && key[i] == kb[i]) ++i;
+  if (kb[i] == 0 && key[i] == 0) {
+    hfl_internal_set_window_bwd(value);
     return HFL_OK;
   }
   const char* k4 = "linear_ablate";
@@ -1797,6 +1805,396 @@ window_attn_bwd_kernel(const WinBwdParams p) {
     }
 }
 
+// ---- backward, second generation (the default): one pass per (window, head) on the 16-cycle bf16 MFMAs -------------
+// Same semantics and interface as window_attn_bwd_kernel above, which spends 28 fp32 MFMAs of 32 cycles per
+// (query tile, key tile) pair because it recomputes the softmax in two orientations.  Here:
+//  * Q, K, dO of the head are staged ONCE as bf16 (hi, lo) rows [16 x hi | 16 x lo] = 64 B (hi = RNE(v), lo = RNE(v - hi):
+//    2^-18 relative); a row is then directly a K = 32 MFMA operand ("[a_hi | a_lo] . [b_hi | b_hi]" + "... [b_lo | b_lo]" =
+//    all four cross terms of a 16-dim dot product in two v_mfma_f32_16x16x32_bf16), and the same image read through
+//    ds_read_b64_tr_b16 gives the transposed operands (K^T, Q^T, dO^T) of the second-stage products.  V stays in registers.
+//  * orientation "keys x queries" only (a lane owns a query column, as in the forward kernels): S^T and dP^T by MFMA,
+//    softmax / D / dS in registers, dQ^T = K^T dS^T straight from those registers (three-term split of dS).
+//  * dK and dV contract over the QUERIES: P and dS of a pair of query tiles are split to bf16 (hi, lo), written to a 4-KiB
+//    per-wave LDS block per key tile and read back transposed (the transposing read again) as the B operand of
+//    dV^T = dO^T P, dK^T = Q^T dS -- no second softmax pass.
+//  8.5 MFMAs of 16 cycles per tile pair instead of 28 of 32; the table gradient still goes through LDS atomics.
+typedef short bwd_b8 __attribute__((ext_vector_type(8)));
+typedef short bwd_s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t bwd_bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+// four floats -> packed bf16 hi (2 dwords) and lo (2 dwords)
+__device__ __forceinline__ void bwd_split4(const float a, const float b, const float c, const float d, uint2& hi, uint2& lo) {
+  const uint32_t h0 = bwd_bf16_rne(a), h1 = bwd_bf16_rne(b), h2 = bwd_bf16_rne(c), h3 = bwd_bf16_rne(d);
+  const uint32_t l0 = bwd_bf16_rne(a - __uint_as_float(h0 << 16)), l1 = bwd_bf16_rne(b - __uint_as_float(h1 << 16));
+  const uint32_t l2 = bwd_bf16_rne(c - __uint_as_float(h2 << 16)), l3 = bwd_bf16_rne(d - __uint_as_float(h3 << 16));
+  hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+__device__ __forceinline__ bwd_b8 bwd_cat(const uint2 a, const uint2 b) {
+  const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
+  return __builtin_bit_cast(bwd_b8, q);
+}
+
+template <int T, int G, int NREP>
+__global__ void __launch_bounds__(128)
+window_attn_bwd2_kernel(const WinBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LP = T * 16;
+  constexpr int TW = T - G;
+  constexpr int NP = (T + 1) / 2;                 // tile pairs (a K = 32 contraction covers two 16-row tiles)
+  constexpr int LR = NP * 32;                     // image rows (the pad rows of an odd T stay zero)
+  constexpr int NHW = 2;                          // heads (waves) per workgroup
+  constexpr float kLog2e = 1.4426950408889634f;
+  typedef __attribute__((address_space(3))) bwd_s4 lds_s4;
+  const int H = p.H, K = p.K;
+  const int C = H * 16;
+  const int nrpe = 2 * p.bnd + 1;
+  const int tabf = (3 * nrpe + 3) & ~3;
+  int4* s_key = reinterpret_cast<int4*>(smem);                          // [LP]
+  int4* s_qry = s_key + LP;                                             // [LP]
+  int* s_row = reinterpret_cast<int*>(s_qry + LP);                      // [LP]
+  unsigned char* wave_base = reinterpret_cast<unsigned char*>(s_row + LP);
+  const int scr_bytes = NREP * tabf * 8 > 4096 ? NREP * tabf * 8 : 4096;   // transposition block / fixed-point table: never live together
+  const int wave_bytes = 3 * LR * 64 + scr_bytes + 2 * tabf * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y * NHW + hw;
+  const int c = lane & 15, g = lane >> 4;
+  const bool rpe = p.table != nullptr;
+  unsigned char* img_k = wave_base + hw * wave_bytes;
+  unsigned char* img_q = img_k + LR * 64;
+  unsigned char* img_d = img_q + LR * 64;
+  unsigned char* scr = img_d + LR * 64;                                  // [Ph | Pl | dSh | dSl] x 32 rows x 32 B
+  float* tabx = reinterpret_cast<float*>(scr + scr_bytes);              // [3 nrpe] * log2e
+  float* dtabx = tabx + tabf;                                            // the wave's table gradient (f32, lane-owned entries)
+  long long* itab = reinterpret_cast<long long*>(scr);                  // [NREP][tabf] fixed-point staging of one query tile (all zero between tiles)
+
+  // Table gradient: ds_add_f32 costs ~190 cycles per wave-instruction on gfx950 whatever the addresses, ds_add_u64 ~5 + 2 per
+  // conflicting lane (tools/micro/lds_atomic_rate.hip), so the scatter-add runs in FIXED POINT: per query tile the wave's
+  // largest |dS| sets a power-of-two scale (values become 31-bit integers), the 3 x L^2/T adds go to an int64 table
+  // (integer adds commute: the result does not depend on the order), and after the tile every lane converts its own entries
+  // back and adds them to the f32 table.  NREP copies (lane (c, g) uses copy c % NREP) thin out equal-address conflicts.
+  long long* itab_mine = itab + (c % NREP) * tabf;
+  const int sh0 = 10 * (g % 3), sh1 = 10 * ((g + 1) % 3), sh2 = 10 * ((g + 2) % 3);
+  if (rpe) {
+    for (int i = lane; i < 3 * nrpe; i += 64) {
+      tabx[i] = p.table[i * H + h] * kLog2e;
+      dtabx[i] = 0.f;
+    }
+  }
+  if (LR > LP)                                                           // pad rows of the three images: zeros, once
+    for (int i = lane; i < (LR - LP) * 4 * 3; i += 64) {
+      const int a = i / ((LR - LP) * 4), r = i % ((LR - LP) * 4);
+      reinterpret_cast<uint4*>(img_k + a * LR * 64 + LP * 64)[r] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  const int hi4 = 8 * p.bnd;
+  const float scale2 = p.scale * kLog2e;
+  const float mask2 = kMaskValue * kLog2e;
+  // transposing reads: lane (c, g) addresses row 4g + (c >> 2), dims 4 (c & 3) .. +3 of a 64-B image row
+  const int tr_img = (4 * g + (c >> 2)) * 64 + (c & 3) * 8;
+  const int tr_scr = (4 * g + (c >> 2)) * 32 + (c & 3) * 8;
+
+  // bias of (key, query) in the exp2 domain; `packed` = the three table offsets, 10 bits each (3 nrpe <= 1023 is checked
+  // by the launcher), -1 without RPE
+  auto bias_of = [&](const int4 k, const int4 q, bool use_rpe, int& packed) -> float {
+    float b = 0.f;
+    packed = -1;
+    if (use_rpe) {
+      const int ox = min(max(q.x + k.x, 0), hi4) >> 2;
+      const int oy = (min(max(q.y + k.y, 0), hi4) >> 2) + nrpe;
+      const int oz = (min(max(q.z + k.z, 0), hi4) >> 2) + 2 * nrpe;
+      b = (tabx[ox] + tabx[oy]) + tabx[oz];
+      packed = ox | (oy << 10) | (oz << 20);
+    }
+    if (k.w != q.w) b += mask2;
+    return b;
+  };
+  auto tr_pair = [&](const unsigned char* base, int stride16) -> bwd_b8 {      // rows r..r+3 of two 16-row tiles
+    const bwd_s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(base));
+    const bwd_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(base + stride16));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
+    __syncthreads();
+    for (int j = tid; j < LP; j += blockDim.x) {
+      int bid = -1, row = -1, x = 0, y = 0, z = 0;
+      if (j < K) {
+        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
+                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
+        if (t < p.n_tokens) {
+          const uint32_t xyz = p.meta[2 * t];
+          x = (int)(xyz & 1023u); y = (int)((xyz >> 10) & 1023u); z = (int)(xyz >> 20);
+          bid = (int)p.meta[2 * t + 1];
+          row = (int)t;
+        }
+      } else if (G > 0 && j == K) {
+        const int64_t t0 = (int64_t)w * K;
+        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
+        row = (int)(p.rt_row0 + w);
+      }
+      s_key[j] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), bid);
+      s_qry[j] = make_int4(4 * x, 4 * y, 4 * z, row >= 0 ? bid : -2);
+      s_row[j] = row;
+    }
+    __syncthreads();
+    // ---- stage Q, K, dO of this head as bf16 (hi, lo) rows -----------------------------------------------------------
+    for (int i = lane; i < LP * 4; i += 64) {
+      const int j = i >> 2, f = i & 3;
+      const int row = s_row[j];
+      float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, d4 = q4;
+      if (row >= 0) {
+        const float* base = p.qkv + (int64_t)row * 3 * C + h * 16 + 4 * f;
+        q4 = *reinterpret_cast<const float4*>(base);
+        k4 = *reinterpret_cast<const float4*>(base + C);
+        d4 = *reinterpret_cast<const float4*>(p.dout + (int64_t)row * C + h * 16 + 4 * f);
+      }
+      uint2 hi, lo;
+      bwd_split4(q4.x, q4.y, q4.z, q4.w, hi, lo);
+      *reinterpret_cast<uint2*>(img_q + j * 64 + f * 8) = hi;
+      *reinterpret_cast<uint2*>(img_q + j * 64 + 32 + f * 8) = lo;
+      bwd_split4(k4.x, k4.y, k4.z, k4.w, hi, lo);
+      *reinterpret_cast<uint2*>(img_k + j * 64 + f * 8) = hi;
+      *reinterpret_cast<uint2*>(img_k + j * 64 + 32 + f * 8) = lo;
+      bwd_split4(d4.x, d4.y, d4.z, d4.w, hi, lo);
+      *reinterpret_cast<uint2*>(img_d + j * 64 + f * 8) = hi;
+      *reinterpret_cast<uint2*>(img_d + j * 64 + 32 + f * 8) = lo;
+    }
+    // V rows as [v_hi | v_lo] A operands, in registers: lane (c, g) holds dims 8 (g & 1) .. +7, hi for g < 2, lo else
+    bwd_b8 av[T];
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      const int row = s_row[kt * 16 + c];
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (row >= 0) {
+        const float* base = p.qkv + (int64_t)row * 3 * C + 2 * C + h * 16 + 8 * (g & 1);
+        a = *reinterpret_cast<const float4*>(base);
+        b = *reinterpret_cast<const float4*>(base + 4);
+      }
+      uint2 h0, l0, h1, l1;
+      bwd_split4(a.x, a.y, a.z, a.w, h0, l0);
+      bwd_split4(b.x, b.y, b.z, b.w, h1, l1);
+      av[kt] = (g < 2) ? bwd_cat(h0, h1) : bwd_cat(l0, l1);
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before it reads them
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4 dk[T], dv[T];
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      dk[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int qp = 0; qp < NP; ++qp) {
+      uint2 ph[2][T], pl[2][T], sh[2][T], sl[2][T];           // P and dS of the pair's two query tiles, bf16 (hi, lo)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * qp + u;
+        if (qt >= T) {
+#pragma unroll
+          for (int kt = 0; kt < T; ++kt) ph[u][kt] = pl[u][kt] = sh[u][kt] = sl[u][kt] = make_uint2(0u, 0u);
+          continue;
+        }
+        const int qi = qt * 16 + c;
+        const int4 q = s_qry[qi];
+        const bool q_rpe = rpe && !(G > 0 && qt == T - 1);
+        const bwd_b8 bq_h = *reinterpret_cast<const bwd_b8*>(img_q + qi * 64 + (g & 1) * 16);        // [q_hi | q_hi]
+        const bwd_b8 bq_l = *reinterpret_cast<const bwd_b8*>(img_q + qi * 64 + 32 + (g & 1) * 16);   // [q_lo | q_lo]
+        const bwd_b8 bd_h = *reinterpret_cast<const bwd_b8*>(img_d + qi * 64 + (g & 1) * 16);
+        const bwd_b8 bd_l = *reinterpret_cast<const bwd_b8*>(img_d + qi * 64 + 32 + (g & 1) * 16);
+        f32x4 s[T], dp[T];
+        int off[T][4];
+        float mx = kDeadValue;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt) {
+          const bwd_b8 ak = *reinterpret_cast<const bwd_b8*>(img_k + (kt * 16 + c) * 64 + g * 16);   // [k_hi | k_lo]
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acd = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bq_l, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bq_h, acc, 0, 0, 0);
+          acd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[kt], bd_l, acd, 0, 0, 0);
+          acd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[kt], bd_h, acd, 0, 0, 0);
+          dp[kt] = acd;
+          const bool t_rpe = q_rpe && kt < TW;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int4 k = s_key[kt * 16 + 4 * g + r];
+            const float v = acc[r] * scale2 + bias_of(k, q, t_rpe, off[kt][r]);
+            acc[r] = v;
+            mx = fmaxf(mx, v);
+          }
+          s[kt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+            s[kt][r] = e;
+            sum += e;
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s[kt][r] *= inv;                        // P
+            dsum += s[kt][r] * dp[kt][r];
+          }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        f32x4 dsv[T];
+        float dmax = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            dsv[kt][r] = s[kt][r] * (dp[kt][r] - dsum);
+            dmax = fmaxf(dmax, fabsf(dsv[kt][r]));
+          }
+          bwd_split4(s[kt][0], s[kt][1], s[kt][2], s[kt][3], ph[u][kt], pl[u][kt]);
+          bwd_split4(dsv[kt][0], dsv[kt][1], dsv[kt][2], dsv[kt][3], sh[u][kt], sl[u][kt]);
+        }
+        if (q_rpe) {
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+          int bexp = (int)((__float_as_uint(dmax) >> 23) & 0xffu);          // dmax in [2^(bexp-127), 2^(bexp-126))
+          if (bexp >= 30) {                                                  // (smaller: the tile's gradient is zero in f32)
+            if (bexp > 250) bexp = 250;
+            const float sc = __uint_as_float((uint32_t)(283 - bexp) << 23);  // |ds| * sc < 2^30
+            const float isc = __uint_as_float((uint32_t)(bexp - 29) << 23);
+            const bool q_live = q.w >= 0;
+            for (int i = lane; i < NREP * tabf; i += 64) itab[i] = 0;           // (the block doubles as the transposition buffer)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kt = 0; kt < TW; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int fx32 = __float2int_rn(dsv[kt][r] * sc);
+                if (off[kt][r] >= 0 && q_live && fx32 != 0) {
+                  // the four lane groups walk the three axes in rotated order: one wave-instruction then spreads over
+                  // the x, y and z parts of the table (an equal address costs 2 cycles per extra lane)
+                  const unsigned long long fx = (unsigned long long)(long long)fx32;
+                  atomicAdd(reinterpret_cast<unsigned long long*>(itab_mine + ((off[kt][r] >> sh0) & 1023)), fx);
+                  atomicAdd(reinterpret_cast<unsigned long long*>(itab_mine + ((off[kt][r] >> sh1) & 1023)), fx);
+                  atomicAdd(reinterpret_cast<unsigned long long*>(itab_mine + ((off[kt][r] >> sh2) & 1023)), fx);
+                }
+              }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < 3 * nrpe; i += 64) {
+              long long acc = 0;
+#pragma unroll
+              for (int rep = 0; rep < NREP; ++rep) acc += itab[rep * tabf + i];
+              dtabx[i] += (float)acc * isc;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        // dQ^T[d][query] = sum over keys K^T[d][key] dS^T[key][query]: K^T by transposing reads, dS^T from registers
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NP; ++kp) {
+          const bwd_b8 kt_h = tr_pair(img_k + (2 * kp) * 16 * 64 + tr_img, 16 * 64);
+          const bwd_b8 kt_l = tr_pair(img_k + (2 * kp) * 16 * 64 + 32 + tr_img, 16 * 64);
+          const uint2 z2 = make_uint2(0u, 0u);
+          const bwd_b8 bs_h = bwd_cat(sh[u][2 * kp], (2 * kp + 1 < T) ? sh[u][(2 * kp + 1 < T) ? 2 * kp + 1 : 0] : z2);
+          const bwd_b8 bs_l = bwd_cat(sl[u][2 * kp], (2 * kp + 1 < T) ? sl[u][(2 * kp + 1 < T) ? 2 * kp + 1 : 0] : z2);
+          dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_h, bs_l, dq, 0, 0, 0);
+          dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_l, bs_h, dq, 0, 0, 0);
+          dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_h, bs_h, dq, 0, 0, 0);
+        }
+        const int qrow = s_row[qi];
+        if (qrow >= 0)
+          *reinterpret_cast<float4*>(p.dqkv + (int64_t)qrow * 3 * C + h * 16 + 4 * g) =
+              make_float4(dq[0] * p.scale, dq[1] * p.scale, dq[2] * p.scale, dq[3] * p.scale);
+      }
+
+      // ---- dK^T, dV^T: contraction over the 32 queries of the pair ---------------------------------------------------
+      const bwd_b8 qT_h = tr_pair(img_q + (2 * qp) * 16 * 64 + tr_img, 16 * 64);
+      const bwd_b8 qT_l = tr_pair(img_q + (2 * qp) * 16 * 64 + 32 + tr_img, 16 * 64);
+      const bwd_b8 dT_h = tr_pair(img_d + (2 * qp) * 16 * 64 + tr_img, 16 * 64);
+      const bwd_b8 dT_l = tr_pair(img_d + (2 * qp) * 16 * 64 + 32 + tr_img, 16 * 64);
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt) {
+        // rows = query (u * 16 + c), 4 consecutive keys 4g..4g+3 of tile kt per lane: 8 B
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          unsigned char* dst = scr + (u * 16 + c) * 32 + g * 8;
+          *reinterpret_cast<uint2*>(dst) = ph[u][kt];
+          *reinterpret_cast<uint2*>(dst + 1024) = pl[u][kt];
+          *reinterpret_cast<uint2*>(dst + 2048) = sh[u][kt];
+          *reinterpret_cast<uint2*>(dst + 3072) = sl[u][kt];
+        }
+        __builtin_amdgcn_wave_barrier();                 // LDS operations of one wave execute in order: no wait needed
+        const bwd_b8 bp_h = tr_pair(scr + tr_scr, 16 * 32);
+        const bwd_b8 bp_l = tr_pair(scr + 1024 + tr_scr, 16 * 32);
+        const bwd_b8 bs_h = tr_pair(scr + 2048 + tr_scr, 16 * 32);
+        const bwd_b8 bs_l = tr_pair(scr + 3072 + tr_scr, 16 * 32);
+        dv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT_h, bp_l, dv[kt], 0, 0, 0);
+        dv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT_l, bp_h, dv[kt], 0, 0, 0);
+        dv[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT_h, bp_h, dv[kt], 0, 0, 0);
+        dk[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT_h, bs_l, dk[kt], 0, 0, 0);
+        dk[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT_l, bs_h, dk[kt], 0, 0, 0);
+        dk[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT_h, bs_h, dk[kt], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();                 // the block is rewritten for the next key tile
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt) {
+      const int krow = s_row[kt * 16 + c];
+      if (krow >= 0) {
+        float* base = p.dqkv + (int64_t)krow * 3 * C + h * 16 + 4 * g;
+        *reinterpret_cast<float4*>(base + C) =
+            make_float4(dk[kt][0] * p.scale, dk[kt][1] * p.scale, dk[kt][2] * p.scale, dk[kt][3] * p.scale);
+        *reinterpret_cast<float4*>(base + 2 * C) = make_float4(dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3]);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (rpe && p.dtable != nullptr)
+    for (int i = lane; i < 3 * nrpe; i += 64) {
+      const float v = dtabx[i];
+      if (v != 0.f) atomicAdd(p.dtable + i * H + h, v);
+    }
+}
+
+static int g_window_bwd_variant = 2;
+
+template <int T, int G, int NREP>
+static int launch_window_bwd2(const WinBwdParams& p, hipStream_t s) {
+  constexpr int LP = T * 16, NP = (T + 1) / 2, LR = NP * 32, NHW = 2;
+  const int nrpe = 2 * p.bnd + 1;
+  const int tabf = (3 * nrpe + 3) & ~3;
+  const size_t scr_bytes = (size_t)NREP * tabf * 8 > 4096 ? (size_t)NREP * tabf * 8 : 4096;
+  const size_t lds = (size_t)LP * 36 + (size_t)NHW * (3 * LR * 64 + scr_bytes + 2 * tabf * 4);
+  if (p.H % NHW != 0) return HFL_EINVAL;
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) return HFL_ECAPACITY;
+  if (per_cu > 8) per_cu = 8;
+  int bx = p.n_windows;
+  const int capx = hfl_num_cus() * per_cu / (p.H / NHW) + 1;
+  if (bx > capx) bx = capx;
+  dim3 grid((unsigned)bx, (unsigned)(p.H / NHW));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd2_kernel<T, G, NREP>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  window_attn_bwd2_kernel<T, G, NREP><<<grid, NHW * 64, lds, s>>>(p);
+  HFL_RETURN_LAST_ERROR();
+}
+
 template <int T, int G>
 static int launch_window_bwd(const WinBwdParams& p, hipStream_t s) {
   constexpr int LP = T * 16;
@@ -1805,6 +2203,12 @@ static int launch_window_bwd(const WinBwdParams& p, hipStream_t s) {
   const size_t lds = (size_t)LP * (16 + 16 + 4) + (size_t)NHW * 4 * LP * 16 * 4 + (size_t)NHW * 3 * LP * 4 +
                      (p.table ? (size_t)2 * NHW * 3 * nrpe * 4 : 0);
   if (p.H % NHW != 0) return HFL_EINVAL;
+  if (g_window_bwd_variant >= 2 && 3 * (2 * p.bnd + 1) <= 1023) {
+    // (replicated fixed-point tables, NREP = 4 / 16, measured slower: the LDS they take costs more occupancy than the
+    // equal-address conflicts they remove -- tools/attn_bwd_bench.py history in DESIGN.md)
+    const int rc = launch_window_bwd2<T, G, 1>(p, s);
+    if (rc != HFL_ECAPACITY) return rc;              // tables that do not fit LDS: first-generation kernel below
+  }
   int bx = p.n_windows;
   const int capx = hfl_num_cus() * 8 / (p.H / NHW) + 1;
   if (bx > capx) bx = capx;
@@ -1817,6 +2221,8 @@ static int launch_window_bwd(const WinBwdParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" void hfl_internal_set_window_bwd(int v) { g_window_bwd_variant = v; }
 
 extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv,
                                         const float* dout, const uint32_t* tok_meta,
