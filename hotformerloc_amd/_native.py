@@ -87,6 +87,9 @@ SIGNATURES = {
     'hfl_wgrad_x3_workspace': (c_int64, [c_int64, c_int64, c_int64]),
     'hfl_wgrad_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'hfl_layer_norm_bwd_blocks': (c_int, [c_int64, c_int64]),
+    'hfl_layer_norm_bwd_add': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                       c_float, c_void_p]),
+    'hfl_layer_norm_bwd_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'hfl_layer_norm_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                    c_float, c_void_p]),
     'hfl_set_variant': (c_int, [c_char_p, c_int]),

@@ -361,6 +361,39 @@ class MlpX3Fn(torch.autograd.Function):
         return dh, dw1, db1, dw2, db2
 
 
+class LnMlpResidualX3Fn(torch.autograd.Function):
+    """x + fc2(gelu(fc1(LN(x)))): the whole pre-norm MLP branch of a transformer block (models/octformer_backbone.py:
+    275-278 with layer scale and stochastic depth off) as five launches forward (LN -> split2, fc1 + GELU, fc2 + bias +
+    residual) and seven backward; no element-wise pass: LayerNorm writes the GEMM operand, the residual add rides in fc2's
+    epilogue, the skip path's gradient joins inside the LayerNorm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        hs = ops.layer_norm_split2(x2, gamma, beta, eps)
+        gs, pre = ops.linear_x3_gelu_fwd(hs, _w2_cached(w1, False), b1)
+        ctx.save_for_backward(x2, gamma, hs, gs, pre, w1, w2)
+        ctx.shape, ctx.eps = shape, eps
+        return ops.linear_x3(gs, _w2_cached(w2, False), bias=b2, residual=x2).view(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, gamma, hs, gs, pre, w1, w2 = ctx.saved_tensors
+        dout2 = dout.reshape(-1, w2.shape[0]).contiguous()
+        dys = ops.split2(dout2)
+        dps = ops.linear_x3_gelu_bwd(dys, _w2_cached(w2, True), pre)
+        dw2, db2 = ops.wgrad_x3(dys, gs, with_bias=True)
+        dh = ops.linear_x3(dps, _w2_cached(w1, True))
+        dw1, db1 = ops.wgrad_x3(dps, hs, with_bias=True)
+        dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)
+        return dx.view(ctx.shape), dg, dbeta, None, dw1, db1, dw2, db2
+
+
+def ln_mlp_residual_x3(x, gamma, beta, eps, w1, b1, w2, b2):
+    return LnMlpResidualX3Fn.apply(x, gamma, beta, eps, w1, b1, w2, b2)
+
+
 def mlp_x3(h, w1, b1, w2, b2):
     return MlpX3Fn.apply(h, w1, b1, w2, b2)
 

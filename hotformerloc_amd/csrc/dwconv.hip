@@ -158,17 +158,22 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_partial(float* __restrict__ 
 }
 
 // out[i] = sum_p partial[p, i] in a fixed order (bitwise reproducible)
-__global__ void dwconv_wgrad_reduce(float* __restrict__ out, const float* __restrict__ partial,
-                                    int n_partial, int64_t kc) {
-  __shared__ float s[4][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+__global__ void __launch_bounds__(1024) dwconv_wgrad_reduce(float* __restrict__ out, const float* __restrict__ partial,
+                                                            int n_partial, int64_t kc) {
+  __shared__ float s[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;                  // 16 groups walk the partial slabs
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (i < kc)
-    for (int p = grp; p < n_partial; p += 4) acc += partial[(int64_t)p * kc + i];
+    for (int p = grp; p < n_partial; p += 16) acc += partial[(int64_t)p * kc + i];
   s[grp][lane] = acc;
   __syncthreads();
-  if (grp == 0 && i < kc) out[i] = (s[0][lane] + s[1][lane]) + (s[2][lane] + s[3][lane]);
+  if (grp == 0 && i < kc) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += s[g][lane];
+    out[i] = v;
+  }
 }
 
 template <typename IdxT>
@@ -209,7 +214,7 @@ static int launch_wgrad(float* out, const float* grad, const float* data, const 
     dwconv_wgrad_partial<IdxT><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows,
                                                                   (int)C, K, g.tpr, g.rpb);
     const int64_t kc = (int64_t)K * C;
-    dwconv_wgrad_reduce<<<(int)hfl_cdiv(kc, 64), 256, 0, s>>>(out, partial, blocks * g.rpb, kc);
+    dwconv_wgrad_reduce<<<(int)hfl_cdiv(kc, 64), 1024, 0, s>>>(out, partial, blocks * g.rpb, kc);
   } else {
     const int64_t kc = (int64_t)K * C;
     dwconv_wgrad_scalar<IdxT><<<(int)hfl_cdiv(kc, 256), 256, 0, s>>>(out, grad, data, neigh, n_rows, C, K);

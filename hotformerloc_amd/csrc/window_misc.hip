@@ -376,7 +376,7 @@ template <int TPR, int VPL>
 __global__ void __launch_bounds__(256)
 layer_norm_bwd_kernel(float* __restrict__ dx, float* __restrict__ dg_part, float* __restrict__ db_part,
                       const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                      int64_t n_rows, float eps) {
+                      const float* dres, int64_t n_rows, float eps) {
   constexpr int C = TPR * VPL * 4;
   constexpr int RPB = 256 / TPR;
   __shared__ float4 s_red[256];
@@ -433,6 +433,10 @@ layer_norm_bwd_kernel(float* __restrict__ dx, float* __restrict__ dg_part, float
         o.y = rstd * (d[v].y - s1 - a[v].y * s2);
         o.z = rstd * (d[v].z - s1 - a[v].z * s2);
         o.w = rstd * (d[v].w - s1 - a[v].w * s2);
+        if (dres != nullptr) {       // pre-norm residual branch y = x + f(LN(x)): the skip path's gradient joins here
+          const float4 rs = reinterpret_cast<const float4*>(dres + r * C)[v * TPR + tx];
+          o.x += rs.x; o.y += rs.y; o.z += rs.z; o.w += rs.w;
+        }
         reinterpret_cast<float4*>(dx + r * C)[v * TPR + tx] = o;
       }
     }
@@ -466,8 +470,8 @@ static int ln_bwd_blocks(int64_t n, int rpb) {
 
 template <int TPR, int VPL>
 static int launch_ln_bwd(float* dx, float* dgp, float* dbp, const float* dy, const float* x, const float* gamma,
-                         int64_t n, float eps, hipStream_t s) {
-  layer_norm_bwd_kernel<TPR, VPL><<<ln_bwd_blocks(n, 256 / TPR), 256, 0, s>>>(dx, dgp, dbp, dy, x, gamma, n, eps);
+                         const float* dres, int64_t n, float eps, hipStream_t s) {
+  layer_norm_bwd_kernel<TPR, VPL><<<ln_bwd_blocks(n, 256 / TPR), 256, 0, s>>>(dx, dgp, dbp, dy, x, gamma, dres, n, eps);
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -608,6 +612,51 @@ int hfl_add_layer_norm_split3(float* x_out, uint16_t* h_out, const float* x, con
                      eps, 1, static_cast<hipStream_t>(stream));
 }
 
+}  // extern "C" (reopened below)
+
+namespace {
+// out[a][c] = sum over the partial rows of array a, fixed order: 4 float4 columns x 64 row groups per workgroup, tree in LDS
+__global__ void __launch_bounds__(256)
+column_sum_kernel(float* __restrict__ out0, float* __restrict__ out1, const float* __restrict__ part0,
+                  const float* __restrict__ part1, int n_rows, int C) {
+  __shared__ float4 red[64][4];
+  const float* part = blockIdx.y == 0 ? part0 : part1;
+  float* out = blockIdx.y == 0 ? out0 : out1;
+  const int col = threadIdx.x & 3, rg = threadIdx.x >> 2;
+  const int c4 = blockIdx.x * 4 + col;                       // float4 column
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < C)
+    for (int r = rg; r < n_rows; r += 64) {
+      const float4 v = reinterpret_cast<const float4*>(part + (int64_t)r * C)[c4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  red[rg][col] = a;
+  __syncthreads();
+  for (int half = 32; half > 0; half >>= 1) {
+    if (rg < half) {
+      const float4 b = red[rg + half][col];
+      float4 m = red[rg][col];
+      m.x += b.x; m.y += b.y; m.z += b.z; m.w += b.w;
+      red[rg][col] = m;
+    }
+    __syncthreads();
+  }
+  if (rg == 0 && c4 * 4 < C) reinterpret_cast<float4*>(out)[c4] = red[0][col];
+}
+}  // namespace
+
+extern "C" {
+
+/* dgamma / dbeta (C) from the partial rows hfl_layer_norm_bwd wrote (fixed summation order). */
+int hfl_layer_norm_bwd_finalize(float* dgamma, float* dbeta, const float* dgamma_partial, const float* dbeta_partial,
+                                int n_blocks, int64_t channels, hfl_stream_t stream) {
+  if (n_blocks <= 0 || channels <= 0 || channels % 4 != 0) return HFL_EINVAL;
+  dim3 grid((unsigned)hfl_cdiv(channels, 16), 2);
+  column_sum_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(dgamma, dbeta, dgamma_partial, dbeta_partial,
+                                                                        n_blocks, (int)channels);
+  HFL_RETURN_LAST_ERROR();
+}
+
 /* Number of (blocks, C) partial-sum rows hfl_layer_norm_bwd writes for this problem. */
 int hfl_layer_norm_bwd_blocks(int64_t n_rows, int64_t channels) {
   switch (channels) {
@@ -620,20 +669,26 @@ int hfl_layer_norm_bwd_blocks(int64_t n_rows, int64_t channels) {
   }
 }
 
-int hfl_layer_norm_bwd(float* dx, float* dgamma_partial, float* dbeta_partial, const float* dy, const float* x,
-                       const float* gamma, int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream) {
+int hfl_layer_norm_bwd_add(float* dx, float* dgamma_partial, float* dbeta_partial, const float* dy, const float* x,
+                           const float* gamma, const float* dres, int64_t n_rows, int64_t channels, float eps,
+                           hfl_stream_t stream) {
   if (n_rows <= 0) return HFL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (channels) {
-    case 16:   return launch_ln_bwd<4, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
-    case 32:   return launch_ln_bwd<8, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
-    case 64:   return launch_ln_bwd<16, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
-    case 128:  return launch_ln_bwd<32, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
-    case 256:  return launch_ln_bwd<64, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
-    case 512:  return launch_ln_bwd<64, 2>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
-    case 1024: return launch_ln_bwd<64, 4>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, n_rows, eps, s);
+    case 16:   return launch_ln_bwd<4, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
+    case 32:   return launch_ln_bwd<8, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
+    case 64:   return launch_ln_bwd<16, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
+    case 128:  return launch_ln_bwd<32, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
+    case 256:  return launch_ln_bwd<64, 1>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
+    case 512:  return launch_ln_bwd<64, 2>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
+    case 1024: return launch_ln_bwd<64, 4>(dx, dgamma_partial, dbeta_partial, dy, x, gamma, dres, n_rows, eps, s);
     default:   return HFL_EINVAL;
   }
+}
+
+int hfl_layer_norm_bwd(float* dx, float* dgamma_partial, float* dbeta_partial, const float* dy, const float* x,
+                       const float* gamma, int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream) {
+  return hfl_layer_norm_bwd_add(dx, dgamma_partial, dbeta_partial, dy, x, gamma, nullptr, n_rows, channels, eps, stream);
 }
 
 int hfl_add_bias(float* out, const float* x, const float* y, const float* bias, int64_t n_rows,

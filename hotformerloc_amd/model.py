@@ -387,6 +387,17 @@ class MLP(nn.Module):
         return self.fc2(F.gelu(self.fc1(x)))
 
 
+def _mlp_branch(x, norm: nn.LayerNorm, mlp: 'MLP'):
+    """x + mlp(LN(x)) on the training path: one fused autograd Function when the shapes allow (LayerNorm writes the GEMM
+    operand, GELU and the residual ride in the GEMM epilogues, the skip gradient joins inside the LayerNorm backward)."""
+    f1, f2 = mlp.fc1, mlp.fc2
+    if (_GEMM_MODE == 'x3' and _TRAIN_X3 and _TRAIN_MLP and _TRAIN_LN and x.is_cuda and x.numel() > 0
+            and x.dtype == torch.float32 and x.shape[-1] in ops._LN_CHANNELS and f1.bias is not None and f2.bias is not None
+            and ag.linear_x3_ok(f1.in_features, f1.out_features) and ag.linear_x3_ok(f2.in_features, f2.out_features)):
+        return ag.ln_mlp_residual_x3(x, norm.weight, norm.bias, norm.eps, f1.weight, f1.bias, f2.weight, f2.bias)
+    return x + mlp(_ln(x, norm))
+
+
 class CPE(nn.Module):
     """models/layers/octformer_layers.py:122-142.  xcpe=False: depth-wise octree conv + LayerNorm (one fused kernel in
     inference); xcpe=True (PointTransformerV3's xCPE): full octree conv with bias + Linear + LayerNorm."""
@@ -513,6 +524,8 @@ class OctFormerBlock(nn.Module):
             bid = plan.row_cloud(depth, with_relay=False)
             x = x + self.drop_path(self.gamma1 * self.attention(_ln(x, self.norm1), plan, depth), bid, plan.B)
             return x + self.drop_path(self.gamma2 * self.mlp(_ln(x, self.norm2)), bid, plan.B)
+        if _grad_path(x):
+            return _mlp_branch(x + self.attention(_ln(x, self.norm1), plan, depth), self.norm2, self.mlp)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
         return x + self.mlp(h)
 
@@ -570,6 +583,8 @@ class HOTFormerBlock(nn.Module):
             bid = plan.row_cloud(depth, with_relay=True)
             buf = buf + self.drop_path(self.gamma1 * self.attention(_ln(buf, self.norm1), plan, depth), bid, plan.B)
             return buf + self.drop_path(self.gamma2 * self.mlp(_ln(buf, self.norm2)), bid, plan.B)
+        if _grad_path(buf):
+            return _mlp_branch(buf + self.attention(_ln(buf, self.norm1), plan, depth), self.norm2, self.mlp)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
         return buf + self.mlp(h)
 

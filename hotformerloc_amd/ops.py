@@ -180,9 +180,10 @@ def layer_norm(x, weight, bias, eps: float = 1e-5):
     return out
 
 
-def layer_norm_bwd(dy, x, weight, eps: float = 1e-5):
-    """(dx, dgamma, dbeta) of LayerNorm over the last axis (hfl_layer_norm_bwd; statistics recomputed from x)."""
-    _dev(dy, x, weight)
+def layer_norm_bwd(dy, x, weight, eps: float = 1e-5, dres=None):
+    """(dx, dgamma, dbeta) of LayerNorm over the last axis (hfl_layer_norm_bwd; statistics recomputed from x); with
+    `dres` the gradient of a skip connection around the normalised branch is added to dx in the same pass."""
+    _dev(dy, x, weight, dres)
     c = x.shape[-1]
     x2, dy2 = _f32c(x).view(-1, c), _f32c(dy).view(-1, c)
     lib = _native.load()
@@ -191,10 +192,13 @@ def layer_norm_bwd(dy, x, weight, eps: float = 1e-5):
         raise _native.NativeLibraryError('hfl_layer_norm_bwd: unsupported channel count %d' % c)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     part = torch.empty((2, nb, c), dtype=torch.float32, device=x.device)
-    check(lib.hfl_layer_norm_bwd(dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), dy2.data_ptr(), x2.data_ptr(),
-                                 _f32c(weight).data_ptr(), x2.shape[0], c, float(eps), _stream()), 'hfl_layer_norm_bwd')
-    sums = part.sum(1)
-    return dx, sums[0], sums[1]
+    check(lib.hfl_layer_norm_bwd_add(dx.data_ptr(), part[0].data_ptr(), part[1].data_ptr(), dy2.data_ptr(), x2.data_ptr(),
+                                     _f32c(weight).data_ptr(), None if dres is None else _f32c(dres).data_ptr(),
+                                     x2.shape[0], c, float(eps), _stream()), 'hfl_layer_norm_bwd')
+    dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    check(lib.hfl_layer_norm_bwd_finalize(dgb[0].data_ptr(), dgb[1].data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
+                                          nb, c, _stream()), 'hfl_layer_norm_bwd_finalize')
+    return dx, dgb[0], dgb[1]
 
 
 def add_layer_norm(x, y, weight, bias, eps: float = 1e-5, add_bias=None, inplace: bool = False):

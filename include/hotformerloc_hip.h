@@ -424,6 +424,13 @@ int hfl_relay_token_init_bwd(float* dx, const float* drt, const uint32_t* tok_me
 int hfl_layer_norm_bwd_blocks(int64_t n_rows, int64_t channels);
 int hfl_layer_norm_bwd(float* dx, float* dgamma_partial, float* dbeta_partial, const float* dy, const float* x,
                        const float* gamma, int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
+/* The same with dx = dres + (LayerNorm input gradient): the skip path of a pre-norm residual branch y = x + f(LN(x))
+ * (models/octformer_backbone.py:275-278) joins inside the kernel; dres (n_rows, channels) may be NULL and may alias dx. */
+int hfl_layer_norm_bwd_add(float* dx, float* dgamma_partial, float* dbeta_partial, const float* dy, const float* x,
+                           const float* gamma, const float* dres, int64_t n_rows, int64_t channels, float eps,
+                           hfl_stream_t stream);
+int hfl_layer_norm_bwd_finalize(float* dgamma, float* dbeta, const float* dgamma_partial, const float* dbeta_partial,
+                                int n_blocks, int64_t channels, hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 11. TruncatedSmoothAP ranking core (replaces the (B,P,B) tensor algebra of

@@ -670,6 +670,33 @@ def test_mlp_x3_matches_fp64_autograd():
             assert err < 2e-5, (m, c, name, err)
 
 
+def test_ln_mlp_residual_x3_matches_fp64_autograd():
+    """x + fc2(gelu(fc1(LN(x)))) as one autograd Function (autograd.LnMlpResidualX3Fn): output and all seven gradients
+    against torch autograd in fp64, <= 3e-5 relative L2."""
+    from hotformerloc_amd import autograd as ag
+    g = torch.Generator().manual_seed(43)
+    for m, c in ((777, 128), (3001, 256)):
+        x = torch.randn(m, c, generator=g) * 1.5
+        gamma = 1 + 0.2 * torch.randn(c, generator=g)
+        beta = 0.1 * torch.randn(c, generator=g)
+        w1 = torch.randn(4 * c, c, generator=g) * 0.06
+        b1 = torch.randn(4 * c, generator=g) * 0.1
+        w2 = torch.randn(c, 4 * c, generator=g) * 0.03
+        b2 = torch.randn(c, generator=g) * 0.1
+        dy = torch.randn(m, c, generator=g)
+        F = torch.nn.functional
+        r = [t.double().requires_grad_(True) for t in (x, gamma, beta, w1, b1, w2, b2)]
+        ref = r[0] + F.linear(F.gelu(F.linear(F.layer_norm(r[0], (c,), r[1], r[2], 1e-5), r[3], r[4])), r[5], r[6])
+        ref.backward(dy.double())
+        d = [t.to(DEV).requires_grad_(True) for t in (x, gamma, beta, w1, b1, w2, b2)]
+        out = ag.ln_mlp_residual_x3(d[0], d[1], d[2], 1e-5, d[3], d[4], d[5], d[6])
+        out.backward(dy.to(DEV))
+        assert ((out.detach().cpu().double() - ref.detach()).norm() / ref.detach().norm()).item() < 2e-5
+        for a, b, name in zip(d, r, ('dx', 'dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2')):
+            err = ((a.grad.cpu().double() - b.grad).norm() / b.grad.norm()).item()
+            assert err < 3e-5, (m, c, name, err)
+
+
 def test_window_attention_backward_matches_autograd():
     """dQ, dK, dV and the RPE-table gradient of the HIP backward against torch autograd over the
     oracle's materialised formulation (both window kinds, dilation, relay token)."""

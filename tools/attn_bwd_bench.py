@@ -48,6 +48,10 @@ for d, H, G, dil in ((md, 8, 0, 1), (md, 8, 0, params.dilation), (md - 1, 16, 1,
         dq2 = torch.zeros_like(qkv)
         t_norpe[variant] = timeit(lambda: ops.check(lib.hfl_window_attention_bwd(dq2.data_ptr(), None, qkv.data_ptr(), dout.data_ptr(),
                                   plan.meta[d].data_ptr(), None, ctypes.byref(desc), ops._stream()), 'bwd'))
+    dq3 = torch.zeros_like(qkv)
+    t_noflush = timeit(lambda: ops.check(lib.hfl_window_attention_bwd(dq3.data_ptr(), None, qkv.data_ptr(), dout.data_ptr(),
+                       plan.meta[d].data_ptr(), table.data_ptr(), ctypes.byref(desc), ops._stream()), 'bwd'))
+    print('   gen2 with the table but without the final global atomics: %.1f us' % t_noflush)
     lib.hfl_set_variant(b'window_bwd', 2)
     print('   without RPE table (no bias lookups, no table-gradient atomics): gen1 %.1f us, gen2 %.1f us' % (t_norpe[1], t_norpe[2]))
     e = (res[1][1] - res[2][1]).abs().max().item() / res[1][1].abs().max().item()
