@@ -394,6 +394,51 @@ def ln_mlp_residual_x3(x, gamma, beta, eps, w1, b1, w2, b2):
     return LnMlpResidualX3Fn.apply(x, gamma, beta, eps, w1, b1, w2, b2)
 
 
+class LnAttnResidualX3Fn(torch.autograd.Function):
+    """x + proj(window_attention(qkv(LN(x)))): the pre-norm attention branch of a transformer block
+    (models/octformer_backbone.py:59-93,275-278; layer scale and stochastic depth off) without element-wise passes:
+    LayerNorm writes the qkv GEMM's operand, the attention kernel writes the proj GEMM's operand, the residual add rides in
+    proj's epilogue, and in the backward the skip gradient joins inside the LayerNorm backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous()
+        hs = ops.layer_norm_split2(x2, gamma, beta, eps)
+        qkv = ops.linear_x3(hs, _w2_cached(wqkv, False), bias=bqkv)
+        os_ = ops.window_attention(qkv, tok_meta, rpe_table, out_split=2, **cfg)
+        ctx.save_for_backward(x2, gamma, hs, qkv, os_, rpe_table if rpe_table is not None else x2.new_empty(0), tok_meta,
+                              wqkv, wp)
+        ctx.shape, ctx.eps, ctx.cfg, ctx.has_table, ctx.has_qkv_bias = shape, eps, cfg, rpe_table is not None, bqkv is not None
+        return ops.linear_x3(os_, _w2_cached(wp, False), bias=bp, residual=x2).view(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, gamma, hs, qkv, os_, table, tok_meta, wqkv, wp = ctx.saved_tensors
+        cfg = ctx.cfg
+        dout2 = dout.reshape(-1, wp.shape[0]).contiguous()
+        dys = ops.split2(dout2)
+        do = ops.linear_x3(dys, _w2_cached(wp, True))
+        dwp, dbp = ops.wgrad_x3(dys, os_, with_bias=True)
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.zeros_like(table) if ctx.has_table else None
+        d = _desc(cfg['n_tokens'], cfg['n_windows'], cfg['patch_size'], cfg['dilation'], cfg['n_relay'],
+                  cfg['n_heads'], cfg['batch_size'], cfg.get('rt_row0', 0), cfg.get('depth', 0))
+        check(_native.load().hfl_window_attention_bwd(
+            dqkv.data_ptr(), dtable.data_ptr() if ctx.has_table else None, qkv.data_ptr(), do.data_ptr(),
+            tok_meta.data_ptr(), table.data_ptr() if ctx.has_table else None, ctypes.byref(d), ops._stream()),
+            'hfl_window_attention_bwd')
+        dqs = ops.split2(dqkv)
+        dh = ops.linear_x3(dqs, _w2_cached(wqkv, True))
+        dwqkv, dbqkv = ops.wgrad_x3(dqs, hs, with_bias=ctx.has_qkv_bias)
+        dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)
+        return dx.view(ctx.shape), dg, dbeta, None, dwqkv, dbqkv, dtable, None, None, dwp, dbp
+
+
+def ln_attn_residual_x3(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp):
+    return LnAttnResidualX3Fn.apply(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp)
+
+
 def mlp_x3(h, w1, b1, w2, b2):
     return MlpX3Fn.apply(h, w1, b1, w2, b2)
 

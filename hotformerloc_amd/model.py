@@ -469,6 +469,21 @@ class OctreeAttention(nn.Module):
         """x: (N_t [+ W], C) token rows [followed by the relay-token rows]."""
         return self.proj(self.core(self.qkv(x), plan, depth))
 
+    def residual_branch(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
+        """x + attention(LN(x)) on the training path: one fused autograd Function when the shapes allow."""
+        C = self.dim
+        if (_GEMM_MODE == 'x3' and _TRAIN_X3 and _TRAIN_MLP and _TRAIN_LN and x.is_cuda and x.numel() > 0
+                and x.dtype == torch.float32 and C in ops._LN_CHANNELS and ag.linear_x3_ok(C, 3 * C)
+                and ag.linear_x3_ok(C, C) and self.proj.bias is not None):
+            nt = plan.n_tokens[depth]
+            cfg = dict(n_tokens=nt, n_windows=plan.n_windows[depth], patch_size=self.patch_size,
+                       dilation=self.dilation, n_relay=self.rt_per_window, n_heads=self.num_heads,
+                       batch_size=plan.B, rt_row0=nt, depth=depth)
+            table = None if self.rpe is None else self.rpe.rpe_table
+            return ag.ln_attn_residual_x3(x, norm1.weight, norm1.bias, norm1.eps, self.qkv.weight, self.qkv.bias, table,
+                                          plan.meta[depth], cfg, self.proj.weight, self.proj.bias)
+        return x + self.forward(_ln(x, norm1), plan, depth)
+
     def forward_split(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
         """LN1 -> qkv -> attention, split-precision path; returns the bf16 operand of `proj`."""
         if _GEMM_MODE == 'x3':         # qkv bias folded into the GEMM epilogue, attention writes split2 rows
@@ -525,7 +540,7 @@ class OctFormerBlock(nn.Module):
             x = x + self.drop_path(self.gamma1 * self.attention(_ln(x, self.norm1), plan, depth), bid, plan.B)
             return x + self.drop_path(self.gamma2 * self.mlp(_ln(x, self.norm2)), bid, plan.B)
         if _grad_path(x):
-            return _mlp_branch(x + self.attention(_ln(x, self.norm1), plan, depth), self.norm2, self.mlp)
+            return _mlp_branch(self.attention.residual_branch(x, self.norm1, plan, depth), self.norm2, self.mlp)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
         return x + self.mlp(h)
 
@@ -584,7 +599,7 @@ class HOTFormerBlock(nn.Module):
             buf = buf + self.drop_path(self.gamma1 * self.attention(_ln(buf, self.norm1), plan, depth), bid, plan.B)
             return buf + self.drop_path(self.gamma2 * self.mlp(_ln(buf, self.norm2)), bid, plan.B)
         if _grad_path(buf):
-            return _mlp_branch(buf + self.attention(_ln(buf, self.norm1), plan, depth), self.norm2, self.mlp)
+            return _mlp_branch(self.attention.residual_branch(buf, self.norm1, plan, depth), self.norm2, self.mlp)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
         return buf + self.mlp(h)
 
