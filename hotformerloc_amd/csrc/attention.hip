@@ -883,7 +883,8 @@ window_attn_kernel_v4(const WinParams p) {
 typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
 typedef short att_s4 __attribute__((ext_vector_type(4)));
 
-template <int T, int G, bool RPE>
+// RPE: 0 none, 1 expanded x + y-z tables (two lookups), 2 three clamped 1-D tables (deep octrees, three lookups)
+template <int T, int G, int RPE>
 __global__ void __launch_bounds__(256)
     __attribute__((amdgpu_waves_per_eu(v4_waves_per_simd(T, G), v4_waves_per_simd(T, G))))
 window_attn_kernel_v5(const WinParams p) {
@@ -895,13 +896,15 @@ window_attn_kernel_v5(const WinParams p) {
   const int H = p.H, K = p.K;
   const int C = H * 16;
   const int R = (1 << p.depth) - 1, W = 2 * R + 1;
-  const int TS = RPE ? ((W + W * W + 3) & ~3) : 0;
-  int4* s_qry0 = reinterpret_cast<int4*>(smem);                        // [2][LP] {4x, 4(yW+z), id, row}
-  int2* s_key0 = reinterpret_cast<int2*>(s_qry0 + 2 * LP);             // [2][LP] {4(R-x), 4(W+(R-y)W+R-z)}
+  const int TS = RPE == 1 ? ((W + W * W + 3) & ~3) : RPE == 2 ? ((3 * W + 3) & ~3) : 0;
+  const int nhw = blockDim.x >> 6;
+  // the tables come FIRST: form 2 packs two LDS byte addresses into the halves of one register, so they must stay below
+  // 64 KiB (the launcher checks nhw * TS * 4 + 12 W < 65536)
+  float* s_tab = reinterpret_cast<float*>(smem);                       // [nhw][TS] * log2e
+  int4* s_qry0 = reinterpret_cast<int4*>(s_tab + nhw * TS);            // [2][LP] {4x, 4(yW+z) | packed 4y, 4z, id, row}
+  int2* s_key0 = reinterpret_cast<int2*>(s_qry0 + 2 * LP);             // [2][LP] {4(R-x), 4(W+(R-y)W+R-z) | packed}
   int* s_kbid0 = reinterpret_cast<int*>(s_key0 + 2 * LP);              // [2][LP] batch id, -1 dead
   unsigned char* s_v0 = reinterpret_cast<unsigned char*>(s_kbid0 + 2 * LP);   // [nhw][2 NP * 16 rows][64 B]  V rows
-  const int nhw = blockDim.x >> 6;
-  float* s_tab = reinterpret_cast<float*>(s_v0 + nhw * (2 * NP * 16) * 64);  // [nhw][TS] * log2e
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -984,9 +987,14 @@ window_attn_kernel_v5(const WinParams p) {
       } else if (G > 0 && j == K) {
         row = rt_row;
       }
-      s_key[j] = make_int2(4 * (R - x), 4 * (W + (R - y) * W + (R - z)));
+      if (RPE == 2) {   // byte offsets into [X | Y | Z]: low half y, high half z (each < 12 W < 65536, sums included)
+        s_key[j] = make_int2(4 * (R - x), (4 * (W + R - y)) | ((4 * (2 * W + R - z)) << 16));
+        s_qry[j] = make_int4(4 * x, (4 * y) | ((4 * z) << 16), bid, row);
+      } else {
+        s_key[j] = make_int2(4 * (R - x), 4 * (W + (R - y) * W + (R - z)));
+        s_qry[j] = make_int4(4 * x, 4 * (y * W + z), bid, row);
+      }
       s_kbid[j] = bid;
-      s_qry[j] = make_int4(4 * x, 4 * (y * W + z), bid, row);
     }
     // stage this head's V rows exactly as loaded: row (tile, key) = 64 B [16 x hi | 16 x lo], lane (c, g) owns chunk g
 #pragma unroll
@@ -1032,7 +1040,7 @@ window_attn_kernel_v5(const WinParams p) {
         // the relay tile needs no metadata (no RPE, its id is rt_bid, its row rt_row): do not read slots >= K
         const int4 qm = is_rt ? make_int4(0, 0, -1, -1) : s_qry[qt * 16 + c];
         const int q_bid = is_rt ? rt_bid : qm.z;
-        const int qxa = qm.x + tabb, qyza = qm.y + tabb;
+        const int qxa = qm.x + tabb, qyza = qm.y + (RPE == 2 ? tabb * 0x10001 : tabb);
         const att_h8 bqh = __builtin_bit_cast(att_h8, qh[qt]);
         const att_h8 bql = __builtin_bit_cast(att_h8, ql[qt]);
 
@@ -1045,7 +1053,7 @@ window_attn_kernel_v5(const WinParams p) {
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak, bqh, acc, 0, 0, 0);
           s[kt] = acc;
         }
-        if (RPE && !is_rt) {                     // no RPE for the relay row / column (octformer_backbone.py:78-80)
+        if (RPE == 1 && !is_rt) {                // no RPE for the relay row / column (octformer_backbone.py:78-80)
 #pragma unroll
           for (int kt = 0; kt < TW; ++kt) {
             f32x4 bx, byz;
@@ -1055,6 +1063,20 @@ window_attn_kernel_v5(const WinParams p) {
               byz[r] = *reinterpret_cast<lds_f32*>(kyza[kt][r] + qyza);
             }
             s[kt] += bx + byz;
+          }
+        }
+        if (RPE == 2 && !is_rt) {
+#pragma unroll
+          for (int kt = 0; kt < TW; ++kt) {
+            f32x4 bx, by, bz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t t = (uint32_t)(kyza[kt][r] + qyza);           // both halves are LDS byte addresses
+              bx[r] = *reinterpret_cast<lds_f32*>(kxa[kt][r] + qxa);
+              by[r] = *reinterpret_cast<lds_f32*>((int)(t & 0xFFFFu));
+              bz[r] = *reinterpret_cast<lds_f32*>((int)(t >> 16));
+            }
+            s[kt] += (bx + by) + bz;
           }
         }
         if (MASKED) {
@@ -1155,6 +1177,41 @@ rpe_expand_kernel(float* __restrict__ out, const float* __restrict__ table, int 
   out[i] = v * 1.4426950408889634f;
 }
 
+// Expanded table, form 2 (deep octrees: depth 6-7, or coordinates beyond pos_bnd): three 1-D tables over the FULL
+// coordinate difference range with the reference's clamp baked in,
+//   out[h][a * W + i] = table[a * nrpe + clamp(i - R, -bnd, bnd) + bnd, h] * log2e,   a = x, y, z;  TS = (3 W + 3) & ~3
+// -- three lookups and no clamp arithmetic per score (the (2R+1)^2 y-z table of form 1 would be 64 KB per head at depth 6)
+__global__ void __launch_bounds__(256)
+rpe_expand3_kernel(float* __restrict__ out, const float* __restrict__ table, int H, int bnd, int R) {
+  const int W = 2 * R + 1;
+  const int TS = (3 * W + 3) & ~3;
+  const int nrpe = 2 * bnd + 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * TS) return;
+  const int h = i / TS, e = i % TS;
+  float v = 0.f;
+  if (e < 3 * W) {
+    const int a = e / W;
+    int d = e % W - R;
+    d = d < -bnd ? -bnd : (d > bnd ? bnd : d);
+    v = table[(a * nrpe + d + bnd) * H + h];
+  }
+  out[i] = v * 1.4426950408889634f;
+}
+
+// which expanded form a (depth, pos_bnd) pair takes: 1 = x table + y-z table (no clamp needed, depth <= 5), 2 = three
+// clamped 1-D tables (depth <= 7), 0 = none (the three-lookup kernel v2 reads the original table)
+static inline int rpe_form(int depth, int bnd) {
+  if (depth < 1 || depth > 7) return 0;
+  if (depth <= 5 && ((1 << depth) - 1) <= bnd) return 1;
+  return 2;
+}
+static inline size_t rpe_form_floats(int depth, int bnd) {      // per head
+  const int W = 2 * ((1 << depth) - 1) + 1;
+  const int f = rpe_form(depth, bnd);
+  return f == 1 ? (size_t)((W + W * W + 3) & ~3) : f == 2 ? (size_t)((3 * W + 3) & ~3) : 0;
+}
+
 static int g_window_variant = 4;
 static int g_window_v4_wgs_per_cu = 1;   // multiples of the resident workgroup count
 static int g_window_dbg = 0;
@@ -1189,13 +1246,17 @@ static int launch_window(const WinParams& p, hipStream_t s) {
       // fp16 (hi, lo) operand layout: only the v5 kernel reads it (callers ask hfl_window_attention_f16_ok first).
       // Heads per workgroup: 4, or 2 when the expanded RPE tables of 4 heads do not leave room in LDS (depth 5)
       const int np5 = (T + 1) / 2;
+      const int form = p.table ? rpe_form(p.depth, p.bnd) : 0;
+      const size_t ts5 = p.table ? rpe_form_floats(p.depth, p.bnd) : 0;
       int hp5 = hpw;
       size_t lds5 = 0;
       for (;; hp5 >>= 1) {
-        lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hp5 * ts4 * 4 + (size_t)hp5 * (2 * np5 * 16) * 64;
+        lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hp5 * ts5 * 4 + (size_t)hp5 * (2 * np5 * 16) * 64;
         if (lds5 <= 72 * 1024 || hp5 <= 2 || p.H % (hp5 / 2) != 0) break;
       }
-      if (p.clamp || p.depth < 1 || p.depth > 5 || (p.table != nullptr && p.rpe2 == nullptr) ||
+      const int W5 = 2 * ((1 << (p.depth > 0 && p.depth <= 7 ? p.depth : 0)) - 1) + 1;
+      if (p.depth < 1 || p.depth > 7 || (p.table != nullptr && (p.rpe2 == nullptr || form == 0)) ||
+          (p.table == nullptr && p.depth > 10) || (form == 2 && (size_t)hp5 * ts5 * 4 + 12 * (size_t)W5 >= 65536) ||
           rows_total * 3 * p.H * 16 * 4 >= (int64_t)1 << 32 || lds5 > 72 * 1024 || hp5 * 64 < LP || p.qkv_bias != nullptr)
         return HFL_EINVAL;
       const int groups5 = p.H / hp5;
@@ -1208,17 +1269,15 @@ static int launch_window(const WinParams& p, hipStream_t s) {
       if (px > p.n_windows) px = p.n_windows;
       dim3 grid5((unsigned)px, (unsigned)groups5);
       hipError_t e;
-      if (p.table == nullptr) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
-        if (e != hipSuccess) return (int)e;
-        window_attn_kernel_v5<T, G, false><<<grid5, hp5 * 64, lds5, s>>>(p);
-      } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
-        if (e != hipSuccess) return (int)e;
-        window_attn_kernel_v5<T, G, true><<<grid5, hp5 * 64, lds5, s>>>(p);
-      }
+#define HFL_V5_LAUNCH(F)                                                                                  \
+  {                                                                                                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, F>),                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);                       \
+    if (e != hipSuccess) return (int)e;                                                                   \
+    window_attn_kernel_v5<T, G, F><<<grid5, hp5 * 64, lds5, s>>>(p);                                      \
+  }
+      if (form == 0) HFL_V5_LAUNCH(0) else if (form == 1) HFL_V5_LAUNCH(1) else HFL_V5_LAUNCH(2)
+#undef HFL_V5_LAUNCH
     } else if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
         (p.table == nullptr || p.rpe2 != nullptr) && rows_total * 3 * p.H * 16 * 4 < (int64_t)1 << 32 &&
         lds4 <= 72 * 1024 && hpw * 64 >= LP) {
@@ -1425,20 +1484,21 @@ int hfl_set_variant(const char* key, int value) {
  * configuration: the v5 kernel needs the expanded RPE table (depth <= 5, no clamp) and <= 72 KiB of LDS */
 int hfl_window_attention_f16_ok(const hfl_window_attn_desc* d, int64_t n_rows_total) {
   if (d == nullptr || d->n_heads <= 0 || d->patch_size % 16 != 0) return 0;
-  if (d->depth < 1 || d->depth > 5 || ((1 << d->depth) - 1) > d->pos_bnd) return 0;
+  if (rpe_form(d->depth, d->pos_bnd) == 0) return 0;
   if (g_window_variant != 4) return 0;
   const int T = d->patch_size / 16 + d->n_relay;
   if (T < 1 || T > 5) return 0;
   int hpw = g_window_heads_per_wg;
   if (hpw < 1 || hpw > 4 || d->n_heads % hpw != 0) hpw = (d->n_heads % 4 == 0) ? 4 : (d->n_heads % 2 == 0) ? 2 : 1;
   const int LP = T * 16;
-  const int R4 = (1 << d->depth) - 1, W4 = 2 * R4 + 1;
-  const size_t ts4 = (size_t)((W4 + W4 * W4 + 3) & ~3);
+  const size_t ts5 = rpe_form_floats(d->depth, d->pos_bnd);
   size_t lds5 = 0;
   for (;; hpw >>= 1) {        // as the launcher: 4 heads per workgroup, or 2 when their tables crowd the LDS
-    lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts4 * 4 + (size_t)hpw * (2 * ((T + 1) / 2) * 16) * 64;
+    lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts5 * 4 + (size_t)hpw * (2 * ((T + 1) / 2) * 16) * 64;
     if (lds5 <= 72 * 1024 || hpw <= 2 || d->n_heads % (hpw / 2) != 0) break;
   }
+  const int W5 = 2 * ((1 << d->depth) - 1) + 1;
+  if (rpe_form(d->depth, d->pos_bnd) == 2 && (size_t)hpw * ts5 * 4 + 12 * (size_t)W5 >= 65536) return 0;
   if (lds5 > 72 * 1024 || hpw * 64 < LP) return 0;
   if (n_rows_total * 3 * d->n_heads * 16 * 4 >= (int64_t)1 << 32) return 0;
   return 1;
@@ -1492,17 +1552,20 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
 }
 
 int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth) {
-  if (n_heads <= 0 || depth < 1 || depth > 5 || ((1 << depth) - 1) > pos_bnd) return 0;
-  const int W = 2 * ((1 << depth) - 1) + 1;
-  return (int64_t)n_heads * ((W + W * W + 3) & ~3);
+  if (n_heads <= 0 || pos_bnd < 0) return 0;
+  return (int64_t)n_heads * (int64_t)rpe_form_floats(depth, pos_bnd);
 }
 
 int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth,
                           hfl_stream_t stream) {
   const int64_t n = hfl_window_rpe_expand_size(n_heads, pos_bnd, depth);
   if (n <= 0 || out == nullptr || rpe_table == nullptr) return HFL_EINVAL;
-  rpe_expand_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      out, rpe_table, n_heads, pos_bnd, (1 << depth) - 1);
+  if (rpe_form(depth, pos_bnd) == 1)
+    rpe_expand_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        out, rpe_table, n_heads, pos_bnd, (1 << depth) - 1);
+  else
+    rpe_expand3_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        out, rpe_table, n_heads, pos_bnd, (1 << depth) - 1);
   HFL_RETURN_LAST_ERROR();
 }
 

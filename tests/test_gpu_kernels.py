@@ -342,14 +342,18 @@ def test_linear_x3_qkv_epilogue_writes_the_attention_operand_layout():
         assert (halves[:, :, :, 1].abs() <= halves[:, :, :, 0].abs() * 2 ** -9 + 1e-6).all()      # lo is the residual
 
 
-@pytest.mark.parametrize('cfg,sizes', [('wild-places', [4096, 30, 2500]), ('cs-wild-places', [5000, 3000])])
-def test_window_attention_matches_oracle(cfg, sizes):
+@pytest.mark.parametrize('cfg,sizes,odepth', [('wild-places', [4096, 30, 2500], 7), ('cs-wild-places', [5000, 3000], 7),
+                                              ('oxford', [4096, 2500], 9)])
+def test_window_attention_matches_oracle(cfg, sizes, odepth):
+    """odepth 9 (Oxford): attention at octree depths 7..4 -- coordinates beyond pos_bnd (the reference's clamp is live)
+    and, on the fp16 path, the three-table form of the expanded RPE table."""
     clouds = [syn.unit_ball_cloud(500 + i, n) for i, n in enumerate(sizes)]
-    params, ref, dev, oplan, plan = _plans(clouds, cfg, 7)
+    params, ref, dev, oplan, plan = _plans(clouds, cfg, odepth)
     K, D = params.patch_size, params.dilation
     g = torch.Generator().manual_seed(3)
     B = len(sizes)
-    for depth, H, G, dil in ((5, 8, 0, 1), (5, 8, 0, D), (4, 16, 1, 1), (3, 16, 1, 1), (2, 16, 1, 1)):
+    md = odepth - 2
+    for depth, H, G, dil in ((md, 8, 0, 1), (md, 8, 0, D), (md - 1, 16, 1, 1), (md - 2, 16, 1, 1), (md - 3, 16, 1, 1)):
         C = H * 16
         nt, W = plan.n_tokens[depth], plan.n_windows[depth]
         assert nt == int(oplan.nnum_t[depth]) and W == int(oplan.nnum_a[depth]) // K
@@ -415,7 +419,7 @@ def test_window_attention_matches_oracle(cfg, sizes):
             rec5 = (got5s[:, :, 0] + got5s[:, :, 1]).reshape(rows_all, C)
             assert (rec5[:nt] - want_tok).abs().max().item() < 4e-5
         else:
-            assert depth == 5 or G == 0 or K == 64, 'the pyramid depths of the shipped configs must be eligible'
+            assert odepth == 7 and (depth == 5 or G == 0 or K == 64), 'the pyramid depths of the shipped configs must be eligible'
         # no RPE (disable_RPE=True path)
         want0 = hotformer_ref._sdpa(q, k, v, mask.unsqueeze(1), 0.25).transpose(1, 2).reshape(-1, K + G, C)
         for dd in (0, depth):
