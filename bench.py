@@ -246,7 +246,7 @@ def main():
         return dt
 
     extras = world == 1 and not args.train and not args.no_extras
-    fp32_line = e2e_line = kern_iso = kern_all = None
+    fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = None
     with (torch.enable_grad() if args.train else torch.inference_mode()):
         # ---- the headline: W warm-ups, K timed steps.  Inside the timed region only the roofline kernel carries
         # HIP events (2 per launch, 34 launches per step); everything else runs un-instrumented.
@@ -287,6 +287,7 @@ def main():
                         step()
                     torch.cuda.synchronize()
                 kern_iso = t_iso.summary()
+                iso_sizes = t_iso.by_size(ATTN)
                 set_pyramid_streams(True)
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -309,7 +310,8 @@ def main():
                     # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
                     # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
                     j = json.load(open(pmc))
-                    hit = [v for k, v in j.items() if k.startswith('window_attn_kernel') and isinstance(v, dict)]
+                    hit = [v for k, v in sorted(j.items(), key=lambda kv: -kv[1].get('launches', 0) if isinstance(kv[1], dict) else 0)
+                           if k.startswith('window_attn_kernel') and isinstance(v, dict)]     # the kernel the step runs most
                     if hit:
                         traffic, traffic_src = hit[0]['hbm_bytes_per_launch'], 'profiles/' + cand
                         break
@@ -325,6 +327,13 @@ def main():
                     'timing': ('HIP events per launch over %d steps, pyramid streams serialised (re-run right '
                                'after the timed region; agrees with rocprofv3 --kernel-trace)' % args.steps) if kern_iso else
                               'HIP events per launch inside the timed region'}
+            if iso_sizes:
+                # the step's launches by size: one per pyramid depth and block (34 here); the depth-2 / depth-3 launches
+                # hold 2 % / 13 % of the bytes and are latency-bound (a few windows per CU)
+                roof['by_launch_size'] = [{'algorithmic_bytes_per_launch': b, 'launches': c,
+                                           'avg_launch_us': round(ms_ * 1e3 / c, 2),
+                                           'frac': round(b * c / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                          for b, c, ms_ in iso_sizes]
             if rec_t:
                 nt_, mst, bt, _, _ = rec_t
                 roof['timed_region'] = {'frac': round(bt / (mst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

@@ -44,6 +44,17 @@ class KernelTimer:
             out[name] = (n + 1, ms + e0.elapsed_time(e1), b + nbytes, f + flops, mv + moved)
         return out
 
+    def by_size(self, name):
+        """Launches of one kernel grouped by their algorithmic byte count: [(bytes per launch, launches, total ms)],
+        largest first (a step's window-attention launches span 9 MB .. 280 MB: the small ones are latency-bound)."""
+        torch.cuda.synchronize()
+        groups = {}
+        for n, e0, e1, nbytes, flops, moved in self.records:
+            if n == name:
+                c, ms = groups.get(nbytes, (0, 0.0))
+                groups[nbytes] = (c + 1, ms + e0.elapsed_time(e1))
+        return [(b, c, ms) for b, (c, ms) in sorted(groups.items(), reverse=True)]
+
 
 class _timed:
     def __init__(self, name, nbytes, flops=0, moved=None):

@@ -23,7 +23,7 @@ def main(fetch_csv, write_csv, out_json):
                   'hbm_bytes_per_launch': int((2.0 * fv / n + wv / max(wn, 1)) * 1024),
                   'correction': '2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes (gfx950, 16-B lane loads)'}
     json.dump(out, open(out_json, 'w'), indent=1, sort_keys=True)
-    for k in ('window_attn_kernel_v4', 'window_attn_kernel_v2', 'cpe_fwd_kernel', 'layer_norm_kernel', 'eltwise_kernel', 'gather_kernel'):
+    for k in ('window_attn_kernel_v5', 'gemm_x3_kernel', 'window_attn_kernel_v4', 'window_attn_kernel_v2', 'cpe_fwd_kernel', 'layer_norm_kernel', 'eltwise_kernel', 'gather_kernel'):
         if k in out: print(k, out[k])
 
 if __name__ == '__main__':
