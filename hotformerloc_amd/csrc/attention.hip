@@ -1400,8 +1400,26 @@ void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
-  const char* k = "window_attention";
+  const char* kr = "reset";                      // every probe knob back to its default (tests call it around each case)
   int i = 0;
+  while (kr[i] != 0 && key[i] == kr[i]) ++i;
+  if (kr[i] == 0 && key[i] == 0) {
+    g_window_variant = 4;
+    g_window_v4_wgs_per_cu = 1;
+    g_window_dbg = 0;
+    g_window_v2_wgs_per_cu = 16;
+    g_window_heads_per_wg = 4;
+    hfl_internal_set_window_bwd(2);
+    hfl_internal_set_linear_ablate(0);
+    hfl_internal_set_x3_dbg(0);
+    hfl_internal_set_x3_dbg(0x100);
+    hfl_internal_set_x3_dbg(0x200);
+    hfl_internal_set_cpe_variant(0, 3);
+    hfl_internal_set_cpe_chunk(0);
+    return HFL_OK;
+  }
+  const char* k = "window_attention";
+  i = 0;
   while (k[i] != 0 && key[i] == k[i]) ++i;
   if (k[i] == 0 && key[i] == 0) {
     g_window_variant = value;

@@ -35,3 +35,19 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_kernel_knobs(request):
+    """The library's probe knobs (`hfl_set_variant`) and the package's mode switches are process-global: put them back to
+    their defaults around every GPU test, so that a test that fails between a set and its `finally` cannot leak a variant
+    into the tests after it."""
+    if 'gpu' not in request.keywords:
+        yield
+        return
+    from hotformerloc_amd import _native, model
+    lib = _native.load()
+    lib.hfl_set_variant(b'reset', 0)
+    yield
+    lib.hfl_set_variant(b'reset', 0)
+    model.set_gemm_mode(os.environ.get('HFL_GEMM', 'x3'))
