@@ -362,36 +362,36 @@ class MlpX3Fn(torch.autograd.Function):
 
 
 class LnMlpResidualX3Fn(torch.autograd.Function):
-    """x + fc2(gelu(fc1(LN(x)))): the whole pre-norm MLP branch of a transformer block (models/octformer_backbone.py:
-    275-278 with layer scale and stochastic depth off) as five launches forward (LN -> split2, fc1 + GELU, fc2 + bias +
-    residual) and seven backward; no element-wise pass: LayerNorm writes the GEMM operand, the residual add rides in fc2's
-    epilogue, the skip path's gradient joins inside the LayerNorm backward kernel."""
+    """x + s * fc2(gelu(fc1(LN(x)))): the whole pre-norm MLP branch of a transformer block (models/octformer_backbone.py:
+    275-278; s = the per-row stochastic-depth factor of OctreeDropPath or None) as three launches forward (LN -> split2,
+    fc1 + GELU, fc2 + bias + scale + residual) and seven backward; no element-wise pass: LayerNorm writes the GEMM operand,
+    the residual add rides in fc2's epilogue, the skip path's gradient joins inside the LayerNorm backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2):
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2, row_scale):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         hs = ops.layer_norm_split2(x2, gamma, beta, eps)
         gs, pre = ops.linear_x3_gelu_fwd(hs, _w2_cached(w1, False), b1)
-        ctx.save_for_backward(x2, gamma, hs, gs, pre, w1, w2)
-        ctx.shape, ctx.eps = shape, eps
-        return ops.linear_x3(gs, _w2_cached(w2, False), bias=b2, residual=x2).view(shape)
+        ctx.save_for_backward(x2, gamma, hs, gs, pre, w1, w2, row_scale if row_scale is not None else x2.new_empty(0))
+        ctx.shape, ctx.eps, ctx.scaled = shape, eps, row_scale is not None
+        return ops.linear_x3(gs, _w2_cached(w2, False), bias=b2, residual=x2, row_scale=row_scale).view(shape)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, gamma, hs, gs, pre, w1, w2 = ctx.saved_tensors
+        x2, gamma, hs, gs, pre, w1, w2, row_scale = ctx.saved_tensors
         dout2 = dout.reshape(-1, w2.shape[0]).contiguous()
-        dys = ops.split2(dout2)
+        dys = ops.split2(dout2, row_scale if ctx.scaled else None)
         dps = ops.linear_x3_gelu_bwd(dys, _w2_cached(w2, True), pre)
         dw2, db2 = ops.wgrad_x3(dys, gs, with_bias=True)
         dh = ops.linear_x3(dps, _w2_cached(w1, True))
         dw1, db1 = ops.wgrad_x3(dps, hs, with_bias=True)
         dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)
-        return dx.view(ctx.shape), dg, dbeta, None, dw1, db1, dw2, db2
+        return dx.view(ctx.shape), dg, dbeta, None, dw1, db1, dw2, db2, None
 
 
-def ln_mlp_residual_x3(x, gamma, beta, eps, w1, b1, w2, b2):
-    return LnMlpResidualX3Fn.apply(x, gamma, beta, eps, w1, b1, w2, b2)
+def ln_mlp_residual_x3(x, gamma, beta, eps, w1, b1, w2, b2, row_scale=None):
+    return LnMlpResidualX3Fn.apply(x, gamma, beta, eps, w1, b1, w2, b2, row_scale)
 
 
 class LnAttnResidualX3Fn(torch.autograd.Function):
@@ -401,23 +401,24 @@ class LnAttnResidualX3Fn(torch.autograd.Function):
     proj's epilogue, and in the backward the skip gradient joins inside the LayerNorm backward kernel."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp):
+    def forward(ctx, x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp, row_scale):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1]).contiguous()
         hs = ops.layer_norm_split2(x2, gamma, beta, eps)
         qkv = ops.linear_x3(hs, _w2_cached(wqkv, False), bias=bqkv)
         os_ = ops.window_attention(qkv, tok_meta, rpe_table, out_split=2, **cfg)
         ctx.save_for_backward(x2, gamma, hs, qkv, os_, rpe_table if rpe_table is not None else x2.new_empty(0), tok_meta,
-                              wqkv, wp)
+                              wqkv, wp, row_scale if row_scale is not None else x2.new_empty(0))
         ctx.shape, ctx.eps, ctx.cfg, ctx.has_table, ctx.has_qkv_bias = shape, eps, cfg, rpe_table is not None, bqkv is not None
-        return ops.linear_x3(os_, _w2_cached(wp, False), bias=bp, residual=x2).view(shape)
+        ctx.scaled = row_scale is not None
+        return ops.linear_x3(os_, _w2_cached(wp, False), bias=bp, residual=x2, row_scale=row_scale).view(shape)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, gamma, hs, qkv, os_, table, tok_meta, wqkv, wp = ctx.saved_tensors
+        x2, gamma, hs, qkv, os_, table, tok_meta, wqkv, wp, row_scale = ctx.saved_tensors
         cfg = ctx.cfg
         dout2 = dout.reshape(-1, wp.shape[0]).contiguous()
-        dys = ops.split2(dout2)
+        dys = ops.split2(dout2, row_scale if ctx.scaled else None)
         do = ops.linear_x3(dys, _w2_cached(wp, True))
         dwp, dbp = ops.wgrad_x3(dys, os_, with_bias=True)
         dqkv = torch.empty_like(qkv)
@@ -432,11 +433,11 @@ class LnAttnResidualX3Fn(torch.autograd.Function):
         dh = ops.linear_x3(dqs, _w2_cached(wqkv, True))
         dwqkv, dbqkv = ops.wgrad_x3(dqs, hs, with_bias=ctx.has_qkv_bias)
         dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)
-        return dx.view(ctx.shape), dg, dbeta, None, dwqkv, dbqkv, dtable, None, None, dwp, dbp
+        return dx.view(ctx.shape), dg, dbeta, None, dwqkv, dbqkv, dtable, None, None, dwp, dbp, None
 
 
-def ln_attn_residual_x3(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp):
-    return LnAttnResidualX3Fn.apply(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp)
+def ln_attn_residual_x3(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp, row_scale=None):
+    return LnAttnResidualX3Fn.apply(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp, row_scale)
 
 
 def mlp_x3(h, w1, b1, w2, b2):

@@ -46,6 +46,7 @@ struct X3Params {
   const uint16_t* w;        // (N, K/32, 2, 32) bf16
   const float* bias;        // (N) or null
   const float* residual;    // (M, N) or null (EPI 0 only; may alias out)
+  const float* row_scale;   // EPI 0: (M) or null: out = (acc + bias) * row_scale[m] + residual (per-cloud stochastic depth)
   float* aux;               // EPI 3: f32 (M, N) pre-activation written next to the split2 output; EPI 4: the same, read
   int64_t M;
   int N, K;
@@ -232,6 +233,10 @@ gemm_x3_kernel(const X3Params p) {
       if (m >= p.M) continue;
       float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
       if (EPI == 0) {
+        if (p.row_scale != nullptr) {
+          const float rsc = p.row_scale[m];
+          v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+        }
         if (p.residual != nullptr) {
           const float4 rs = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
           v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
@@ -291,15 +296,20 @@ gemm_x3_kernel(const X3Params p) {
   }
 }
 
-// fp32 (rows, C) -> split2 (rows, C/32, 2, 32) bf16
+// fp32 (rows, C) [* row_scale[row]] -> split2 (rows, C/32, 2, 32) bf16
 __global__ void __launch_bounds__(256)
-split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, int64_t n_rows, int C) {
+split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const float* __restrict__ row_scale, int64_t n_rows,
+              int C) {
   const int cv = C / 4;
   const int64_t total = n_rows * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cv;
     const int c = (int)(i % cv) * 4;
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (row_scale != nullptr) {
+      const float rsc = row_scale[r];
+      v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+    }
     const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
     const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
     const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
@@ -323,13 +333,20 @@ void hfl_internal_set_x3_dbg(int v) {
 
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
-                     float q_scale, hfl_stream_t stream, float* aux = nullptr);
+                     float q_scale, hfl_stream_t stream, float* aux = nullptr, const float* row_scale = nullptr);
 
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream) {
   return x3_launch(out, x_split2, w_split2, bias, residual, n_rows, in_features, out_features,
                    gelu_split_out ? 1 : 0, 1.0f, stream);
+}
+
+int hfl_linear_x3_rows(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                       const float* residual, const float* row_scale, int64_t n_rows, int in_features, int out_features,
+                       hfl_stream_t stream) {
+  return x3_launch(out, x_split2, w_split2, bias, residual, n_rows, in_features, out_features, 0, 1.0f, stream, nullptr,
+                   row_scale);
 }
 
 int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
@@ -355,7 +372,7 @@ int hfl_linear_x3_gelu_bwd(uint16_t* out_split2, const uint16_t* dy_split2, cons
 
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
-                     float q_scale, hfl_stream_t stream, float* aux) {
+                     float q_scale, hfl_stream_t stream, float* aux, const float* row_scale) {
   const int gelu_split_out = epi == 1 || epi == 3 || epi == 4;
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
   if (in_features % 32 != 0 || out_features % XT != 0) return HFL_EINVAL;
@@ -364,6 +381,7 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   if (n_rows == 0) return HFL_OK;
   X3Params p;
   p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual; p.aux = aux;
+  p.row_scale = row_scale;
   p.M = n_rows; p.N = out_features; p.K = in_features;
   p.tiles_n = out_features / XT;
   // 128-row tiles (3 workgroups per CU).  The 256-row instantiation moves 25 % fewer operand bytes per flop but holds
@@ -396,14 +414,19 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   HFL_RETURN_LAST_ERROR();
 }
 
-int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream) {
+int hfl_split2_rows(uint16_t* out, const float* x, const float* row_scale, int64_t n_rows, int64_t channels,
+                    hfl_stream_t stream) {
   if (n_rows < 0 || channels <= 0 || channels % 32 != 0) return HFL_EINVAL;
   if (n_rows == 0) return HFL_OK;
   const int64_t need = hfl_cdiv(n_rows * (channels / 4), 256);
   const int64_t cap = (int64_t)hfl_num_cus() * 16;
-  split2_kernel<<<(int)(need < cap ? need : cap), 256, 0, static_cast<hipStream_t>(stream)>>>(out, x, n_rows,
+  split2_kernel<<<(int)(need < cap ? need : cap), 256, 0, static_cast<hipStream_t>(stream)>>>(out, x, row_scale, n_rows,
                                                                                               (int)channels);
   HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream) {
+  return hfl_split2_rows(out, x, nullptr, n_rows, channels, stream);
 }
 
 }  // extern "C"

@@ -241,6 +241,16 @@ class OctreeDropPath(nn.Module):
             rnd = rnd / keep
         return data * rnd[bid]
 
+    def row_scale(self, bid, batch_size: int, like):
+        """The same draw as forward() as a per-row factor (rows,) for the fused residual branches; None when inactive."""
+        if self.drop_prob <= 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        rnd = torch.floor(torch.rand(batch_size, 1, dtype=like.dtype, device=like.device) + keep)
+        if keep > 0.0 and self.scale_by_keep:
+            rnd = rnd / keep
+        return rnd[bid].reshape(-1).contiguous()
+
     def extra_repr(self):
         return 'drop_prob={:.4f}'.format(self.drop_prob)
 
@@ -387,15 +397,16 @@ class MLP(nn.Module):
         return self.fc2(F.gelu(self.fc1(x)))
 
 
-def _mlp_branch(x, norm: nn.LayerNorm, mlp: 'MLP'):
+def _mlp_branch(x, norm: nn.LayerNorm, mlp: 'MLP', row_scale=None):
     """x + mlp(LN(x)) on the training path: one fused autograd Function when the shapes allow (LayerNorm writes the GEMM
     operand, GELU and the residual ride in the GEMM epilogues, the skip gradient joins inside the LayerNorm backward)."""
     f1, f2 = mlp.fc1, mlp.fc2
     if (_GEMM_MODE == 'x3' and _TRAIN_X3 and _TRAIN_MLP and _TRAIN_LN and x.is_cuda and x.numel() > 0
             and x.dtype == torch.float32 and x.shape[-1] in ops._LN_CHANNELS and f1.bias is not None and f2.bias is not None
             and ag.linear_x3_ok(f1.in_features, f1.out_features) and ag.linear_x3_ok(f2.in_features, f2.out_features)):
-        return ag.ln_mlp_residual_x3(x, norm.weight, norm.bias, norm.eps, f1.weight, f1.bias, f2.weight, f2.bias)
-    return x + mlp(_ln(x, norm))
+        return ag.ln_mlp_residual_x3(x, norm.weight, norm.bias, norm.eps, f1.weight, f1.bias, f2.weight, f2.bias, row_scale)
+    y = mlp(_ln(x, norm))
+    return x + (y if row_scale is None else y * row_scale.unsqueeze(1))
 
 
 class CPE(nn.Module):
@@ -469,7 +480,7 @@ class OctreeAttention(nn.Module):
         """x: (N_t [+ W], C) token rows [followed by the relay-token rows]."""
         return self.proj(self.core(self.qkv(x), plan, depth))
 
-    def residual_branch(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
+    def residual_branch(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int, row_scale=None):
         """x + attention(LN(x)) on the training path: one fused autograd Function when the shapes allow."""
         C = self.dim
         if (_GEMM_MODE == 'x3' and _TRAIN_X3 and _TRAIN_MLP and _TRAIN_LN and x.is_cuda and x.numel() > 0
@@ -481,8 +492,9 @@ class OctreeAttention(nn.Module):
                        batch_size=plan.B, rt_row0=nt, depth=depth)
             table = None if self.rpe is None else self.rpe.rpe_table
             return ag.ln_attn_residual_x3(x, norm1.weight, norm1.bias, norm1.eps, self.qkv.weight, self.qkv.bias, table,
-                                          plan.meta[depth], cfg, self.proj.weight, self.proj.bias)
-        return x + self.forward(_ln(x, norm1), plan, depth)
+                                          plan.meta[depth], cfg, self.proj.weight, self.proj.bias, row_scale)
+        y = self.forward(_ln(x, norm1), plan, depth)
+        return x + (y if row_scale is None else y * row_scale.unsqueeze(1))
 
     def forward_split(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
         """LN1 -> qkv -> attention, split-precision path; returns the bf16 operand of `proj`."""
@@ -535,10 +547,14 @@ class OctFormerBlock(nn.Module):
         if _split_path(x) and not self.use_layer_scale and not _drops(self):
             o3 = self.attention.forward_split(x, self.norm1, plan, depth)
             return _block_tail_split(x, o3, self.attention, self.norm2, self.mlp)
-        if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
+        if self.use_layer_scale:
             bid = plan.row_cloud(depth, with_relay=False)
             x = x + self.drop_path(self.gamma1 * self.attention(_ln(x, self.norm1), plan, depth), bid, plan.B)
             return x + self.drop_path(self.gamma2 * self.mlp(_ln(x, self.norm2)), bid, plan.B)
+        if self.training and self.drop_path.drop_prob > 0.0:        # stochastic depth: per-row factor inside the branches
+            bid = plan.row_cloud(depth, with_relay=False)
+            x = self.attention.residual_branch(x, self.norm1, plan, depth, self.drop_path.row_scale(bid, plan.B, x))
+            return _mlp_branch(x, self.norm2, self.mlp, self.drop_path.row_scale(bid, plan.B, x))
         if _grad_path(x):
             return _mlp_branch(self.attention.residual_branch(x, self.norm1, plan, depth), self.norm2, self.mlp)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
@@ -594,10 +610,14 @@ class HOTFormerBlock(nn.Module):
         if _split_path(buf) and not self.use_layer_scale and not _drops(self):
             o3 = self.attention.forward_split(buf, self.norm1, plan, depth)
             return _block_tail_split(buf, o3, self.attention, self.norm2, self.mlp)
-        if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
+        if self.use_layer_scale:
             bid = plan.row_cloud(depth, with_relay=True)
             buf = buf + self.drop_path(self.gamma1 * self.attention(_ln(buf, self.norm1), plan, depth), bid, plan.B)
             return buf + self.drop_path(self.gamma2 * self.mlp(_ln(buf, self.norm2)), bid, plan.B)
+        if self.training and self.drop_path.drop_prob > 0.0:
+            bid = plan.row_cloud(depth, with_relay=True)
+            buf = self.attention.residual_branch(buf, self.norm1, plan, depth, self.drop_path.row_scale(bid, plan.B, buf))
+            return _mlp_branch(buf, self.norm2, self.mlp, self.drop_path.row_scale(bid, plan.B, buf))
         if _grad_path(buf):
             return _mlp_branch(self.attention.residual_branch(buf, self.norm1, plan, depth), self.norm2, self.mlp)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)

@@ -362,13 +362,16 @@ def gemm_bf16(a3: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, out=
 
 
 # ------------------------------------------- hand-written split-precision Linear (csrc/gemm_x3.hip)
-def split2(x):
-    """fp32 (rows, C) -> split2 bf16 (rows, 2C): per 32-channel block [32 x hi | 32 x lo] (hfl_split2)."""
-    _dev(x)
+def split2(x, row_scale=None):
+    """fp32 (rows, C) [* row_scale (rows)] -> split2 bf16 (rows, 2C): per 32-channel block [32 x hi | 32 x lo]
+    (hfl_split2 / hfl_split2_rows)."""
+    _dev(x, row_scale)
     c = x.shape[-1]
     x2 = _f32c(x).view(-1, c)
     out = torch.empty((x2.shape[0], 2 * c), dtype=torch.bfloat16, device=x.device)
-    check(_native.load().hfl_split2(out.data_ptr(), x2.data_ptr(), x2.shape[0], c, _stream()), 'hfl_split2')
+    check(_native.load().hfl_split2_rows(out.data_ptr(), x2.data_ptr(),
+                                         None if row_scale is None else _f32c(row_scale).data_ptr(), x2.shape[0], c,
+                                         _stream()), 'hfl_split2')
     return out
 
 
@@ -396,7 +399,7 @@ def split2_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu_split_out: bool = False,
-              out=None) -> torch.Tensor:
+              out=None, row_scale=None) -> torch.Tensor:
     """y = x W^T [+ bias] [+ residual] (fp32), or with gelu_split_out the split2 bf16 operand of the next Linear,
     split2(gelu(x W^T + bias)); x2 / w2 are split2 operands (hfl_linear_x3)."""
     _dev(x2, w2, bias, residual)
@@ -417,6 +420,13 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
             assert tuple(residual.shape) == (m, n)
     # algorithmic bytes: x once (4 B/elt), out once (4 B/elt either form), residual once; 2 M K N flop (fp32-equivalent)
     with _timed('hfl_linear_x3', m * k * 4 + m * n * (8 if residual is not None else 4), 2 * m * k * n):
+        if row_scale is not None:          # (acc + bias) * row_scale[m] + residual: stochastic depth of a fused branch
+            assert not gelu_split_out and tuple(row_scale.shape) == (m,)
+            check(_native.load().hfl_linear_x3_rows(out.data_ptr(), x2.data_ptr(), w2.data_ptr(),
+                                                    None if bias is None else _f32c(bias).data_ptr(),
+                                                    None if residual is None else residual.data_ptr(),
+                                                    _f32c(row_scale).data_ptr(), m, k, n, _stream()), 'hfl_linear_x3_rows')
+            return out
         check(_native.load().hfl_linear_x3(out.data_ptr(), x2.data_ptr(), w2.data_ptr(),
                                            None if bias is None else _f32c(bias).data_ptr(),
                                            None if residual is None else residual.data_ptr(), m, k, n,

@@ -350,6 +350,14 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream);
 int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* Per-row scaled forms for per-cloud stochastic depth (OctreeDropPath, models/layers/octformer_layers.py:213-289) inside the
+ * fused residual branches: out = (x W^T + bias) * row_scale[m] + residual, and split2(x * row_scale[row]) for the branch's
+ * incoming gradient.  row_scale (n_rows) may be NULL (= 1). */
+int hfl_linear_x3_rows(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                       const float* residual, const float* row_scale, int64_t n_rows, int in_features, int out_features,
+                       hfl_stream_t stream);
+int hfl_split2_rows(uint16_t* out, const float* x, const float* row_scale, int64_t n_rows, int64_t channels,
+                    hfl_stream_t stream);
 /* Training forms of the MLP's first Linear (models/layers/octformer_layers.py:53-59 under autograd):
  *   _gelu_fwd: out_split2 = split2(gelu(x W^T + b)) AND preact (n_rows, out_features) f32 = x W^T + b in one launch (GELU's
  *              backward needs the pre-activation);

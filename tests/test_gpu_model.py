@@ -236,6 +236,40 @@ def test_drop_path_is_per_cloud_and_off_in_eval():
         assert torch.all(rows == rows[0, 0]) and rows[0, 0].item() in (0.0, 2.0)
 
 
+def test_stochastic_depth_inside_the_fused_branches_matches_the_unfused_path():
+    """Train mode with the config's drop_path = 0.5: the fused residual-branch Functions apply the per-cloud factor in the
+    proj / fc2 epilogues and to the incoming gradient (hfl_linear_x3_rows, hfl_split2_rows); with the same random draws the
+    un-fused formulation (branch * factor, torch autograd) must give the same descriptors and parameter gradients."""
+    from hotformerloc_amd import model as M
+    params, depth = load_config('wild-places')
+    assert params.drop_path == 0.5
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'stress')
+    model = model.cuda().train()
+    clouds = syn.make_clouds(77, 4, 1500, params.coordinates)
+    octree = build_batch_octree(clouds, depth, 2, 'cuda')
+    proj = torch.randn(4, params.output_dim, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
+    res = {}
+    for fused in (True, False):
+        M._TRAIN_MLP = fused
+        try:
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(11)
+            y = model({'octree': octree})['global']
+            (y * proj).sum().backward()
+            res[fused] = (y.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            M._TRAIN_MLP = True
+    ya, yb = res[True][0], res[False][0]
+    assert (ya - yb).abs().max().item() < 1e-4 * yb.abs().max().item() + 1e-6
+    worst = 0.0
+    for n, gb in res[False][1].items():
+        ga = res[True][1][n]
+        if gb.norm().item() > 1e-9:
+            worst = max(worst, ((ga - gb).norm() / gb.norm()).item())
+    assert worst < 1e-3, worst
+
+
 def test_large_oxford_batch_completes_and_is_deterministic():
     """Regression for the stream-K dead-lock ("hipBLASLt schedule"): Oxford cfg, 48 clouds --
     every pyramid depth is chip-filling (92k-194k rows).  With stream-K GEMMs on three streams this configuration
