@@ -1414,6 +1414,7 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_x3_dbg(0);
     hfl_internal_set_x3_dbg(0x100);
     hfl_internal_set_x3_dbg(0x200);
+    hfl_internal_set_x3_dbg(0x400);
     hfl_internal_set_cpe_variant(0, 3);
     hfl_internal_set_cpe_chunk(0);
     return HFL_OK;

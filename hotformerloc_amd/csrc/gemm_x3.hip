@@ -60,6 +60,8 @@ struct X3Params {
 
 static int g_x3_dbg = 0;
 static int g_x3_mt = 0;      // 8: force the 256-row tile (tools/x3_ablate.py); anything else: 128-row tile
+static int g_x3_wide = 0;     // 1: 128 x 256 tiles, 8 waves, two LDS stages, where out_features % 256 == 0
+static int g_x3_wide_min_tiles = 256;
 static int g_x3_nt = 0;     // measured: no end-to-end difference (the consumer kernel re-reads the output anyway)
 
 __device__ __forceinline__ uint32_t x3_bf16_rne(float v) {
@@ -94,6 +96,101 @@ __device__ __forceinline__ float x3_gelu_grad(float v) {
   const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);         // exp(-v^2 / 2)
   const float erf_v = copysignf(fmaf(-poly * t, e, 1.0f), v);
   return fmaf(v * 0.3989422804014327f, e, 0.5f * (1.0f + erf_v));
+}
+
+// Epilogue shared by the kernels below.  acc[i][j]: features 16 i + 4 fq .. +3 (registers) of row 16 j + frow of the
+// (16 MT) x 64 tile at (m_tile, n_tile) that one wavefront owns; ep = that wavefront's private 8-KiB LDS region.
+template <int EPI, int MT>
+__device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][MT], unsigned char* ep, int64_t m_tile,
+                                            int n_tile, int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+  // The accumulator holds features n..n+3 (registers) of row m = lane & 15: stored as is, a 128-B line would be
+  // written in two halves by different instructions.  Each wave transposes its (16 MT) x 64 tile through a private 8 KiB
+  // LDS region, 32 rows at a time (16-B chunks XOR-swizzled by the row: conflict-free both ways), and reads it back so
+  // that 16 consecutive lanes hold 256 contiguous bytes of one output row: every store instruction writes whole lines.
+  const int N = p.N;
+  const int ecol = lane & 15;                                                 // 16-B chunk (4 features) inside the row
+  const int nbase = n_tile + ecol * 4;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + nbase);
+#pragma unroll
+  for (int h = 0; h < MT / 2; ++h) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = jj * 16 + frow;
+        *reinterpret_cast<f32x4*>(ep + r * 256 + (((i * 4 + fq) ^ frow) << 4)) = acc[i][2 * h + jj];
+      }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 4 + fq;                                              // row inside the 32
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ (r & 15)) << 4));
+      const int64_t m = m_tile + h * 32 + r;
+      if (m >= p.M) continue;
+      float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
+      if (EPI == 0) {
+        if (p.row_scale != nullptr) {
+          const float rsc = p.row_scale[m];
+          v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+        }
+        if (p.residual != nullptr) {
+          const float4 rs = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+        }
+        // non-temporal: the output is not re-read by this kernel, and letting it allocate in L2 evicts the operand
+        // tiles the co-resident workgroups are re-reading (measured: 160 -> 106 us for the depth-4 fc1 shape)
+        const f32x4 vv = {v.x, v.y, v.z, v.w};
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * N + nbase);
+        if (p.nt & 1) __builtin_nontemporal_store(vv, dst);
+        else *dst = vv;
+      } else if (EPI == 2) {
+        if (nbase < p.qk_channels) { v.x *= p.q_scale; v.y *= p.q_scale; v.z *= p.q_scale; v.w *= p.q_scale; }
+        const auto h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+        const auto l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01[0], v.y - (float)h01[1]);
+        const auto l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23[0], v.w - (float)h23[1]);
+        const uint32_t uh0 = __builtin_bit_cast(uint32_t, h01), uh1 = __builtin_bit_cast(uint32_t, h23);
+        const uint32_t ul0 = __builtin_bit_cast(uint32_t, l01), ul1 = __builtin_bit_cast(uint32_t, l23);
+        // lane pair (2k, 2k+1) holds 8 consecutive dims of one head: the even lane stores their hi halves (16 B), the
+        // odd lane their lo halves
+        const uint32_t mine0 = (lane & 1) ? uh0 : ul0, mine1 = (lane & 1) ? uh1 : ul1;
+        const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
+        const u32x4 qq = (lane & 1) ? (u32x4){got0, got1, ul0, ul1} : (u32x4){uh0, uh1, got0, got1};
+        const int n8 = n_tile + (ecol & ~1) * 4;                       // first of the pair's 8 features
+        const int dim0 = n8 & 15;                                              // 0 or 8
+        unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + m * (int64_t)N * 4 + n8 * 4 - dim0 * 2 +
+                           ((lane & 1) ? 32 : 0);
+        *reinterpret_cast<u32x4*>(o) = qq;
+      } else {
+        if (EPI == 4) {
+          const float4 y = *reinterpret_cast<const float4*>(p.aux + m * N + nbase);
+          v.x *= x3_gelu_grad(y.x); v.y *= x3_gelu_grad(y.y); v.z *= x3_gelu_grad(y.z); v.w *= x3_gelu_grad(y.w);
+        } else {
+          if (EPI == 3) *reinterpret_cast<float4*>(p.aux + m * N + nbase) = v;
+          v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
+        }
+        const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
+        const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
+        const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
+        const uint32_t l2 = x3_bf16_rne(v.z - __uint_as_float(h2 << 16));
+        const uint32_t l3 = x3_bf16_rne(v.w - __uint_as_float(h3 << 16));
+        // lane pair (2k, 2k+1) holds 8 consecutive features: the even lane stores their 8 hi values (16 B), the odd
+        // lane their 8 lo values, so one instruction writes both halves of every [32 x hi | 32 x lo] line
+        const uint32_t mine0 = (lane & 1) ? h0 | (h1 << 16) : l0 | (l1 << 16);   // what the partner needs from me
+        const uint32_t mine1 = (lane & 1) ? h2 | (h3 << 16) : l2 | (l3 << 16);
+        const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
+        uint4 q;
+        if (lane & 1) q = make_uint4(got0, got1, l0 | (l1 << 16), l2 | (l3 << 16));        // lo of (partner, me)
+        else          q = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), got0, got1);        // hi of (me, partner)
+        const int nfeat = n_tile + (ecol & ~1) * 4;                      // first of the pair's 8 features
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + m * (2 * (int64_t)N) + (nfeat >> 5) * 64 + (nfeat & 31) +
+                      ((lane & 1) ? 32 : 0);
+        const u32x4 qq = {q.x, q.y, q.z, q.w};
+        if (p.nt & 2) __builtin_nontemporal_store(qq, reinterpret_cast<u32x4*>(o));
+        else *reinterpret_cast<u32x4*>(o) = qq;
+      }
+    }
+  }
 }
 
 // EPI 0: out f32 = acc + bias [+ residual];  EPI 1: out split2 = split(gelu(acc + bias));
@@ -205,95 +302,108 @@ gemm_x3_kernel(const X3Params p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
       }
   }
-  // ---- epilogue -------------------------------------------------------------------------------------------------
-  // The accumulator holds features n..n+3 (registers) of row m = lane & 15: stored as is, a 128-B line would be
-  // written in two halves by different instructions.  Each wave transposes its (16 MT) x 64 tile through a private 8 KiB
-  // LDS region, 32 rows at a time (16-B chunks XOR-swizzled by the row: conflict-free both ways), and reads it back so
-  // that 16 consecutive lanes hold 256 contiguous bytes of one output row: every store instruction writes whole lines.
-  const int N = p.N;
-  unsigned char* ep = smem + wave * 8192;                                     // the stage is free after the last barrier
-  const int ecol = lane & 15;                                                 // 16-B chunk (4 features) inside the row
-  const int nbase = n0 + wn * 64 + ecol * 4;
-  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + nbase);
-#pragma unroll
-  for (int h = 0; h < MT / 2; ++h) {
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = jj * 16 + frow;
-        *reinterpret_cast<f32x4*>(ep + r * 256 + (((i * 4 + fq) ^ frow) << 4)) = acc[i][2 * h + jj];
-      }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = it * 4 + fq;                                              // row inside the 32
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ (r & 15)) << 4));
-      const int64_t m = m0 + wm * (16 * MT) + h * 32 + r;
-      if (m >= p.M) continue;
-      float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
-      if (EPI == 0) {
-        if (p.row_scale != nullptr) {
-          const float rsc = p.row_scale[m];
-          v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
-        }
-        if (p.residual != nullptr) {
-          const float4 rs = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
-          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-        }
-        // non-temporal: the output is not re-read by this kernel, and letting it allocate in L2 evicts the operand
-        // tiles the co-resident workgroups are re-reading (measured: 160 -> 106 us for the depth-4 fc1 shape)
-        const f32x4 vv = {v.x, v.y, v.z, v.w};
-        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * N + nbase);
-        if (p.nt & 1) __builtin_nontemporal_store(vv, dst);
-        else *dst = vv;
-      } else if (EPI == 2) {
-        if (nbase < p.qk_channels) { v.x *= p.q_scale; v.y *= p.q_scale; v.z *= p.q_scale; v.w *= p.q_scale; }
-        const auto h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-        const auto l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01[0], v.y - (float)h01[1]);
-        const auto l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23[0], v.w - (float)h23[1]);
-        const uint32_t uh0 = __builtin_bit_cast(uint32_t, h01), uh1 = __builtin_bit_cast(uint32_t, h23);
-        const uint32_t ul0 = __builtin_bit_cast(uint32_t, l01), ul1 = __builtin_bit_cast(uint32_t, l23);
-        // lane pair (2k, 2k+1) holds 8 consecutive dims of one head: the even lane stores their hi halves (16 B), the
-        // odd lane their lo halves
-        const uint32_t mine0 = (lane & 1) ? uh0 : ul0, mine1 = (lane & 1) ? uh1 : ul1;
-        const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
-        const u32x4 qq = (lane & 1) ? (u32x4){got0, got1, ul0, ul1} : (u32x4){uh0, uh1, got0, got1};
-        const int n8 = n0 + wn * 64 + (ecol & ~1) * 4;                       // first of the pair's 8 features
-        const int dim0 = n8 & 15;                                              // 0 or 8
-        unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + m * (int64_t)N * 4 + n8 * 4 - dim0 * 2 +
-                           ((lane & 1) ? 32 : 0);
-        *reinterpret_cast<u32x4*>(o) = qq;
-      } else {
-        if (EPI == 4) {
-          const float4 y = *reinterpret_cast<const float4*>(p.aux + m * N + nbase);
-          v.x *= x3_gelu_grad(y.x); v.y *= x3_gelu_grad(y.y); v.z *= x3_gelu_grad(y.z); v.w *= x3_gelu_grad(y.w);
-        } else {
-          if (EPI == 3) *reinterpret_cast<float4*>(p.aux + m * N + nbase) = v;
-          v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
-        }
-        const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
-        const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
-        const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
-        const uint32_t l2 = x3_bf16_rne(v.z - __uint_as_float(h2 << 16));
-        const uint32_t l3 = x3_bf16_rne(v.w - __uint_as_float(h3 << 16));
-        // lane pair (2k, 2k+1) holds 8 consecutive features: the even lane stores their 8 hi values (16 B), the odd
-        // lane their 8 lo values, so one instruction writes both halves of every [32 x hi | 32 x lo] line
-        const uint32_t mine0 = (lane & 1) ? h0 | (h1 << 16) : l0 | (l1 << 16);   // what the partner needs from me
-        const uint32_t mine1 = (lane & 1) ? h2 | (h3 << 16) : l2 | (l3 << 16);
-        const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
-        uint4 q;
-        if (lane & 1) q = make_uint4(got0, got1, l0 | (l1 << 16), l2 | (l3 << 16));        // lo of (partner, me)
-        else          q = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), got0, got1);        // hi of (me, partner)
-        const int nfeat = n0 + wn * 64 + (ecol & ~1) * 4;                      // first of the pair's 8 features
-        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + m * (2 * (int64_t)N) + (nfeat >> 5) * 64 + (nfeat & 31) +
-                      ((lane & 1) ? 32 : 0);
-        const u32x4 qq = {q.x, q.y, q.z, q.w};
-        if (p.nt & 2) __builtin_nontemporal_store(qq, reinterpret_cast<u32x4*>(o));
-        else *reinterpret_cast<u32x4*>(o) = qq;
-      }
-    }
+  // ---- epilogue (the stage is free after the last barrier: every wave transposes through its own 8 KiB of it) ----------
+  x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane);
+}
+
+// ---- wide variant: 128 x 256 tile, 8 waves (2 x 4 of 64 x 64), TWO LDS stages, one barrier per k-step -----------------
+// Per k-step the workgroup fetches (128 + 256) x 128 B = 48 KiB for 128 x 256 x 32 MACs: 25 % less operand traffic per
+// MAC than the 128 x 128 tile, and the MFMA work of a step (2 waves per SIMD x 48 MFMAs x 16 cycles = 1536 cycles) is level
+// with its LDS-DMA time (~1650 cycles at the ~70 GB/s per CU an XCD's L2 serves).  One workgroup per CU (96 KiB of LDS):
+// the DMA of step t+1 is issued right after the barrier of step t into the other stage and has the whole step to land.
+template <int EPI>
+__global__ void __launch_bounds__(512, 1)
+gemm_x3_wide_kernel(const X3Params p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 stages x (x tile 16 KiB | w tile 32 KiB)
+  constexpr int STAGE_B = (128 + 256) * 128;
+  constexpr int XTILE_B = 128 * 128;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wm = wave & 1;
+
+  int64_t wg = blockIdx.x;
+  {
+    const int64_t q = p.n_wg >> 3, r = p.n_wg & 7;
+    const int64_t xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
+  const int64_t m0 = (wg / p.tiles_n) * 128;
+  const int n0 = (int)(wg % p.tiles_n) * 256;
+  const int K = p.K;
+  const int nk = K >> 5;
+  const int64_t row_b = (int64_t)K * 4;
+
+  // staging: wave w moves rows [16w, 16w+16) of the x tile (2 instructions) and [32w, 32w+32) of the w tile (4)
+  const int srow = lane >> 3, sslot = lane & 7;
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
+  const int rows_valid = (int)((p.M - m0) < 128 ? (p.M - m0) : 128);
+  uint32_t xoff[2], woff[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 16 + i * 8 + srow;
+    const int t = sslot ^ ((row >> 1) & 7);
+    const int xr = row < rows_valid ? row : rows_valid - 1;
+    xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + srow;
+    woff[i] = (uint32_t)row * (uint32_t)row_b + (sslot ^ ((row >> 1) & 7)) * 16;
+  }
+  auto stage = [&](int kt) {
+    const unsigned char* xk = xbase + (int64_t)kt * 128;
+    const unsigned char* wk = wbase + (int64_t)kt * 128;
+    unsigned char* st = smem + (kt & 1) * STAGE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
+                                       (__attribute__((address_space(3))) void*)(st + (wave * 16 + i * 8) * 128), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
+                                       (__attribute__((address_space(3))) void*)(st + XTILE_B + (wave * 32 + i * 8) * 128),
+                                       16, 0, 0);
+  };
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int rn0 = wn * 64 + frow, rm0 = wm * 64 + frow;
+  const int offw_hi = XTILE_B + rn0 * 128 + ((fq ^ ((rn0 >> 1) & 7)) << 4), offw_lo = offw_hi ^ 64;
+  const int offx_hi = rm0 * 128 + ((fq ^ ((rm0 >> 1) & 7)) << 4), offx_lo = offx_hi ^ 64;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                       // stage kt has landed for every wave; everyone is done reading stage kt-1
+    if (kt + 1 < nk) stage(kt + 1);        // ... which is therefore free: refill it behind this step's reads and MFMAs
+    const unsigned char* st = smem + (kt & 1) * STAGE_B;
+    bf16x8 wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wh[i] = *reinterpret_cast<const bf16x8*>(st + offw_hi + i * 2048);
+      wl[i] = *reinterpret_cast<const bf16x8*>(st + offw_lo + i * 2048);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = *reinterpret_cast<const bf16x8*>(st + offx_hi + j * 2048);
+      xl[j] = *reinterpret_cast<const bf16x8*>(st + offx_lo + j * 2048);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  __syncthreads();                         // the last stage is read: the epilogue reuses the LDS
+  x3_epilogue<EPI, 4>(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // fp32 (rows, C) [* row_scale[row]] -> split2 (rows, C/32, 2, 32) bf16
@@ -326,7 +436,8 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const flo
 extern "C" {
 
 void hfl_internal_set_x3_dbg(int v) {
-  if (v >= 0x200) g_x3_mt = v & 15;         // 0x200 | 0 / 4 / 8
+  if (v >= 0x400) g_x3_wide = v & 1;        // 0x400 | 0 / 1
+  else if (v >= 0x200) g_x3_mt = v & 15;    // 0x200 | 0 / 4 / 8
   else if (v >= 0x100) g_x3_nt = v & 3;     // 0x100 | nt bits
   else g_x3_dbg = v;
 }
@@ -402,6 +513,22 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
     if (e != hipSuccess) return (int)e;                                                                  \
     gemm_x3_kernel<E, M><<<(unsigned)p.n_wg, 256, lds, s>>>(p);                                          \
+  }
+  if (g_x3_wide && out_features % 256 == 0 && hfl_cdiv(n_rows, 128) * (out_features / 256) >= g_x3_wide_min_tiles) {
+    p.tiles_n = out_features / 256;
+    p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
+    const size_t ldsw = (size_t)2 * (128 + 256) * 128;
+#define HFL_X3_WIDE(E)                                                                                   \
+  {                                                                                                      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_wide_kernel<E>),            \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);           \
+    if (e != hipSuccess) return (int)e;                                                                  \
+    gemm_x3_wide_kernel<E><<<(unsigned)p.n_wg, 512, ldsw, s>>>(p);                                       \
+  }
+    if (epi == 4) HFL_X3_WIDE(4) else if (epi == 3) HFL_X3_WIDE(3) else if (epi == 2) HFL_X3_WIDE(2)
+    else if (epi == 1) HFL_X3_WIDE(1) else HFL_X3_WIDE(0)
+#undef HFL_X3_WIDE
+    HFL_RETURN_LAST_ERROR();
   }
   if (mt == 8 && epi <= 2) {
     if (epi == 2) HFL_X3_LAUNCH(2, 8) else if (epi == 1) HFL_X3_LAUNCH(1, 8) else HFL_X3_LAUNCH(0, 8)

@@ -1,4 +1,5 @@
-"""A/B of the x3 GEMM's row-tile height (128 vs 256 rows per workgroup) on the model's shapes, all three epilogues."""
+"""A/B of the x3 GEMM tile variants on the model's shapes: 128 x 128 (default), 256 x 128 single-stage (knob 0x200 | 8), and the
+wide 128 x 256 two-stage 8-wave kernel (knob 0x400 | 1)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hotformerloc_amd import ops, _native
@@ -19,13 +20,16 @@ for (M, K, N, tag) in [(68167, 256, 768, 'qkv d4'), (68167, 256, 256, 'proj d4')
     res = torch.randn(M, N, device='cuda')
     x2 = ops.split2(x); w2 = ops.split2_weight(w)
     out = {}
-    for mt in (4, 8):
-        lib.hfl_set_variant(b'x3_dbg', 0x200 | mt)
+    for name, knobs in (('128x128', (0x200, 0x400)), ('256x128', (0x200 | 8, 0x400)), ('wide 128x256', (0x200, 0x400 | 1))):
+        for kb in knobs:
+            lib.hfl_set_variant(b'x3_dbg', kb)
         y = ops.linear_x3(x2, w2, bias=b, residual=res)
         g = ops.linear_x3(x2, w2, bias=b, gelu_split_out=True)
-        out[mt] = (y, g, timeit(lambda: ops.linear_x3(x2, w2, bias=b, residual=res)),
-                   timeit(lambda: ops.linear_x3(x2, w2, bias=b, gelu_split_out=True)))
+        out[name] = (y, g, timeit(lambda: ops.linear_x3(x2, w2, bias=b, residual=res)),
+                     timeit(lambda: ops.linear_x3(x2, w2, bias=b, gelu_split_out=True)))
     lib.hfl_set_variant(b'x3_dbg', 0x200)
-    same = torch.equal(out[4][0], out[8][0]) and torch.equal(out[4][1], out[8][1])
-    print('%-8s M=%6d K=%4d N=%4d | +res: 128-row %7.1f us, 256-row %7.1f us | gelu-epi: %7.1f / %7.1f us | bit-equal %s'
-          % (tag, M, K, N, out[4][2], out[8][2], out[4][3], out[8][3], same))
+    lib.hfl_set_variant(b'x3_dbg', 0x400)
+    same = all(torch.equal(out['128x128'][0], o[0]) and torch.equal(out['128x128'][1], o[1]) for o in out.values())
+    print('%-8s M=%6d K=%4d N=%4d | +res: %s | gelu-epi: %s | bit-equal %s'
+          % (tag, M, K, N, ' / '.join('%s %6.1f us' % (k, v[2]) for k, v in out.items()),
+             ' / '.join('%6.1f' % v[3] for v in out.values()), same))
