@@ -46,6 +46,7 @@ struct X3Params {
   const uint16_t* w;        // (N, K/32, 2, 32) bf16
   const float* bias;        // (N) or null
   const float* residual;    // (M, N) or null (EPI 0 only; may alias out)
+  const int32_t* tiles;     // grouped launch (EPI 0): per row tile {first row, rows (<= 128), first row of its W block}, or null
   const float* row_scale;   // EPI 0: (M) or null: out = (acc + bias) * row_scale[m] + residual (per-cloud stochastic depth)
   float* aux;               // EPI 3: f32 (M, N) pre-activation written next to the split2 output; EPI 4: the same, read
   int64_t M;
@@ -102,7 +103,7 @@ __device__ __forceinline__ float x3_gelu_grad(float v) {
 // (16 MT) x 64 tile at (m_tile, n_tile) that one wavefront owns; ep = that wavefront's private 8-KiB LDS region.
 template <int EPI, int MT>
 __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][MT], unsigned char* ep, int64_t m_tile,
-                                            int n_tile, int lane) {
+                                            int n_tile, int lane, int64_t m_end) {
   const int frow = lane & 15, fq = lane >> 4;
   // The accumulator holds features n..n+3 (registers) of row m = lane & 15: stored as is, a 128-B line would be
   // written in two halves by different instructions.  Each wave transposes its (16 MT) x 64 tile through a private 8 KiB
@@ -111,8 +112,9 @@ __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][M
   const int N = p.N;
   const int ecol = lane & 15;                                                 // 16-B chunk (4 features) inside the row
   const int nbase = n_tile + ecol * 4;
+  const bool n_ok = EPI != 0 || nbase < N;          // EPI 0 takes N = 64: the upper half of the tile is W's zero padding
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + nbase);
+  if (p.bias != nullptr && n_ok) b = *reinterpret_cast<const float4*>(p.bias + nbase);
 #pragma unroll
   for (int h = 0; h < MT / 2; ++h) {
 #pragma unroll
@@ -127,7 +129,7 @@ __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][M
       const int r = it * 4 + fq;                                              // row inside the 32
       const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ (r & 15)) << 4));
       const int64_t m = m_tile + h * 32 + r;
-      if (m >= p.M) continue;
+      if (m >= m_end || !n_ok) continue;
       float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
       if (EPI == 0) {
         if (p.row_scale != nullptr) {
@@ -219,11 +221,19 @@ gemm_x3_kernel(const X3Params p) {
     const int64_t xcd = wg & 7, loc = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int64_t m0 = (wg / p.tiles_n) * BM;
+  int64_t m0 = (wg / p.tiles_n) * BM;
   const int n0 = (int)(wg % p.tiles_n) * XT;
   const int K = p.K;
   const int nk = K >> 5;
   const int64_t row_b = (int64_t)K * 4;                       // bytes per split2 row (2K bf16)
+  int64_t m_end = p.M;
+  int64_t w_row0 = n0;
+  if (p.tiles != nullptr) {                                   // grouped launch: this row tile's rows and weight block
+    const int32_t* tt = p.tiles + 3 * (wg / p.tiles_n);
+    m0 = tt[0];
+    m_end = m0 + tt[1];
+    w_row0 = (int64_t)tt[2] + n0;
+  }
 
   // ---- staging: wave w moves rows [8 MT w, 8 MT (w+1)) of the x tile and [32w, 32w+32) of the w tile, 8 rows per
   // instruction
@@ -231,8 +241,8 @@ gemm_x3_kernel(const X3Params p) {
   const int srow = lane >> 3, sslot = lane & 7;
   // uniform tile bases (SGPRs) + 32-bit per-lane offsets: tail rows fetch the last valid row, never stored
   const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
-  const int rows_valid = (int)((p.M - m0) < BM ? (p.M - m0) : BM);
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + w_row0 * row_b;
+  const int rows_valid = (int)((m_end - m0) < BM ? (m_end - m0) : BM);
   uint32_t xoff[MT], woff[4];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -303,7 +313,7 @@ gemm_x3_kernel(const X3Params p) {
       }
   }
   // ---- epilogue (the stage is free after the last barrier: every wave transposes through its own 8 KiB of it) ----------
-  x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane);
+  x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
 }
 
 // ---- wide variant: 128 x 256 tile, 8 waves (2 x 4 of 64 x 64), TWO LDS stages, one barrier per k-step -----------------
@@ -403,7 +413,7 @@ gemm_x3_wide_kernel(const X3Params p) {
       }
   }
   __syncthreads();                         // the last stage is read: the epilogue reuses the LDS
-  x3_epilogue<EPI, 4>(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, lane);
+  x3_epilogue<EPI, 4>(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, lane, p.M);
 }
 
 // fp32 (rows, C) [* row_scale[row]] -> split2 (rows, C/32, 2, 32) bf16
@@ -444,7 +454,8 @@ void hfl_internal_set_x3_dbg(int v) {
 
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
-                     float q_scale, hfl_stream_t stream, float* aux = nullptr, const float* row_scale = nullptr);
+                     float q_scale, hfl_stream_t stream, float* aux = nullptr, const float* row_scale = nullptr,
+                     const int32_t* tiles = nullptr, int64_t n_tiles = 0);
 
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
@@ -458,6 +469,14 @@ int hfl_linear_x3_rows(float* out, const uint16_t* x_split2, const uint16_t* w_s
                        hfl_stream_t stream) {
   return x3_launch(out, x_split2, w_split2, bias, residual, n_rows, in_features, out_features, 0, 1.0f, stream, nullptr,
                    row_scale);
+}
+
+int hfl_linear_x3_grouped(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const int32_t* tiles,
+                          int64_t n_tiles, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream) {
+  if (tiles == nullptr || n_tiles < 0) return HFL_EINVAL;
+  if (n_tiles == 0) return HFL_OK;
+  return x3_launch(out, x_split2, w_split2, nullptr, nullptr, n_rows, in_features, out_features, 0, 1.0f, stream, nullptr,
+                   nullptr, tiles, n_tiles);
 }
 
 int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
@@ -483,23 +502,26 @@ int hfl_linear_x3_gelu_bwd(uint16_t* out_split2, const uint16_t* dy_split2, cons
 
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
-                     float q_scale, hfl_stream_t stream, float* aux, const float* row_scale) {
+                     float q_scale, hfl_stream_t stream, float* aux, const float* row_scale, const int32_t* tiles,
+                     int64_t n_tiles) {
   const int gelu_split_out = epi == 1 || epi == 3 || epi == 4;
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
-  if (in_features % 32 != 0 || out_features % XT != 0) return HFL_EINVAL;
+  const bool narrow = tiles != nullptr && epi == 0 && out_features == 64;       // W blocks padded to 128 rows by the caller
+  if (in_features % 32 != 0 || (out_features % XT != 0 && !narrow)) return HFL_EINVAL;
   if (out == nullptr || x_split2 == nullptr || w_split2 == nullptr) return HFL_EINVAL;
   if (gelu_split_out && residual != nullptr) return HFL_EINVAL;
   if (n_rows == 0) return HFL_OK;
   X3Params p;
   p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual; p.aux = aux;
   p.row_scale = row_scale;
+  p.tiles = tiles;
   p.M = n_rows; p.N = out_features; p.K = in_features;
-  p.tiles_n = out_features / XT;
+  p.tiles_n = narrow ? 1 : out_features / XT;
   // 128-row tiles (3 workgroups per CU).  The 256-row instantiation moves 25 % fewer operand bytes per flop but holds
   // 256 VGPRs (2 workgroups per CU) and measured 10 - 120 % slower on every shape of the model (tools/x3_ablate.py,
   // DESIGN.md); it is only reachable through the probe knob.
-  const int mt = g_x3_mt == 8 ? 8 : 4;
-  p.n_wg = hfl_cdiv(n_rows, 32 * mt) * p.tiles_n;
+  const int mt = (g_x3_mt == 8 && tiles == nullptr) ? 8 : 4;
+  p.n_wg = (tiles != nullptr ? n_tiles : hfl_cdiv(n_rows, 32 * mt)) * p.tiles_n;
   p.dbg = g_x3_dbg;
   p.nt = g_x3_nt;
   p.qk_channels = out_features / 3;
@@ -514,7 +536,7 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
     if (e != hipSuccess) return (int)e;                                                                  \
     gemm_x3_kernel<E, M><<<(unsigned)p.n_wg, 256, lds, s>>>(p);                                          \
   }
-  if (g_x3_wide && out_features % 256 == 0 && hfl_cdiv(n_rows, 128) * (out_features / 256) >= g_x3_wide_min_tiles) {
+  if (g_x3_wide && tiles == nullptr && out_features % 256 == 0 && hfl_cdiv(n_rows, 128) * (out_features / 256) >= g_x3_wide_min_tiles) {
     p.tiles_n = out_features / 256;
     p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
     const size_t ldsw = (size_t)2 * (128 + 256) * 128;
@@ -533,7 +555,7 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   if (mt == 8 && epi <= 2) {
     if (epi == 2) HFL_X3_LAUNCH(2, 8) else if (epi == 1) HFL_X3_LAUNCH(1, 8) else HFL_X3_LAUNCH(0, 8)
   } else {
-    p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
+    if (tiles == nullptr) p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
     if (epi == 4) HFL_X3_LAUNCH(4, 4) else if (epi == 3) HFL_X3_LAUNCH(3, 4) else if (epi == 2) HFL_X3_LAUNCH(2, 4)
     else if (epi == 1) HFL_X3_LAUNCH(1, 4) else HFL_X3_LAUNCH(0, 4)
   }

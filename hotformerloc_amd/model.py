@@ -92,6 +92,7 @@ _TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
 _ATTN_F16 = os.environ.get('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
 _TRAIN_LN = os.environ.get('HFL_TRAIN_LN', '1') != '0'    # training-path LayerNorm: HIP forward + backward kernels
 _TRAIN_MLP = os.environ.get('HFL_TRAIN_MLP', '1') != '0'          # fused fc1 -> GELU -> fc2 autograd Function
+_GROUPED_TAPS = os.environ.get('HFL_GROUPED_TAPS', '1') != '0'     # live-tap convolutions: one grouped x3 launch for all taps
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 
@@ -296,6 +297,17 @@ class OctreeConv(nn.Module):
         then every output row sums its own partial products through the slot table (the depth-wise conv kernel
         with unit weights: no atomics, fixed summation order)."""
         src, slot, edges = octree.sparse_taps(depth, self.kernel, self.stride)
+        if (_GROUPED_TAPS and _GEMM_MODE == 'x3' and self.in_channels % 32 == 0
+                and (self.out_channels % 128 == 0 or self.out_channels == 64) and edges[-1] > 0):
+            # ONE launch of the split-precision GEMM over all taps: the pairs are gathered from the split2 form of the input
+            # (a split2 row is Cin 4-byte cells, so the same gather kernel moves it), row tiles never straddle a tap and
+            # carry the offset of their tap's weight block
+            npad = max(self.out_channels, 128)
+            gs = ops.octree_gather(ops.split2(data).view(torch.float32), src).view(torch.bfloat16)
+            part = ops.linear_x3_grouped(gs, self._tap_weights_split2(npad),
+                                         octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
+            out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
+            return out if self.bias is None else out + self.bias
         g = ops.octree_gather(data, src)                                  # (P, Cin)
         part = torch.empty((g.shape[0], self.out_channels), dtype=torch.float32, device=data.device)
         w = self.weights
@@ -315,12 +327,28 @@ class OctreeConv(nn.Module):
         else:
             for k in live:
                 torch.mm(g[edges[k]:edges[k + 1]], w[k], out=part[edges[k]:edges[k + 1]])
-        ones = self.__dict__.get('_unit_taps')
-        if ones is None or ones.device != data.device:
-            ones = torch.ones((self.kdim, 1, self.out_channels), dtype=torch.float32, device=data.device)
-            self.__dict__['_unit_taps'] = ones
-        out = ops.dwconv_forward_backward(part, ones, slot)
+        out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
         return out if self.bias is None else out + self.bias
+
+    def _unit(self, device):
+        ones = self.__dict__.get('_unit_taps')
+        if ones is None or ones.device != device:
+            ones = torch.ones((self.kdim, 1, self.out_channels), dtype=torch.float32, device=device)
+            self.__dict__['_unit_taps'] = ones
+        return ones
+
+    def _tap_weights_split2(self, npad: int):
+        """split2 layout of the per-tap weight blocks W[k]^T (Cout x Cin), each padded to `npad` rows, cached per parameter
+        version: (kdim * npad, 2 Cin) bf16."""
+        w = self.weights
+        hit = self.__dict__.get('_w_taps')
+        if hit is None or hit[0] != w._version or hit[1] != w.data_ptr() or hit[2] != npad:
+            wt = w.detach().transpose(1, 2)                                   # (kdim, Cout, Cin)
+            if npad > self.out_channels:
+                wt = torch.cat([wt, wt.new_zeros(self.kdim, npad - self.out_channels, self.in_channels)], 1)
+            hit = (w._version, w.data_ptr(), npad, ops.split2(wt.reshape(self.kdim * npad, self.in_channels).contiguous()))
+            self.__dict__['_w_taps'] = hit
+        return hit[3]
 
 
 class OctreeDWConvParams(nn.Module):

@@ -238,6 +238,21 @@ class Octree:
             self._build_tap_lists([key])
         return cache[key]
 
+    def tap_tiles(self, depth: int, kernel: str, stride: int, w_rows: int):
+        """Row tiles of the grouped tap GEMM (ops.linear_x3_grouped) over the pair list of `sparse_taps`: (n, 3) int32
+        {first pair, pairs (<= 128), tap * w_rows}; no tile straddles a tap.  Host-built from the tap edges, cached."""
+        cache = self.__dict__.setdefault('_tap_tiles', {})
+        key = (depth, kernel, stride, w_rows)
+        if key not in cache:
+            _, _, edges = self.sparse_taps(depth, kernel, stride)
+            rows = []
+            for k in range(len(edges) - 1):
+                for a in range(edges[k], edges[k + 1], 128):
+                    rows.append((a, min(128, edges[k + 1] - a), k * w_rows))
+            t = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3)[:len(rows)]
+            cache[key] = t.to(self.device)
+        return cache[key]
+
     def sparse_taps_bwd(self, depth: int, kernel: str = '333', stride: int = 1):
         """What the backward of a live-tap convolution needs besides `sparse_taps`: `rowof` (P, 1) int32, the output row
         of every pair (to gather the output gradient pair-major), and `inv_slot` (n_src, taps) int32, for every INPUT row

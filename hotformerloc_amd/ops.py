@@ -464,6 +464,21 @@ def linear_x3_gelu_bwd(dy2: torch.Tensor, wt2: torch.Tensor, preact: torch.Tenso
     return out
 
 
+def linear_x3_grouped(x2: torch.Tensor, w2: torch.Tensor, tiles: torch.Tensor, out_features: int) -> torch.Tensor:
+    """One launch of the split-precision GEMM over row tiles with different weight blocks (hfl_linear_x3_grouped):
+    x2 (rows, 2K) split2, w2 (blocks * Npad, 2K) split2, tiles (n, 3) int32 {first row, rows, first weight row};
+    returns (rows, out_features) f32."""
+    _dev(x2, w2, tiles)
+    assert x2.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x2.is_contiguous() and w2.is_contiguous()
+    assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.shape[1] == 3 and w2.shape[1] == x2.shape[1]
+    m, k = x2.shape[0], x2.shape[1] // 2
+    out = torch.empty((m, out_features), dtype=torch.float32, device=x2.device)
+    with _timed('hfl_linear_x3', m * k * 4 + m * out_features * 4, 2 * m * k * out_features):
+        check(_native.load().hfl_linear_x3_grouped(out.data_ptr(), x2.data_ptr(), w2.data_ptr(), tiles.data_ptr(),
+                                                   tiles.shape[0], m, k, out_features, _stream()), 'hfl_linear_x3_grouped')
+    return out
+
+
 def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):
     """(dW, db) of y = x W^T + b from split2 operands: dW (N, K) = dy^T x, db (N) = dy summed over rows (hfl_wgrad_x3;
     fixed reduction order)."""

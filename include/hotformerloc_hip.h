@@ -350,6 +350,13 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream);
 int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* Grouped form: ONE launch over row tiles that use DIFFERENT weight blocks -- the per-tap products of an octree convolution
+ * over its live (row, tap) pairs (models/layers/octformer_layers.py:89-95; model.OctreeConv._forward_live_taps), which were
+ * 27 library GEMM launches.  tiles (n_tiles, 3) int32 = {first row, rows (1..128), first row of the tile's weight block in
+ * w_split2}; out (n_rows, out_features) f32 = x W_block^T for the rows of every tile (rows outside all tiles are not
+ * written).  out_features % 128 == 0, or out_features == 64 with every weight block padded to 128 rows (zeros). */
+int hfl_linear_x3_grouped(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const int32_t* tiles,
+                          int64_t n_tiles, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream);
 /* Per-row scaled forms for per-cloud stochastic depth (OctreeDropPath, models/layers/octformer_layers.py:213-289) inside the
  * fused residual branches: out = (x W^T + bias) * row_scale[m] + residual, and split2(x * row_scale[row]) for the branch's
  * incoming gradient.  row_scale (n_rows) may be NULL (= 1). */
