@@ -103,12 +103,18 @@ class LiveTapConvFn(torch.autograd.Function):
         src, slot, edges = octree.sparse_taps(depth, kernel, stride)
         g = ops.octree_gather(data, src)
         kdim, cin, cout = weights.shape
-        part = torch.empty((g.shape[0], cout), dtype=torch.float32, device=data.device)
-        for k in range(kdim):
-            if edges[k + 1] > edges[k]:
-                torch.mm(g[edges[k]:edges[k + 1]], weights[k], out=part[edges[k]:edges[k + 1]])
+        grouped = _grouped_ok(cin, cout) and edges[-1] > 0
+        if grouped:            # one grouped split-precision launch over all taps (hfl_linear_x3_grouped)
+            npad = max(cout, 128)
+            part = ops.linear_x3_grouped(ops.split2(g), _tap_blocks(weights, True, npad),
+                                         octree.tap_tiles(depth, kernel, stride, npad), cout)
+        else:
+            part = torch.empty((g.shape[0], cout), dtype=torch.float32, device=data.device)
+            for k in range(kdim):
+                if edges[k + 1] > edges[k]:
+                    torch.mm(g[edges[k]:edges[k + 1]], weights[k], out=part[edges[k]:edges[k + 1]])
         ctx.save_for_backward(g, weights)
-        ctx.octree, ctx.key, ctx.n_src = octree, (depth, kernel, stride), data.shape[0]
+        ctx.octree, ctx.key, ctx.n_src, ctx.grouped = octree, (depth, kernel, stride), data.shape[0], grouped
         return ops.dwconv_forward_backward(part, _unit_taps(kdim, cout, data.device), slot)
 
     @staticmethod
@@ -118,7 +124,6 @@ class LiveTapConvFn(torch.autograd.Function):
         rowof, inv_slot, chunks, tap_off = ctx.octree.sparse_taps_bwd(*ctx.key)
         kdim, cin, cout = weights.shape
         dpart = ops.octree_gather(dout.contiguous(), rowof)
-        dg = torch.empty_like(g) if ctx.needs_input_grad[0] else None
         if cin % 64 == 0 and cout % 64 == 0:
             dw = ops.tap_wgrad(g, dpart, chunks, tap_off, kdim)       # long contractions into small matrices: own kernel
         else:
@@ -126,15 +131,50 @@ class LiveTapConvFn(torch.autograd.Function):
             for k in range(kdim):
                 if edges[k + 1] > edges[k]:
                     torch.mm(g[edges[k]:edges[k + 1]].t(), dpart[edges[k]:edges[k + 1]], out=dw[k])
-        if dg is not None:
-            for k in range(kdim):
-                a, b = edges[k], edges[k + 1]
-                if b > a:
-                    torch.mm(dpart[a:b], weights[k].t(), out=dg[a:b])
         ddata = None
-        if dg is not None:
+        if ctx.needs_input_grad[0]:
+            if ctx.grouped:
+                npad = max(cin, 128)
+                dg = ops.linear_x3_grouped(ops.split2(dpart), _tap_blocks(weights, False, npad),
+                                           ctx.octree.tap_tiles(*ctx.key, npad), cin)
+            else:
+                dg = torch.empty_like(g)
+                for k in range(kdim):
+                    a, b = edges[k], edges[k + 1]
+                    if b > a:
+                        torch.mm(dpart[a:b], weights[k].t(), out=dg[a:b])
             ddata = ops.dwconv_forward_backward(dg, _unit_taps(kdim, cin, dg.device), inv_slot)
         return ddata, dw, None, None, None, None
+
+
+def _grouped_ok(cin, cout) -> bool:
+    return (cin % 32 == 0 and cout % 32 == 0 and (cout % 128 == 0 or cout == 64) and (cin % 128 == 0 or cin == 64)
+            and _GROUPED_TAPS)
+
+
+_GROUPED_TAPS = __import__('os').environ.get('HFL_GROUPED_TAPS', '1') != '0'
+_TAP_BLOCK_CACHE = {}
+
+
+def _tap_blocks(weights, transposed: bool, npad: int):
+    """split2 layout of the per-tap weight blocks of an octree convolution, every block padded to `npad` rows:
+    transposed = W[k]^T (Cout x Cin) for the forward product, else W[k] (Cin x Cout) for the input gradient; rebuilt when
+    the optimizer updates the parameter."""
+    import weakref
+    key = (id(weights), transposed, npad)
+    hit = _TAP_BLOCK_CACHE.get(key)
+    if hit is None or hit[0]() is not weights or hit[1] != weights._version or hit[3] != weights.data_ptr():
+        w = weights.detach()
+        blocks = w.transpose(1, 2) if transposed else w                   # (kdim, rows, K)
+        kdim, rows, kk = blocks.shape
+        if npad > rows:
+            blocks = torch.cat([blocks, blocks.new_zeros(kdim, npad - rows, kk)], 1)
+        if len(_TAP_BLOCK_CACHE) > 256:
+            _TAP_BLOCK_CACHE.clear()
+        hit = (weakref.ref(weights), weights._version, ops.split2(blocks.reshape(kdim * npad, kk).contiguous()),
+               weights.data_ptr())
+        _TAP_BLOCK_CACHE[key] = hit
+    return hit[2]
 
 
 _UNIT_TAPS = {}
