@@ -245,12 +245,14 @@ class Octree:
         key = (depth, kernel, stride, w_rows)
         if key not in cache:
             _, _, edges = self.sparse_taps(depth, kernel, stride)
-            rows = []
+            e = np.asarray(edges, dtype=np.int64)
+            per_tap = []
             for k in range(len(edges) - 1):
-                for a in range(edges[k], edges[k + 1], 128):
-                    rows.append((a, min(128, edges[k + 1] - a), k * w_rows))
-            t = torch.tensor(rows if rows else [(0, 0, 0)], dtype=torch.int32).view(-1, 3)[:len(rows)]
-            cache[key] = t.to(self.device)
+                a = np.arange(e[k], e[k + 1], 128, dtype=np.int64)
+                if a.size:
+                    per_tap.append(np.stack([a, np.minimum(128, e[k + 1] - a), np.full_like(a, k * w_rows)], 1))
+            t = np.concatenate(per_tap, 0).astype(np.int32) if per_tap else np.zeros((0, 3), np.int32)
+            cache[key] = torch.from_numpy(t).to(self.device)
         return cache[key]
 
     def sparse_taps_bwd(self, depth: int, kernel: str = '333', stride: int = 1):
@@ -273,14 +275,17 @@ class Octree:
             ops.inverse_table(inv, neigh)
             inv_slot = torch.where(inv >= 0, slot.gather(0, inv.clamp_min(0).long()), torch.full_like(inv, -1))
             # pair chunks of the weight-gradient kernel: <= 2048 pairs each, never across a tap boundary
-            chunks, tap_off = [], [0]
+            e = np.asarray(edges, dtype=np.int64)
+            per_tap, tap_off = [], [0]
             for k in range(len(edges) - 1):
-                for a in range(edges[k], edges[k + 1], 2048):
-                    chunks.append((k, a, min(a + 2048, edges[k + 1])))
-                tap_off.append(len(chunks))
-            chunks_t = torch.tensor(chunks if chunks else [(0, 0, 0)], dtype=torch.int32).view(-1, 3)[:len(chunks)]
+                a = np.arange(e[k], e[k + 1], 2048, dtype=np.int64)
+                if a.size:
+                    per_tap.append(np.stack([np.full_like(a, k), a, np.minimum(a + 2048, e[k + 1])], 1))
+                tap_off.append(tap_off[-1] + int(a.size))
+            chunks_np = np.concatenate(per_tap, 0).astype(np.int32) if per_tap else np.zeros((0, 3), np.int32)
             cache[key] = (rowof[:edges[-1]].view(-1, 1), inv_slot.contiguous(),
-                          chunks_t.to(slot.device), torch.tensor(tap_off, dtype=torch.int32, device=slot.device))
+                          torch.from_numpy(chunks_np).to(slot.device),
+                          torch.tensor(tap_off, dtype=torch.int32, device=slot.device))
         return cache[key]
 
     def _build_tap_lists(self, keys):
