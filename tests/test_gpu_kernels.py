@@ -626,6 +626,37 @@ def test_linear_x3_matches_fp64_linear():
         assert torch.equal(got, a3[:, :C] + a3[:, 2 * C:])
 
 
+def test_linear_x3_grouped_matches_per_block_products():
+    """One launch over row tiles with different weight blocks (hfl_linear_x3_grouped, the per-tap products of a live-tap
+    octree convolution): exact on small integers, <= 1e-5 relative L2 on real data; ragged tile heights (1..128 rows), empty
+    blocks, out_features = 64 on 128-row zero-padded blocks."""
+    g = torch.Generator().manual_seed(51)
+    for cin, cout in ((64, 64), (128, 128), (32, 64), (64, 128), (128, 256)):
+        npad = max(cout, 128)
+        sizes = [0, 1, 127, 128, 129, 700, 0, 33, 2049]                    # rows per block ("tap")
+        nb = len(sizes)
+        edges = [0]
+        for n in sizes:
+            edges.append(edges[-1] + n)
+        tiles = [(a, min(128, edges[k + 1] - a), k * npad) for k in range(nb) for a in range(edges[k], edges[k + 1], 128)]
+        tiles_t = torch.tensor(tiles, dtype=torch.int32, device=DEV)
+        for integer in (True, False):
+            if integer:
+                x = torch.randint(-3, 4, (edges[-1], cin), generator=g).float()
+                w = torch.randint(-3, 4, (nb, cout, cin), generator=g).float()
+            else:
+                x = torch.randn(edges[-1], cin, generator=g)
+                w = torch.randn(nb, cout, cin, generator=g) * 0.1
+            wp = torch.cat([w, torch.zeros(nb, npad - cout, cin)], 1) if npad > cout else w
+            got = ops.linear_x3_grouped(ops.split2(x.to(DEV)), ops.split2(wp.reshape(nb * npad, cin).to(DEV)), tiles_t,
+                                        cout).cpu()
+            ref = torch.cat([x[edges[k]:edges[k + 1]].double() @ w[k].double().t() for k in range(nb)], 0)
+            if integer:
+                assert torch.equal(got, ref.float()), (cin, cout)
+            else:
+                assert ((got.double() - ref).norm() / ref.norm()).item() < 1e-5, (cin, cout)
+
+
 def test_wgrad_x3_matches_fp64_and_is_reproducible():
     """dW = dy^T x and db = column sums of dy from split2 operands (hfl_wgrad_x3): exact on small integers (every product
     and partial sum is representable), <= 1e-5 relative L2 against fp64 on real data, ragged row counts (not a multiple of
