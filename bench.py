@@ -51,8 +51,9 @@ def parse():
     ap.add_argument('--config', default='wild-places')
     ap.add_argument('--batch', type=int, default=None, help='clouds per GPU (default 32; 64 for cs-wild-places --train)')
     ap.add_argument('--points', type=int, default=4096)
-    ap.add_argument('--keep-drop-path', action='store_true',
-                    help='--train: keep the config\'s stochastic depth (drop_path = 0.5) instead of switching it off')
+    ap.add_argument('--no-drop-path', action='store_true',
+                    help='--train: switch the config\'s per-cloud stochastic depth (drop_path = 0.5) off')
+    ap.add_argument('--keep-drop-path', action='store_true', help='(default now; kept for old command lines)')
     ap.add_argument('--points-max', type=int, default=None,
                     help='variable density: per-cloud point count ~ U{points..points_max}, forest / unit-ball mix '
                          '(default for cs-wild-places: 32768, BASELINE config 3)')
@@ -162,7 +163,7 @@ def main():
 
     params, depth = load_config(args.config)
     if args.train:
-        if not args.keep_drop_path:
+        if args.no_drop_path:
             params.drop_path = 0.0
     model = model_factory(params)
     syn.fill_synthetic_weights(model, 'init')
@@ -366,7 +367,7 @@ def main():
                                       '%d..%d (forest/ball mix)' % (args.points, args.points_max) if args.points_max
                                       else '%d' % args.points, depth,
                                       ('multi-staged training step (stage 1 + TruncatedSmoothAP + stage 3 + grad all-reduce + AdamW)'
-                                       if args.multistaged else ('forward+backward, stochastic depth %s' % ('on' if args.keep_drop_path else 'off'))) if args.train else 'forward-only'),
+                                       if args.multistaged else ('forward+backward, stochastic depth %s' % ('off' if args.no_drop_path else 'on (drop_path = %.2f, as the config trains)' % params.drop_path))) if args.train else 'forward-only'),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
                        'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
                                      ('rccl all_gather at world size 1' if collective else 'none')},
