@@ -527,7 +527,7 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   p.qk_channels = out_features / 3;
   p.q_scale = q_scale;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
-  const size_t lds = (size_t)(32 * mt + XT) * 128;                 // one stage: x tile | w tile (32 or 48 KiB)
+  const size_t lds = (size_t)(32 * mt + XT) * 128 + (size_t)(g_x3_dbg & 0xFF) * 1024;   // (+ probe: extra KiB to cut occupancy)
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define HFL_X3_LAUNCH(E, M)                                                                              \
   {                                                                                                      \
