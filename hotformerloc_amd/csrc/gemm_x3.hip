@@ -86,6 +86,45 @@ __device__ __forceinline__ float x3_gelu(float v) {
   return 0.5f * v * (1.0f + erf_v);
 }
 
+// ---- packed (two values per instruction) forms for the epilogues: the fc1 epilogue was 2500 VALU instructions per wave
+// (PMC: 43 M per launch, 70 us of every SIMD against 43 us of MFMA) in its scalar form
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 x3_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 x3_erf_abs2(f32x2 v, f32x2& e_out) {          // erf(|v| / sqrt 2), e_out = exp(-v^2 / 2)
+  const f32x2 z = __builtin_elementwise_abs(v) * 0.70710678118654752440f;
+  const f32x2 den = z * 0.3275911f + 1.0f;
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 poly = t * 1.061405429f + (-1.453152027f);
+  poly = poly * t + 1.421413741f;
+  poly = poly * t + (-0.284496736f);
+  poly = poly * t + 0.254829592f;
+  const f32x2 a = z * z * (-1.4426950408889634f);
+  const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  e_out = e;
+  return 1.0f - poly * t * e;
+}
+__device__ __forceinline__ f32x2 x3_gelu2(f32x2 v) {
+  f32x2 e;
+  const f32x2 erf_abs = x3_erf_abs2(v, e);
+  const f32x2 erf_v = {copysignf(erf_abs[0], v[0]), copysignf(erf_abs[1], v[1])};
+  return v * 0.5f * (erf_v + 1.0f);
+}
+__device__ __forceinline__ f32x2 x3_gelu_grad2(f32x2 v) {
+  f32x2 e;
+  const f32x2 erf_abs = x3_erf_abs2(v, e);
+  const f32x2 erf_v = {copysignf(erf_abs[0], v[0]), copysignf(erf_abs[1], v[1])};
+  return v * 0.3989422804014327f * e + (erf_v + 1.0f) * 0.5f;
+}
+// two floats -> packed bf16 hi pair and lo pair (v_cvt_pk_bf16_f32: round to nearest even, as x3_bf16_rne)
+__device__ __forceinline__ void x3_split_pair(f32x2 v, uint32_t& hi, uint32_t& lo) {
+  const x3_bf16x2 h = __builtin_convertvector(v, x3_bf16x2);
+  const f32x2 r = v - __builtin_convertvector(h, f32x2);
+  const x3_bf16x2 l = __builtin_convertvector(r, x3_bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // d/dv gelu(v) = Phi(v) + v phi(v), same erf approximation
 __device__ __forceinline__ float x3_gelu_grad(float v) {
   const float z = fabsf(v) * 0.70710678118654752440f;
@@ -164,26 +203,27 @@ __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][M
                            ((lane & 1) ? 32 : 0);
         *reinterpret_cast<u32x4*>(o) = qq;
       } else {
+        f32x2 v01 = {v.x, v.y}, v23 = {v.z, v.w};
+        uint32_t h01, l01, h23, l23;                                      // packed bf16 pairs
         if (EPI == 4) {
           const float4 y = *reinterpret_cast<const float4*>(p.aux + m * N + nbase);
-          v.x *= x3_gelu_grad(y.x); v.y *= x3_gelu_grad(y.y); v.z *= x3_gelu_grad(y.z); v.w *= x3_gelu_grad(y.w);
+          v01 *= x3_gelu_grad2((f32x2){y.x, y.y});
+          v23 *= x3_gelu_grad2((f32x2){y.z, y.w});
         } else {
           if (EPI == 3) *reinterpret_cast<float4*>(p.aux + m * N + nbase) = v;
-          v.x = x3_gelu(v.x); v.y = x3_gelu(v.y); v.z = x3_gelu(v.z); v.w = x3_gelu(v.w);
+          v01 = x3_gelu2(v01);
+          v23 = x3_gelu2(v23);
         }
-        const uint32_t h0 = x3_bf16_rne(v.x), h1 = x3_bf16_rne(v.y), h2 = x3_bf16_rne(v.z), h3 = x3_bf16_rne(v.w);
-        const uint32_t l0 = x3_bf16_rne(v.x - __uint_as_float(h0 << 16));
-        const uint32_t l1 = x3_bf16_rne(v.y - __uint_as_float(h1 << 16));
-        const uint32_t l2 = x3_bf16_rne(v.z - __uint_as_float(h2 << 16));
-        const uint32_t l3 = x3_bf16_rne(v.w - __uint_as_float(h3 << 16));
+        x3_split_pair(v01, h01, l01);
+        x3_split_pair(v23, h23, l23);
         // lane pair (2k, 2k+1) holds 8 consecutive features: the even lane stores their 8 hi values (16 B), the odd
         // lane their 8 lo values, so one instruction writes both halves of every [32 x hi | 32 x lo] line
-        const uint32_t mine0 = (lane & 1) ? h0 | (h1 << 16) : l0 | (l1 << 16);   // what the partner needs from me
-        const uint32_t mine1 = (lane & 1) ? h2 | (h3 << 16) : l2 | (l3 << 16);
+        const uint32_t mine0 = (lane & 1) ? h01 : l01;                    // what the partner needs from me
+        const uint32_t mine1 = (lane & 1) ? h23 : l23;
         const uint32_t got0 = __shfl_xor(mine0, 1, 64), got1 = __shfl_xor(mine1, 1, 64);
         uint4 q;
-        if (lane & 1) q = make_uint4(got0, got1, l0 | (l1 << 16), l2 | (l3 << 16));        // lo of (partner, me)
-        else          q = make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), got0, got1);        // hi of (me, partner)
+        if (lane & 1) q = make_uint4(got0, got1, l01, l23);               // lo of (partner, me)
+        else          q = make_uint4(h01, h23, got0, got1);               // hi of (me, partner)
         const int nfeat = n_tile + (ecol & ~1) * 4;                      // first of the pair's 8 features
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + m * (2 * (int64_t)N) + (nfeat >> 5) * 64 + (nfeat & 31) +
                       ((lane & 1) ? 32 : 0);
