@@ -60,6 +60,17 @@ class Points:
         return self.to('cpu')
 
 
+def _split_ranges(edges: np.ndarray, step: int):
+    """Cut the consecutive ranges [edges[k], edges[k+1]) into pieces of at most `step`: (range id, first, length) of every
+    piece, in order (no Python loop over the ranges: this runs once per convolution and fresh batch)."""
+    cnt = np.diff(edges)
+    n = (cnt + step - 1) // step
+    rid = np.repeat(np.arange(cnt.size, dtype=np.int64), n)
+    within = np.arange(int(n.sum()), dtype=np.int64) - np.repeat(np.cumsum(n) - n, n)
+    first = edges[rid] + within * step
+    return rid, first, np.minimum(step, edges[rid + 1] - first)
+
+
 class Octree:
     def __init__(self, depth: int, full_depth: int = 2, batch_size: int = 1,
                  device: Union[torch.device, str] = 'cpu', **kwargs):
@@ -245,13 +256,8 @@ class Octree:
         key = (depth, kernel, stride, w_rows)
         if key not in cache:
             _, _, edges = self.sparse_taps(depth, kernel, stride)
-            e = np.asarray(edges, dtype=np.int64)
-            per_tap = []
-            for k in range(len(edges) - 1):
-                a = np.arange(e[k], e[k + 1], 128, dtype=np.int64)
-                if a.size:
-                    per_tap.append(np.stack([a, np.minimum(128, e[k + 1] - a), np.full_like(a, k * w_rows)], 1))
-            t = np.concatenate(per_tap, 0).astype(np.int32) if per_tap else np.zeros((0, 3), np.int32)
+            tap, a, rows = _split_ranges(np.asarray(edges, dtype=np.int64), 128)
+            t = np.stack([a, rows, tap * w_rows], 1).astype(np.int32)
             cache[key] = torch.from_numpy(t).to(self.device)
         return cache[key]
 
@@ -276,13 +282,9 @@ class Octree:
             inv_slot = torch.where(inv >= 0, slot.gather(0, inv.clamp_min(0).long()), torch.full_like(inv, -1))
             # pair chunks of the weight-gradient kernel: <= 2048 pairs each, never across a tap boundary
             e = np.asarray(edges, dtype=np.int64)
-            per_tap, tap_off = [], [0]
-            for k in range(len(edges) - 1):
-                a = np.arange(e[k], e[k + 1], 2048, dtype=np.int64)
-                if a.size:
-                    per_tap.append(np.stack([np.full_like(a, k), a, np.minimum(a + 2048, e[k + 1])], 1))
-                tap_off.append(tap_off[-1] + int(a.size))
-            chunks_np = np.concatenate(per_tap, 0).astype(np.int32) if per_tap else np.zeros((0, 3), np.int32)
+            tap, a, rows = _split_ranges(e, 2048)
+            chunks_np = np.stack([tap, a, a + rows], 1).astype(np.int32)
+            tap_off = np.concatenate([[0], np.cumsum((np.diff(e) + 2047) // 2048)]).tolist()
             cache[key] = (rowof[:edges[-1]].view(-1, 1), inv_slot.contiguous(),
                           torch.from_numpy(chunks_np).to(slot.device),
                           torch.tensor(tap_off, dtype=torch.int32, device=slot.device))
