@@ -14,7 +14,20 @@ from . import _native
 from ._native import WindowAttnDesc, check
 
 
+# torch.cuda.current_stream() / current_device() cost ~8 us / ~1 us of Python per call (device-index normalisation, lazy-init
+# checks) and every launch wrapper needs both: 3.4 ms of a 9.9 ms host issue budget per forward.  The raw C hooks are the ones
+# torch's own compiled-kernel launchers use.
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_RAW_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
+def _current_device() -> int:
+    return _RAW_DEVICE() if _RAW_DEVICE is not None else torch.cuda.current_device()
+
+
 def _stream():
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -90,7 +103,7 @@ def _dev(*tensors):
             raise _native.NativeLibraryError(
                 'hotformerloc_amd ops need GPU tensors (got %s); there is no CPU fallback' % t.device)
         if cur is None:
-            cur = torch.cuda.current_device()
+            cur = _current_device()
         if t.device.index != cur:
             raise _native.NativeLibraryError(
                 'tensor on %s but the current device is cuda:%d; wrap the call in torch.cuda.device(...)'
