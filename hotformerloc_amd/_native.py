@@ -28,6 +28,22 @@ class WindowAttnDesc(ctypes.Structure):
                 ('scale', c_float), ('depth', c_int32), ('rpe_expanded', c_void_p)]
 
 
+class BlockWeights(ctypes.Structure):
+    """hfl_block_weights"""
+    _fields_ = [('channels', c_int64), ('eps', c_float), ('q_scale', c_float),
+                ('cpe_weight', c_void_p), ('cpe_gamma', c_void_p), ('cpe_beta', c_void_p),
+                ('norm1_gamma', c_void_p), ('norm1_beta', c_void_p), ('norm2_gamma', c_void_p), ('norm2_beta', c_void_p),
+                ('qkv_w', c_void_p), ('proj_w', c_void_p), ('fc1_w', c_void_p), ('fc2_w', c_void_p),
+                ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p),
+                ('rpe_table', c_void_p)]
+
+
+class BlockIO(ctypes.Structure):
+    """hfl_block_io"""
+    _fields_ = [('x_in', c_void_p), ('relay', c_void_p), ('out', c_void_p), ('arena', c_void_p),
+                ('neigh', c_void_p), ('tok_meta', c_void_p), ('n_rows', c_int64), ('n_tokens', c_int64)]
+
+
 # name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
 SIGNATURES = {
     'hfl_version': (c_int, []),
@@ -80,6 +96,8 @@ SIGNATURES = {
     'hfl_linear_x3_qkv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     'hfl_window_attention_f16_ok': (c_int, [ctypes.POINTER(WindowAttnDesc), c_int64]),
     'hfl_split2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'hfl_block_forward_x3_arena': (c_int64, [c_int64, c_int64]),
+    'hfl_block_forward_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'hfl_linear_x3_grouped': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'hfl_split2_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_linear_x3_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

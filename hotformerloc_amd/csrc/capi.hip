@@ -7,4 +7,52 @@ int hfl_version(void) { return 100; }   // 1.00
 
 const char* hfl_arch(void) { return "gfx950"; }
 
+// One transformer block of the inference path as ONE call: the nine launches a block makes (CPE, relay-row copy, LN1 -> split2,
+// qkv GEMM into the fp16 attention operand, window attention, proj GEMM + residual, LN2 -> split2, fc1 GEMM + GELU, fc2 GEMM +
+// residual) issued back to back from native code.  Nothing new runs on the GPU; what goes away is eight Python launch wrappers
+// per block (~22 us of host time each: the fresh-batch path is host-bound).  See include/hotformerloc_hip.h.
+int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, const hfl_window_attn_desc* desc,
+                         hfl_stream_t stream) {
+  if (w == nullptr || io == nullptr || desc == nullptr) return HFL_EINVAL;
+  const int64_t C = w->channels, rows = io->n_rows, nt = io->n_tokens;
+  if (C <= 0 || C % 128 != 0 || rows < nt || nt < 0) return HFL_EINVAL;
+  if (rows == 0) return HFL_OK;
+  // arena carve (16-B aligned: C % 128 == 0): x0 f32 | a2 split2 | qkv | o2 split2 | x1 f32 | h2 split2 | g2 split2 (4C)
+  unsigned char* a = static_cast<unsigned char*>(io->arena);
+  const size_t unit = (size_t)rows * C * 4;
+  float* x0 = reinterpret_cast<float*>(a);
+  uint16_t* a2 = reinterpret_cast<uint16_t*>(a + unit);
+  float* qkv = reinterpret_cast<float*>(a + 2 * unit);
+  uint16_t* o2 = reinterpret_cast<uint16_t*>(a + 5 * unit);
+  float* x1 = reinterpret_cast<float*>(a + 6 * unit);
+  uint16_t* h2 = reinterpret_cast<uint16_t*>(a + 7 * unit);
+  uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
+  int rc;
+  if (nt > 0) {
+    rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
+    if (rc != HFL_OK) return rc;
+  }
+  if (rows > nt) {
+    const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
+    hipError_t e = hipMemcpyAsync(x0 + nt * C, src, (size_t)(rows - nt) * C * 4, hipMemcpyDeviceToDevice,
+                                  static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return (int)e;
+  }
+  rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, rows, C, w->eps, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_linear_x3_qkv(qkv, a2, w->qkv_w, w->qkv_b, rows, (int)C, (int)(3 * C), w->q_scale, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);
+  if (rc != HFL_OK) return rc;
+  return hfl_linear_x3(io->out, g2, w->fc2_w, w->fc2_b, x1, rows, (int)(4 * C), (int)C, 0, stream);
+}
+
+int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) { return n_rows * channels * 4 * 12; }
+
 }  // extern "C"

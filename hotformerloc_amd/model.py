@@ -556,6 +556,45 @@ def _init_layer_scale(block, dim, layer_scale):
         block.gamma1 = block.gamma2 = 1
 
 
+_NATIVE_BLOCK = os.environ.get('HFL_NATIVE_BLOCK', '1') != '0'     # inference blocks as one native call (hfl_block_forward_x3)
+
+
+def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
+    """The block's inference forward as ONE native call, or None when this block / launch is not eligible (then the Python
+    sequence of the same kernels runs).  Same kernels, same order, same results; only the host work differs."""
+    att = block.attention
+    C = att.dim
+    if not (_NATIVE_BLOCK and _GEMM_MODE == 'x3' and _ATTN_F16 and _split_path(x_in) and ops.KernelTimer.active is None
+            and not block.use_layer_scale and not _drops(block) and not block.cpe.xcpe and C % 128 == 0
+            and x_in.dtype == torch.float32 and x_in.is_contiguous()):
+        return None
+    nt = plan.n_tokens[depth]
+    rows = x_in.shape[0]
+    if not ops.window_attention_f16_ok(rows, att.patch_size, att.dilation, att.rt_per_window, att.num_heads, depth):
+        return None
+    from ._native import BlockWeights, WindowAttnDesc
+    table = None if att.rpe is None else att.rpe.rpe_table
+    bnd = int(0.8 * att.patch_size * att.dilation ** 0.5)
+    expanded = None if table is None else ops.rpe_expand(table, att.num_heads, bnd, depth)
+    if table is not None and expanded is None:
+        return None
+    mlp, cpe = block.mlp, block.cpe
+    keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2), expanded)
+    w = BlockWeights(channels=C, eps=block.norm1.eps, q_scale=16 ** -0.5 * 1.4426950408889634,
+                     cpe_weight=cpe.conv.weights.data_ptr(), cpe_gamma=cpe.norm.weight.data_ptr(),
+                     cpe_beta=cpe.norm.bias.data_ptr(), norm1_gamma=block.norm1.weight.data_ptr(),
+                     norm1_beta=block.norm1.bias.data_ptr(), norm2_gamma=block.norm2.weight.data_ptr(),
+                     norm2_beta=block.norm2.bias.data_ptr(), qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(),
+                     fc1_w=keep[2].data_ptr(), fc2_w=keep[3].data_ptr(), qkv_b=att.qkv.bias.data_ptr(),
+                     proj_b=att.proj.bias.data_ptr(), fc1_b=mlp.fc1.bias.data_ptr(), fc2_b=mlp.fc2.bias.data_ptr(),
+                     rpe_table=None if table is None else table.data_ptr())
+    desc = WindowAttnDesc(n_tokens=nt, rt_row0=nt, n_windows=plan.n_windows[depth], patch_size=att.patch_size,
+                          dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
+                          batch_size=plan.B, scale=16 ** -0.5, depth=depth,
+                          rpe_expanded=None if expanded is None else expanded.data_ptr())
+    return ops.block_forward_x3(w, keep, x_in, relay, plan.neigh(depth), plan.meta[depth], nt, desc)
+
+
 class OctFormerBlock(nn.Module):
     """models/octformer_backbone.py:182-299 (use_rt=False)"""
 
@@ -571,6 +610,10 @@ class OctFormerBlock(nn.Module):
         _init_layer_scale(self, dim, layer_scale)
 
     def forward(self, x, plan: WindowPlan, depth: int):
+        if not _grad_path(x):
+            y = _native_block(self, x, None, plan, depth)
+            if y is not None:
+                return y
         x = self.cpe(x, plan, depth, residual=True)
         if _split_path(x) and not self.use_layer_scale and not _drops(self):
             o3 = self.attention.forward_split(x, self.norm1, plan, depth)
@@ -631,6 +674,9 @@ class HOTFormerBlock(nn.Module):
         if _grad_path(buf):
             buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:] if relay is None else relay], 0)
         else:                                   # CPE writes straight into the new buffer's token rows
+            y = _native_block(self, buf, relay, plan, depth)
+            if y is not None:
+                return y
             new = torch.empty_like(buf)
             self.cpe(buf[:nt], plan, depth, residual=True, out=new[:nt])
             new[nt:].copy_(buf[nt:] if relay is None else relay)

@@ -492,6 +492,23 @@ def linear_x3_grouped(x2: torch.Tensor, w2: torch.Tensor, tiles: torch.Tensor, o
     return out
 
 
+def block_forward_x3(weights, keep_alive, x_in, relay, neigh, tok_meta, n_tokens: int, desc: WindowAttnDesc):
+    """One transformer block of the inference path in ONE native call (hfl_block_forward_x3): CPE -> [relay rows] -> LN1 ->
+    qkv -> window attention -> proj + residual -> LN2 -> fc1 + GELU -> fc2 + residual.  `weights` = a filled
+    `_native.BlockWeights` (see model._block_weights), `keep_alive` the tensors its pointers refer to."""
+    _dev(x_in, relay, neigh, tok_meta)
+    rows, c = x_in.shape
+    lib = _native.load()
+    out = torch.empty((rows, c), dtype=torch.float32, device=x_in.device)
+    arena = torch.empty(int(lib.hfl_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=x_in.device)
+    io = _native.BlockIO(x_in=x_in.data_ptr(), relay=None if relay is None else relay.data_ptr(), out=out.data_ptr(),
+                         arena=arena.data_ptr(), neigh=neigh.data_ptr(), tok_meta=tok_meta.data_ptr(), n_rows=rows,
+                         n_tokens=n_tokens)
+    check(lib.hfl_block_forward_x3(ctypes.byref(weights), ctypes.byref(io), ctypes.byref(desc), _stream()),
+          'hfl_block_forward_x3')
+    return out
+
+
 def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):
     """(dW, db) of y = x W^T + b from split2 operands: dW (N, K) = dy^T x, db (N) = dy summed over rows (hfl_wgrad_x3;
     fixed reduction order)."""

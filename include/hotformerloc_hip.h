@@ -412,6 +412,37 @@ int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv, c
 int hfl_relay_attention_bwd(float* dqkv, const float* qkv, const float* dout, const int32_t* seq_rows,
                             const int32_t* seq_off, int batch, int n_heads, float scale,
                             int max_seq_len, hfl_stream_t stream);
+/* ----------------------------------------------------------------------
+ * 12. A whole transformer block of the inference path in one call (csrc/capi.hip): OctFormerBlock / HOTFormerBlock forward
+ *     (models/octformer_backbone.py:232-281, models/hotformerloc_backbone.py:130-236 with layer scale and stochastic depth
+ *     off) = CPE -> [relay rows] -> LN1 -> qkv -> window attention -> proj + residual -> LN2 -> fc1 + GELU -> fc2 +
+ *     residual, on the entry points above (split-precision GEMMs, fp16 (hi, lo) attention operands: the caller checks
+ *     hfl_window_attention_f16_ok first).  Weights in the layouts those entry points take; `rpe_table` may be NULL.
+ *     io->x_in: (n_rows, C) input buffer [tokens | relay rows]; io->relay: optional fresh relay rows (n_rows - n_tokens, C)
+ *     that replace x_in's; io->out (n_rows, C); io->arena >= hfl_block_forward_x3_arena(n_rows, C) bytes of scratch.
+ * ---------------------------------------------------------------------- */
+typedef struct hfl_block_weights {
+  int64_t channels;
+  float eps, q_scale;
+  const float *cpe_weight, *cpe_gamma, *cpe_beta;
+  const float *norm1_gamma, *norm1_beta, *norm2_gamma, *norm2_beta;
+  const uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;     /* split2 */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+  const float* rpe_table;                              /* (3 (2 pos_bnd + 1), H) or NULL */
+} hfl_block_weights;
+typedef struct hfl_block_io {
+  const float* x_in;
+  const float* relay;
+  float* out;
+  void* arena;
+  const int32_t* neigh;                                /* (n_tokens, 27) */
+  const uint32_t* tok_meta;
+  int64_t n_rows, n_tokens;
+} hfl_block_io;
+int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels);
+int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, const hfl_window_attn_desc* desc,
+                         hfl_stream_t stream);
+
 /* Weight gradient of an octree convolution over its live (row, tap) pairs (csrc/tapconv.hip; replaces autograd over
  * ocnn's octree2col + mm, models/layers/octformer_layers.py:89-95): dw[k] (cin, cout) = g_k^T dpart_k over the pairs of tap
  * k.  g (P, cin), dpart (P, cout) fp32 pair-major; chunks (n_chunks, 3) int32 = {tap, first pair, end pair}, ascending, no

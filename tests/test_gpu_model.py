@@ -270,6 +270,25 @@ def test_stochastic_depth_inside_the_fused_branches_matches_the_unfused_path():
     assert worst < 1e-3, worst
 
 
+def test_native_block_executor_equals_the_python_launch_sequence():
+    """hfl_block_forward_x3 issues the same kernels in the same order as the Python wrappers: bitwise equal descriptors."""
+    from hotformerloc_amd import model as M
+    params, depth = load_config('wild-places')
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'stress')
+    model = model.cuda().eval()
+    octree = build_batch_octree(syn.make_clouds(91, 3, 2000, params.coordinates), depth, 2, 'cuda')
+    out = {}
+    for native in (True, False):
+        M._NATIVE_BLOCK = native
+        try:
+            with torch.no_grad():
+                out[native] = model({'octree': octree})['global']
+        finally:
+            M._NATIVE_BLOCK = True
+    assert torch.equal(out[True], out[False])
+
+
 def test_large_oxford_batch_completes_and_is_deterministic():
     """Regression for the stream-K dead-lock ("hipBLASLt schedule"): Oxford cfg, 48 clouds --
     every pyramid depth is chip-filling (92k-194k rows).  With stream-K GEMMs on three streams this configuration
