@@ -153,3 +153,19 @@ def test_synthetic_generators_are_pinned():
     assert syn.synthetic_tensor('x.norm1.weight', (128,)).mean() > 0.9
     f = syn.forest_cloud(5, 6000)
     assert f.shape == (6000, 3) and np.all(np.abs(f) < 1)
+
+
+def test_split_ranges_matches_the_python_loop():
+    """Row tiles / pair chunks of the tap kernels (octree._split_ranges): consecutive ranges cut into pieces of <= step, in
+    order, never across a range boundary -- against the obvious double loop, with empty ranges and exact multiples."""
+    from hotformerloc_amd.octree import _split_ranges
+    rng = np.random.default_rng(3)
+    for step in (128, 2048):
+        for _ in range(20):
+            cnt = rng.integers(0, 5 * step, size=rng.integers(1, 30))
+            cnt[rng.integers(0, cnt.size)] = 0
+            cnt[rng.integers(0, cnt.size)] = 2 * step
+            e = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            rid, first, length = _split_ranges(e, step)
+            want = [(k, a, min(step, e[k + 1] - a)) for k in range(cnt.size) for a in range(e[k], e[k + 1], step)]
+            assert [(int(a), int(b), int(c)) for a, b, c in zip(rid, first, length)] == [tuple(int(v) for v in w) for w in want]
