@@ -8,26 +8,34 @@ GPU over RCCL.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by
 
 Workload (BASELINE.json configs[1]): batch of 32 synthetic 4096-point clouds per GPU,
 Wild-Places cfg (octree depth 7, cylindrical, K=48), forward only, eval mode, random-init
-style closed-form weights; the batch octree is resident on the device with neighbour tables
-built when the timed region starts (the reference's model boundary: `misc/torch_utils.py:47-51`
-happens before `model(batch)`).  A step = `model(batch)['global']` on every rank followed, for
-N > 1, by the RCCL all-gather of the (B_local,256) descriptors.  Weak scaling: each rank
-encodes its own contiguous slice of the global batch.
+style closed-form weights.  The timed step is what the reference's `model(batch)` is
+(`models/hotformerloc.py:33-59`): the batch octree is on the device with its 27-neighbour tables
+built (`misc/torch_utils.py:47-51` happens before `model(batch)`), and EVERYTHING the reference
+derives from it inside the forward is derived inside the timed step here too -- the window / relay-token
+plan (`OctreeT.__init__` + `build_t`, `models/hotformerloc_backbone.py:712-716`), the live-tap lists and
+row-tile tables of the octree convolutions (ocnn's `octree2col` per call): `Octree.drop_forward_caches()`
+runs at the top of every step.  For N > 1 the step ends with the RCCL all-gather of the (B_local,256)
+descriptors.  Weak scaling: each rank encodes its own contiguous slice of the global batch.
 
-What one default run times (all with the same W-warm-up / K-step / barrier protocol, on rank 0 at N = 1):
-  value          Linear layers as 3-term split-bf16 products with fp32 accumulation on the hand-written MFMA GEMM
-                 (`--gemm x3`; `--gemm bf16x3` = the same arithmetic through hipBLASLt)
-  fp32_linear    the same forward with every Linear as an fp32 GEMM -- the reference's arithmetic
-  e2e            a FRESH octree per step: device build + neighbour tables + tap lists + window plan + forward
-                 (SURVEY 8d "report separately the end-to-end rate including device octree build")
+What one default run times (same W-warm-up / K-step / barrier protocol for every leg, rank 0, N = 1):
+  value          boundary-faithful step, Linear layers as 3-term split-bf16 products with fp32 accumulation on the
+                 hand-written MFMA GEMM (`--gemm x3`), window attention on fp16 (hi, lo) pairs
+  resident_plan  the same step with the plan / tap tables kept on the octree between steps (what a caller that
+                 re-submits one octree sees; round 2's headline)
+  fp32_linear    the boundary-faithful step with every Linear as an fp32 GEMM and fp32-MFMA attention -- the
+                 reference's arithmetic
+  e2e            a FRESH octree per step from device-resident points: device build + neighbour tables + forward
+  train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process
 and then, outside any timed value: the `roofline` legs (HIP events per launch) and the `cpu_baseline`
-(the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol).
+(the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol) whose descriptors are also the
+`parity` reference of the timed workload's GPU descriptors (BASELINE metric: "descriptor L2 vs ref").
 """
 
 import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -40,6 +48,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak (v_mfma_f32_16x16x32_f16)
 ATTN = 'hfl_window_attention_fwd'
 
 
@@ -61,6 +70,8 @@ def parse():
                     help="Linear layers of the headline `value`: 'x3' = hand-written split-bf16 MFMA GEMM with fused "
                          "bias/GELU/residual epilogues (default); 'bf16x3' = the same three-term split as one hipBLASLt bf16 "
                          "GEMM over K-concatenated operands; 'fp32' = hipBLASLt fp32 GEMMs")
+    ap.add_argument('--resident-plan', action='store_true',
+                    help='headline step keeps the window plan / tap tables cached on the octree (round-2 behaviour)')
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
     ap.add_argument('--attn-variant', type=int, default=0, help='A/B: window attention kernel variant (0 = default)')
     ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
@@ -70,7 +81,10 @@ def parse():
     ap.add_argument('--no-train-x3', action='store_true', help='A/B with --train: Linear layers as fp32 torch GEMMs')
     ap.add_argument('--x3-nt', type=int, default=None, help='A/B: non-temporal store bits of the hand-written GEMM (0..3)')
     ap.add_argument('--no-collective', action='store_true', help='A/B: skip the descriptor all-gather (N > 1 diagnostics)')
-    ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no fp32 / e2e / roofline legs)')
+    ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no other legs)')
+    ap.add_argument('--no-train-leg', action='store_true', help='skip the config-3 child process')
+    ap.add_argument('--train-leg-steps', type=int, default=5)
+    ap.add_argument('--train-leg-warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=16,
                     help='torch threads of the CPU baseline (8-16 is the optimum measured on the 2x64-core host; more threads are slower)')
@@ -82,7 +96,8 @@ def parse():
 def cpu_baseline(params, depth, args):
     """Oracle forward (port of the reference, torch CPU fp32), BASELINE.md section 3: octree prebuilt with neighbour
     tables (the model boundary), eval / inference mode, 2 warm-ups + 5 timed runs, median, at B=1 (BASELINE config 1)
-    and at the GPU workload's batch (B=32, the first clouds of the same workload).  Bounded by --cpu-budget-s."""
+    and at the GPU workload's batch (B=32, the first clouds of the same workload).  Bounded by --cpu-budget-s.
+    Returns (record, descriptors of the B = args.batch run as numpy) -- the latter is the parity reference."""
     import torch
     from hotformerloc_amd import synthetic as syn
     from oracle import hotformer_ref
@@ -92,6 +107,7 @@ def cpu_baseline(params, depth, args):
     sd = synthetic_state_dict(params, 'init')
     t_start = time.perf_counter()
     out = {}
+    want = None
     for b in (1, args.batch):
         clouds = syn.make_clouds(2, b, args.points, params.coordinates)
         t0 = time.perf_counter()
@@ -103,11 +119,13 @@ def cpu_baseline(params, depth, args):
                 break
             t0 = time.perf_counter()
             with torch.inference_mode():
-                hotformer_ref.forward(sd, params, octree)
+                y = hotformer_ref.forward(sd, params, octree)
             dt = time.perf_counter() - t0
             log('cpu baseline: B=%d run %d %.2f s%s' % (b, i, dt, ' (warm-up)' if i < 2 else ''))
             if i >= 2:
                 runs.append(dt)
+        if b == args.batch:
+            want = y.numpy().copy()
         med = statistics.median(runs)
         out[b] = {'clouds_per_s': round(b / med, 4), 'median_s': round(med, 3), 'timed_runs': len(runs),
                   'warmups': 2, 'octree_build_s': round(t_build, 3)}
@@ -118,7 +136,39 @@ def cpu_baseline(params, depth, args):
                       'threads (host has %d logical CPUs)'
                       % (args.config, args.batch, args.points, big['timed_runs'], big['median_s'],
                          torch.get_num_threads(), os.cpu_count() or 1),
-            'b1': out[1], 'b%d' % args.batch: big}
+            'b1': out[1], 'b%d' % args.batch: big}, want
+
+
+def parity_record(got, want):
+    """Relative L2 distance per cloud between GPU descriptors and the oracle's (north_star: <= 1e-3)."""
+    import numpy as np
+    rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    return {'max_rel_l2': float('%.3e' % rel.max()), 'mean_rel_l2': float('%.3e' % rel.mean()),
+            'clouds': int(got.shape[0]), 'bar': 1e-3, 'ok': bool(np.isfinite(got).all() and rel.max() <= 1e-3)}
+
+
+def train_leg(args):
+    """BASELINE config 3 (CS-Wild-Places cfg, B = 64, 4096..32768 points per cloud, forward + backward) timed by this same
+    script in a CHILD process (its own hipBLASLt schedule, its own allocator), same warm-up / step / barrier protocol."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', 'cs-wild-places', '--train', '--no-extras',
+           '--no-cpu-baseline', '--steps', str(args.train_leg_steps), '--warmup', str(args.train_leg_warmup)]
+    env = dict(os.environ)
+    env.pop('TENSILE_STREAMK_DATA_PARALLEL', None)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout'}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'error': 'rc %d' % r.returncode, 'stderr_tail': r.stderr[-400:]}
+    j = json.loads(lines[-1])
+    return {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'],
+            'warmup': j['warmup'], 'workload': j['config']['workload'], 'dtype': j['dtype'],
+            'peak_memory_GiB': j.get('peak_memory_GiB'), 'wall_s': round(time.perf_counter() - t0, 1),
+            'what': 'child process: python bench.py --config cs-wild-places --train (BASELINE config 3)'}
 
 
 _T0 = time.perf_counter()
@@ -171,13 +221,7 @@ def main():
     log('model ready')
 
     # this rank's contiguous slice of the global batch (ordered)
-    if args.points_max:
-        clouds = []
-        for i in range(rank * args.batch, (rank + 1) * args.batch):        # forest / unit-ball mix, n ~ U{points..max}
-            clouds += syn.make_clouds(3, 1, args.points, params.coordinates, kind='forest' if i % 2 == 0 else 'ball',
-                                      n_points_max=args.points_max, first_index=i)
-    else:
-        clouds = syn.make_clouds(2, args.batch, args.points, params.coordinates, first_index=rank * args.batch)
+    clouds = bench_clouds(syn, params, args, rank)
     octree = build_batch_octree(clouds, depth, 2, dev, construct_neigh=True)
     batch = {'octree': octree}
     torch.cuda.synchronize()
@@ -206,8 +250,12 @@ def main():
         optim = torch.optim.AdamW(model.parameters(), lr=1e-5)
 
     collective = use_dist and not args.no_collective and not args.train
+    state = {'fresh_plan': not args.resident_plan}
 
     def step():
+        # the reference boundary: octree + 27-neighbour tables resident, everything else derived inside model(batch)
+        if state['fresh_plan']:
+            octree.drop_forward_caches()
         if args.train and args.multistaged:
             multistaged_training_step(model, [batch], pos_mask, neg_mask, loss_fn, optim, n_total=n_tot)
             return torch.ones(1, device=dev)
@@ -227,7 +275,9 @@ def main():
         fresh = build_batch_octree(dev_clouds, depth, 2, dev, construct_neigh=True)
         return model({'octree': fresh})['global']
 
-    def timed(fn, steps, warmup, timer=None):
+    last = {}
+
+    def timed(fn, steps, warmup, tag=None):
         """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; seconds (this rank)."""
         for i in range(warmup):
             fn()
@@ -235,8 +285,6 @@ def main():
         if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
-        if timer is not None:
-            timer.__enter__()
         t0 = time.perf_counter()
         for _ in range(steps):
             y = fn()
@@ -244,34 +292,52 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if timer is not None:
-            timer.__exit__(None, None, None)
         assert torch.isfinite(y).all()
+        if tag is not None:
+            last[tag] = y.detach().float().cpu().numpy()
         return dt
 
+    def leg(dt):
+        return {'value': round(args.batch * args.steps / dt, 2), 'unit': 'clouds/s',
+                'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup}
+
     extras = world == 1 and not args.train and not args.no_extras
-    fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = None
+    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = None
     with (torch.enable_grad() if args.train else torch.inference_mode()):
-        # ---- the headline: W warm-ups, K timed steps.  Inside the timed region only the roofline kernel carries
-        # HIP events (2 per launch, 34 launches per step); everything else runs un-instrumented.
-        timer = ops.KernelTimer(only=[ATTN]) if not args.train else None
-        elapsed = timed(step, args.steps, args.warmup, timer)
-        kern = timer.summary() if timer is not None else {}
+        # ---- the headline: W warm-ups, K timed steps, nothing instrumented inside the timed region
+        elapsed = timed(step, args.steps, args.warmup, tag='value')
         log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
         if extras:
+            state['fresh_plan'] = not state['fresh_plan']
+            dt = timed(step, args.steps, args.warmup)
+            state['fresh_plan'] = not state['fresh_plan']
+            resident_line = leg(dt)
+            resident_line['what'] = ('window plan, tap lists and tile tables %s between steps'
+                                     % ('rebuilt' if args.resident_plan else 'kept on the octree'))
+            log('resident-plan leg: %.3f s' % dt)
             other = 'fp32' if args.gemm != 'fp32' else 'x3'
             set_gemm_mode(other)
-            dt = timed(step, args.steps, args.warmup)
-            set_gemm_mode(args.gemm)
-            fp32_line = {'gemm': other, 'value': round(args.batch * args.steps / dt, 2), 'unit': 'clouds/s',
-                         'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup}
+            dt = timed(step, args.steps, args.warmup, tag='other')
+            fp32_line = leg(dt)
+            fp32_line['gemm'] = other
             log('%s Linear leg: %.3f s' % (other, dt))
+            if other == 'fp32':
+                # roofline of the fp32-MFMA window kernel this leg runs (v4), pyramid depths serialised
+                set_pyramid_streams(False)
+                step()
+                torch.cuda.synchronize()
+                with ops.KernelTimer(only=[ATTN]) as t32:
+                    for _ in range(args.steps):
+                        step()
+                    torch.cuda.synchronize()
+                kern_iso32 = t32.summary()
+                set_pyramid_streams(not args.no_streams)
+            set_gemm_mode(args.gemm)
             dt = timed(step_e2e, args.steps, args.warmup)
-            e2e_line = {'value': round(args.batch * args.steps / dt, 2), 'unit': 'clouds/s',
-                        'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
-                        'what': 'fresh octree every step from device-resident points: HIP octree build + merge + '
+            e2e_line = leg(dt)
+            e2e_line['what'] = ('fresh octree every step from device-resident points: HIP octree build + merge + '
                                 'neighbour tables + live-tap lists (one device->host read of counts each for build and '
-                                'taps) + window plan + forward'}
+                                'taps) + window plan + forward')
             log('e2e leg: %.3f s' % dt)
             # ---- roofline legs (not part of any value): every hand-written kernel instrumented, streams as in the
             # timed region, then once more with the pyramid depths on ONE stream.  With three streams sharing the GPU
@@ -294,6 +360,25 @@ def main():
                 iso_sizes = t_iso.by_size(ATTN)
                 set_pyramid_streams(True)
 
+    # ---- per-rank times (N > 1 diagnostics) and the collective alone
+    per_rank = None
+    allgather_ms = None
+    if use_dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [round(float(x.item()) / args.steps * 1e3, 3) for x in allt]
+        if collective:
+            y = torch.zeros((args.batch, params.output_dim), device=dev)
+            for _ in range(3):
+                all_gather_descriptors(y, args.batch * world, force=True)
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                all_gather_descriptors(y, args.batch * world, force=True)
+            torch.cuda.synchronize()
+            allgather_ms = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -301,56 +386,22 @@ def main():
 
     if rank == 0:
         total_clouds = args.batch * world * args.steps
-        roof = None
-        rec_t = kern.get(ATTN)
-        rec = (kern_iso or {}).get(ATTN) or rec_t
-        if rec:
-            n, ms, nbytes, flops, moved = rec
-            gbs = nbytes / (ms * 1e-3) / 1e9
-            traffic, traffic_src = None, None
-            for cand in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-                pmc = os.path.join(ROOT, 'profiles', cand)
-                if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
-                    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-                    # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
-                    j = json.load(open(pmc))
-                    hit = [v for k, v in sorted(j.items(), key=lambda kv: -kv[1].get('launches', 0) if isinstance(kv[1], dict) else 0)
-                           if k.startswith('window_attn_kernel') and isinstance(v, dict)]     # the kernel the step runs most
-                    if hit:
-                        traffic, traffic_src = hit[0]['hbm_bytes_per_launch'], 'profiles/' + cand
-                        break
-            roof = {'kernel': ATTN, 'bound': 'hbm',
-                    'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                    'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
-                    'algorithmic_bytes_per_launch': int(nbytes / n),
-                    'algorithmic_bytes': 'SURVEY 8(d): 16 B x (row, channel) = read q,k,v + write out in f32',
-                    'moved_bytes_per_launch': int(moved / n),
-                    'mfma_tflops': round(flops / (ms * 1e-3) / 1e12, 2),
-                    'mfma_frac': round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                    'timing': ('HIP events per launch over %d steps, pyramid streams serialised (re-run right '
-                               'after the timed region; agrees with rocprofv3 --kernel-trace)' % args.steps) if kern_iso else
-                              'HIP events per launch inside the timed region'}
-            if iso_sizes:
-                # the step's launches by size: one per pyramid depth and block (34 here); the depth-2 / depth-3 launches
-                # hold 2 % / 13 % of the bytes and are latency-bound (a few windows per CU)
-                roof['by_launch_size'] = [{'algorithmic_bytes_per_launch': b, 'launches': c,
-                                           'avg_launch_us': round(ms_ * 1e3 / c, 2),
-                                           'frac': round(b * c / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                          for b, c, ms_ in iso_sizes]
-            if rec_t:
-                nt_, mst, bt, _, _ = rec_t
-                roof['timed_region'] = {'frac': round(bt / (mst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        'avg_launch_us': round(mst * 1e3 / nt_, 2), 'launches': nt_,
-                                        'note': 'events inside the timed region; three HIP streams overlap, so a launch '
-                                                'shares the CUs with its neighbours'}
+        roof = roofline_block(kern_iso or kern_all, kern_all, iso_sizes, args,
+                              'hand-written fp16 (hi, lo) MFMA window kernel (v5)' if args.gemm != 'fp32'
+                              else 'fp32-MFMA window kernel (v4)', MFMA_F32_PEAK_TFLOPS, bool(kern_iso))
+        roof32 = roofline_block(kern_iso32, None, None, args, 'fp32-MFMA window kernel (v4), fp32_linear leg',
+                                MFMA_F32_PEAK_TFLOPS, True) if kern_iso32 else None
         others = {}
         for name, (kn, kms, kb, kf, kmv) in (kern_all or {}).items():
             others[name] = {'launches_per_step': kn // args.steps,
                             'ms_per_step': round(kms / args.steps, 4),
                             'GBps': round(kb / (kms * 1e-3) / 1e9, 1) if kms > 0 else None}
-        split_txt = 'f32 (Linear products as 3-term bf16 split, f32 accumulate; fp32_linear = all-f32 rate)'
+        split_txt = ('f32 storage and accumulation; Linear products as 3-term bf16 (hi, lo) split (16 significant bits per '
+                     'operand); window-attention QK^T / PV on fp16 (hi, lo) pairs (22 significant bits), softmax in f32; '
+                     'fp32_linear leg = f32 GEMMs + f32-MFMA attention (the reference\'s arithmetic)')
         mode_txt = {'fp32': 'f32', 'bf16x3': split_txt, 'x3': split_txt}
+        plan_txt = ('window plan + tap tables cached on the octree' if args.resident_plan else
+                    'window plan + tap tables rebuilt inside every step (reference boundary)')
         line = {
             'metric': 'point-clouds/sec (4096 pts, Wild-Places cfg)' if (args.config == 'wild-places' and not args.points_max
                                                                          and args.points == 4096)
@@ -362,17 +413,26 @@ def main():
             'dtype': mode_txt[args.gemm],
             'data': 'synthetic',
             'config': {'workload': '%s cfg, batch=%d clouds/GPU x %s pts, octree depth %d, %s, '
-                                   'octree+neighbours resident'
+                                   'octree+neighbours resident, %s'
                                    % (args.config, args.batch,
                                       '%d..%d (forest/ball mix)' % (args.points, args.points_max) if args.points_max
                                       else '%d' % args.points, depth,
                                       ('multi-staged training step (stage 1 + TruncatedSmoothAP + stage 3 + grad all-reduce + AdamW)'
-                                       if args.multistaged else ('forward+backward, stochastic depth %s' % ('off' if args.no_drop_path else 'on (drop_path = %.2f, as the config trains)' % params.drop_path))) if args.train else 'forward-only'),
+                                       if args.multistaged else ('forward+backward, stochastic depth %s' % ('off' if args.no_drop_path else 'on (drop_path = %.2f, as the config trains)' % params.drop_path))) if args.train else 'forward-only',
+                                      plan_txt),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
                        'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
                                      ('rccl all_gather at world size 1' if collective else 'none')},
             'roofline': roof,
         }
+        if roof32:
+            line['roofline_fp32'] = roof32
+        if per_rank is not None:
+            line['per_rank_ms_per_step'] = {'min': min(per_rank), 'max': max(per_rank), 'ranks': per_rank}
+        if allgather_ms is not None:
+            line['allgather_ms'] = allgather_ms
+        if resident_line:
+            line['boundary_plan' if args.resident_plan else 'resident_plan'] = resident_line
         if fp32_line:
             line['fp32_linear' if fp32_line['gemm'] == 'fp32' else 'split_linear'] = fp32_line
         if e2e_line:
@@ -381,12 +441,91 @@ def main():
             line['kernels'] = others
         if args.train:
             line['peak_memory_GiB'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        if extras and not args.no_train_leg and args.config == 'wild-places':
+            log('config-3 training leg (child process) ...')
+            line['train_cs'] = train_leg(args)
+            log('train leg:', line['train_cs'])
         if world == 1 and not args.no_cpu_baseline and not args.train:
-            line['cpu_baseline'] = cpu_baseline(params, depth, args)
+            line['cpu_baseline'], want = cpu_baseline(params, depth, args)
             line['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)
+            # descriptors of the LAST timed step of each leg against the oracle's on the same clouds and weights
+            par = {'reference': 'oracle/hotformer_ref.py forward (pinned to the reference model on tests/golden/model_*.npz), '
+                                'same %d clouds, same closed-form weights' % args.batch,
+                   args.gemm: parity_record(last['value'], want)}
+            if 'other' in last:
+                par[fp32_line['gemm']] = parity_record(last['other'], want)
+            line['parity'] = par
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def bench_clouds(syn, params, args, rank):
+    """Rank `rank`'s contiguous slice [rank * B, (rank + 1) * B) of the global synthetic batch."""
+    if args.points_max:
+        clouds = []
+        for i in range(rank * args.batch, (rank + 1) * args.batch):        # forest / unit-ball mix, n ~ U{points..max}
+            clouds += syn.make_clouds(3, 1, args.points, params.coordinates, kind='forest' if i % 2 == 0 else 'ball',
+                                      n_points_max=args.points_max, first_index=i)
+        return clouds
+    return syn.make_clouds(2, args.batch, args.points, params.coordinates, first_index=rank * args.batch)
+
+
+def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32, serialised):
+    rec = (kern or {}).get(ATTN)
+    if not rec:
+        return None
+    n, ms, nbytes, flops, moved = rec
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    for cand in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        pmc = os.path.join(ROOT, 'profiles', cand)
+        if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
+            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            # (tools/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
+            j = json.load(open(pmc))
+            hit = [v for k, v in sorted(j.items(), key=lambda kv: -kv[1].get('launches', 0) if isinstance(kv[1], dict) else 0)
+                   if k.startswith('window_attn_kernel') and isinstance(v, dict)]     # the kernel the step runs most
+            if hit:
+                traffic, traffic_src = hit[0]['hbm_bytes_per_launch'], 'profiles/' + cand
+                break
+    useful_tf = flops / (ms * 1e-3) / 1e12
+    f16 = 'fp16' in kernel_txt
+    roof = {'kernel': ATTN, 'kernel_variant': kernel_txt, 'bound': 'hbm',
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 2),
+            'algorithmic_bytes_per_launch': int(nbytes / n),
+            'algorithmic_bytes': 'SURVEY 8(d): 16 B x (row, channel) = read q,k,v + write out in f32',
+            'moved_bytes_per_launch': int(moved / n),
+            # useful = 4 L^2 C flop per real window (QK^T + PV at head dim 16).  The fp16 kernel issues 2 K=32 MFMAs per
+            # 16x16 score tile (all four hi/lo cross terms of a 16-dim product: 4x the useful flop) and 3 per PV tile
+            # (3x): 3.5x overall, on the fp16 engine.  The fp32 kernel issues exactly the useful flop on the fp32 engine.
+            'mfma': {'useful_tflops': round(useful_tf, 2),
+                     'issued_tflops': round(useful_tf * (3.5 if f16 else 1.0), 2),
+                     'mfma_peak_used': MFMA_F16_PEAK_TFLOPS if f16 else mfma_peak_f32,
+                     'engine': 'v_mfma_f32_16x16x32_f16' if f16 else 'v_mfma_f32_16x16x4_f32',
+                     'frac_issued_of_peak_used': round(useful_tf * (3.5 if f16 else 1.0) /
+                                                       (MFMA_F16_PEAK_TFLOPS if f16 else mfma_peak_f32), 4),
+                     'useful_over_f32_peak': round(useful_tf / MFMA_F32_PEAK_TFLOPS, 4)},
+            'timing': ('HIP events per launch over %d steps, pyramid streams serialised (re-run right '
+                       'after the timed region, never inside it; agrees with rocprofv3 --kernel-trace)' % args.steps)
+                      if serialised else 'HIP events per launch, re-run after the timed region with the streams of the step'}
+    if sizes:
+        # the step's launches by size: one per pyramid depth and block (34 here); the depth-2 / depth-3 launches
+        # hold 2 % / 13 % of the bytes and are latency-bound (a few windows per CU)
+        roof['by_launch_size'] = [{'algorithmic_bytes_per_launch': b, 'launches': c,
+                                   'avg_launch_us': round(ms_ * 1e3 / c, 2),
+                                   'frac': round(b * c / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                  for b, c, ms_ in sizes]
+    rec_o = (kern_overlapped or {}).get(ATTN) if kern_overlapped is not kern else None
+    if rec_o:
+        nt_, mst, bt, _, _ = rec_o
+        roof['overlapped_streams'] = {'frac': round(bt / (mst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      'avg_launch_us': round(mst * 1e3 / nt_, 2), 'launches': nt_,
+                                      'note': 'same steps with the three pyramid streams of the timed step (events after the '
+                                              'timed region): a launch shares the CUs with its neighbours'}
+    return roof
 
 
 if __name__ == '__main__':

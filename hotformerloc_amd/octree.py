@@ -177,10 +177,21 @@ class Octree:
                 self.neighs[d] = ops.octree_neigh(self.neighs[d - 1] if d > self.full_depth else None,
                                                   self.nidx[d], self.children[d], self.nkeys[d],
                                                   d, self.full_depth)
-        if fresh and self.device.type == 'cuda':
+        if (fresh or '_sparse_taps' not in self.__dict__) and self.device.type == 'cuda':
             lo = max(self.full_depth + 1, 3)
             keys = [(d, '333', 1) for d in range(lo, self.depth)] + [(d, '222', 2) for d in range(lo, self.depth + 1)]
             self._build_tap_lists(keys)
+
+    _FORWARD_CACHES = ('_window_plans', '_sparse_taps', '_tap_tiles', '_sparse_taps_bwd')
+
+    def drop_forward_caches(self):
+        """Forget everything `model(batch)` derives from the octree and keeps on it between calls: the window / relay-token
+        plans (the reference rebuilds `OctreeT` in every forward, `models/hotformerloc_backbone.py:712-716`), the live-tap
+        lists and the row-tile tables of the octree convolutions (ocnn's `octree2col` gathers per call).  What stays is the
+        ocnn state the reference's `to_device` hands to the model (`misc/torch_utils.py:47-51`): keys, children and the
+        27-neighbour tables.  `bench.py` calls this at the top of every timed step (the reference's model boundary)."""
+        for name in self._FORWARD_CACHES:
+            self.__dict__.pop(name, None)
 
     def _need_built(self):
         if not self._built:

@@ -341,3 +341,27 @@ def test_grad_checkpoint_recomputes_the_same_gradients():
             assert torch.equal(g, h), (k, (g - h).abs().max().item())
     print('peak memory: plain %.2f GiB, checkpointed %.2f GiB' % (res[False][2] / 2 ** 30, res[True][2] / 2 ** 30))
     assert res[True][2] < res[False][2]
+
+
+def test_drop_forward_caches_rebuilds_the_same_plan():
+    """`Octree.drop_forward_caches()` (the reference boundary of bench.py: OctreeT and the octree2col tables are rebuilt in
+    every forward, `models/hotformerloc_backbone.py:712-716`) leaves keys / children / neighbour tables alone and the next
+    forward derives everything again: bitwise the same descriptors, and new plan objects."""
+    params, depth = load_config('wild-places')
+    model = _device_model(params)
+    octree = build_batch_octree(syn.make_clouds(17, 3, 3000, params.coordinates), depth, 2, 'cuda')
+    with torch.inference_mode():
+        y1 = model({'octree': octree})['global']
+        plans = dict(octree._window_plans)
+        taps = dict(octree._sparse_taps)
+        assert plans and taps
+        neighs = [None if t is None else t.data_ptr() for t in octree.neighs]
+        octree.drop_forward_caches()
+        for name in Octree._FORWARD_CACHES:
+            assert name not in octree.__dict__
+        assert [None if t is None else t.data_ptr() for t in octree.neighs] == neighs
+        y2 = model({'octree': octree})['global']
+    assert torch.equal(y1, y2)
+    for k, p in octree._window_plans.items():
+        assert p is not plans[k]
+    assert set(octree._sparse_taps) >= set(taps)
