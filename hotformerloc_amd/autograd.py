@@ -379,6 +379,14 @@ def linear_x3(x, weight, bias=None):
     return LinearX3Fn.apply(x, weight, bias)
 
 
+def _wgrad(dys, xs, need_w: bool, need_b: bool):
+    """(dW, db) through `hfl_wgrad_x3`, or (None, None) without a launch when neither is wanted (frozen layers)."""
+    if not (need_w or need_b):
+        return None, None
+    dw, db = ops.wgrad_x3(dys, xs, with_bias=need_b)
+    return (dw if need_w else None), db
+
+
 class MlpX3Fn(torch.autograd.Function):
     """fc2(gelu(fc1(h))) of a transformer block (models/layers/octformer_layers.py:53-59) with no element-wise pass of its
     own: fc1 writes split2(gelu(.)) and the pre-activation in one launch, the backward's dx GEMM of fc2 multiplies by
@@ -398,9 +406,10 @@ class MlpX3Fn(torch.autograd.Function):
         hs, gs, pre, w1, w2 = ctx.saved_tensors
         dys = ops.split2(dout.reshape(-1, w2.shape[0]).contiguous())
         dps = ops.linear_x3_gelu_bwd(dys, _w2_cached(w2, True), pre)
-        dw2, db2 = ops.wgrad_x3(dys, gs, with_bias=True)
-        dh = ops.linear_x3(dps, _w2_cached(w1, True)).view(ctx.shape) if ctx.needs_input_grad[0] else None
-        dw1, db1 = ops.wgrad_x3(dps, hs, with_bias=True)
+        need = ctx.needs_input_grad
+        dw2, db2 = _wgrad(dys, gs, need[3], need[4])
+        dh = ops.linear_x3(dps, _w2_cached(w1, True)).view(ctx.shape) if need[0] else None
+        dw1, db1 = _wgrad(dps, hs, need[1], need[2])
         return dh, dw1, db1, dw2, db2
 
 
@@ -426,11 +435,14 @@ class LnMlpResidualX3Fn(torch.autograd.Function):
         dout2 = dout.reshape(-1, w2.shape[0]).contiguous()
         dys = ops.split2(dout2, row_scale if ctx.scaled else None)
         dps = ops.linear_x3_gelu_bwd(dys, _w2_cached(w2, True), pre)
-        dw2, db2 = ops.wgrad_x3(dys, gs, with_bias=True)
+        need = ctx.needs_input_grad                    # (x, gamma, beta, eps, w1, b1, w2, b2, row_scale)
+        dw2, db2 = _wgrad(dys, gs, need[6], need[7])
+        dw1, db1 = _wgrad(dps, hs, need[4], need[5])
+        if not (need[0] or need[1] or need[2]):
+            return None, None, None, None, dw1, db1, dw2, db2, None
         dh = ops.linear_x3(dps, _w2_cached(w1, True))
-        dw1, db1 = ops.wgrad_x3(dps, hs, with_bias=True)
         dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)
-        return dx.view(ctx.shape), dg, dbeta, None, dw1, db1, dw2, db2, None
+        return (dx.view(ctx.shape), dg if need[1] else None, dbeta if need[2] else None, None, dw1, db1, dw2, db2, None)
 
 
 def ln_mlp_residual_x3(x, gamma, beta, eps, w1, b1, w2, b2, row_scale=None):
@@ -462,8 +474,9 @@ class LnAttnResidualX3Fn(torch.autograd.Function):
         cfg = ctx.cfg
         dout2 = dout.reshape(-1, wp.shape[0]).contiguous()
         dys = ops.split2(dout2, row_scale if ctx.scaled else None)
+        need = ctx.needs_input_grad    # (x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp, row_scale)
         do = ops.linear_x3(dys, _w2_cached(wp, True))
-        dwp, dbp = ops.wgrad_x3(dys, os_, with_bias=True)
+        dwp, dbp = _wgrad(dys, os_, need[9], need[10])
         dqkv = torch.empty_like(qkv)
         dtable = torch.zeros_like(table) if ctx.has_table else None
         d = _desc(cfg['n_tokens'], cfg['n_windows'], cfg['patch_size'], cfg['dilation'], cfg['n_relay'],
@@ -474,9 +487,10 @@ class LnAttnResidualX3Fn(torch.autograd.Function):
             'hfl_window_attention_bwd')
         dqs = ops.split2(dqkv)
         dh = ops.linear_x3(dqs, _w2_cached(wqkv, True))
-        dwqkv, dbqkv = ops.wgrad_x3(dqs, hs, with_bias=ctx.has_qkv_bias)
+        dwqkv, dbqkv = _wgrad(dqs, hs, need[4], ctx.has_qkv_bias and need[5])
         dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)
-        return dx.view(ctx.shape), dg, dbeta, None, dwqkv, dbqkv, dtable, None, None, dwp, dbp, None
+        return (dx.view(ctx.shape), dg if need[1] else None, dbeta if need[2] else None, None, dwqkv, dbqkv,
+                dtable if need[6] else None, None, None, dwp, dbp, None)
 
 
 def ln_attn_residual_x3(x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp, row_scale=None):

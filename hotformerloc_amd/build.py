@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libhotformerloc_hip.so'
 ARCH = 'gfx950'
-SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'linear.hip', 'gemm_x3.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
+SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'linear.hip', 'gemm_x3.hip', 'mlp_fused.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 # hipBLASLt for hfl_gemm_bf16 (the ROCm copy that matches the headers; rpath so the loader finds it)
@@ -24,7 +24,10 @@ ROCM = os.environ.get('ROCM_PATH', '/opt/rocm')
 LINK_FLAGS = ['-L' + os.path.join(ROCM, 'lib'), '-lhipblaslt', '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]
 # per-file extras.  attention.hip: MFMA results feed VALU softmax code directly, so keep the MFMA
 # destination in arch VGPRs (the default heuristic parks it in AGPRs and pays a v_accvgpr_read per score)
-EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
+               # mlp_fused.hip: element-wise math runs BETWEEN MFMAs there; packed f32 VALU (what SLP vectorisation of adjacent
+               # scalar ops produces) stalls the matrix pipe, plain VALU does not
+               'mlp_fused.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc() -> str:
@@ -46,7 +49,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'hfl_common.h'),
+    headers = [os.path.join(CSRC, 'hfl_common.h'), os.path.join(CSRC, 'x3_math.h'),
                os.path.join(HERE, '..', 'include', 'hotformerloc_hip.h')]
     jobs = []
     for src in SOURCES:

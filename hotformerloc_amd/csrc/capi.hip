@@ -7,9 +7,9 @@ int hfl_version(void) { return 100; }   // 1.00
 
 const char* hfl_arch(void) { return "gfx950"; }
 
-// One transformer block of the inference path as ONE call: the nine launches a block makes (CPE, relay-row copy, LN1 -> split2,
-// qkv GEMM into the fp16 attention operand, window attention, proj GEMM + residual, LN2 -> split2, fc1 GEMM + GELU, fc2 GEMM +
-// residual) issued back to back from native code.  Nothing new runs on the GPU; what goes away is eight Python launch wrappers
+// One transformer block of the inference path as ONE call: the launches a block makes (CPE, relay-row copy, LN1 -> split2,
+// qkv GEMM into the fp16 attention operand, window attention, proj GEMM + residual, then either LN2 -> split2, fc1 GEMM + GELU,
+// fc2 GEMM + residual or the fused MLP launch) issued back to back from native code.  Nothing new runs on the GPU; what goes away is eight Python launch wrappers
 // per block (~22 us of host time each: the fresh-batch path is host-bound).  See include/hotformerloc_hip.h.
 int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, const hfl_window_attn_desc* desc,
                          hfl_stream_t stream) {
@@ -46,6 +46,9 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
+  if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
+    return hfl_ln_mlp_fused(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
+                            stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);

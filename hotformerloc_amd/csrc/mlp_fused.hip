@@ -1,0 +1,480 @@
+// The pre-norm MLP branch of a transformer block as ONE kernel on the bf16 matrix cores of gfx950:
+//
+//     out (M, C) = x + fc2( gelu( fc1( LayerNorm(x) ) ) )        fc1: C -> 4C, fc2: 4C -> C
+//
+// Replaces norm2 -> mlp.fc1 -> GELU -> mlp.fc2 -> residual add of every transformer block of the reference
+// (models/octformer_backbone.py:275-278, models/hotformerloc_backbone.py:213-216, models/layers/octformer_layers.py:38-59),
+// which round 2 ran as three launches (hfl_layer_norm_split2, hfl_linear_x3 with the GELU epilogue, hfl_linear_x3 with the
+// residual epilogue): there the M x 4C hidden activation crossed HBM twice (8 of the 13 M*C*4-byte units those three
+// launches move); here it never leaves the register file.
+//
+// Arithmetic: identical to csrc/gemm_x3.hip -- every fp32 operand split into bf16 (hi, lo), products x_lo w_hi + x_hi w_lo +
+// x_hi w_hi with fp32 accumulation (v_mfma_f32_16x16x32_bf16), exact-erf GELU in fp32, LayerNorm with two-pass statistics.
+//
+// Dataflow (C = 256; C = 128 in brackets).  A 512-lane workgroup owns up to 128 [256] rows per pass; wave w owns NT = 1 [2]
+// tiles of 16 rows and keeps, for the whole pass,
+//   * LayerNorm(x) of its rows as MFMA B-operand fragments, bf16 (hi, lo), K = C: 64 VGPRs,
+//   * the fc2 accumulators out^T[C features x its rows]: 64 VGPRs.
+// The weights stream through LDS in chunks of 32 hidden features: stage A_j = W1[32 j .. 32 j + 31][0 .. C) and stage
+// B_j = W2[0 .. C)[32 j .. 32 j + 31], C rows x 128 B each, laid out ONCE per parameter on the host as the byte image the LDS
+// wants (hfl_mlp_fused_pack_*: stages in consumption order, 16-B slots of every row XOR-swizzled), so a stage is a linear
+// LDS-DMA copy (global_load_lds_dwordx4) with no address arithmetic.  Per chunk a wave runs
+//   GEMM1  h^T[32 hidden x 16 rows] = W1_chunk . LN(x)^T     (A from LDS, B from registers)
+//   GELU   in registers; the accumulator layout of GEMM1 (4 consecutive hidden features per lane, row on the lane) IS a
+//          B-operand layout of GEMM2 once W2's k-order inside the 32-chunk is permuted to match (done in the pack): the
+//          hidden activation is converted to (hi, lo) bf16 fragments in place -- no LDS round trip, no barrier
+//   GEMM2  out^T[C x 16 rows] += W2_chunk . g^T
+// software-pipelined by one chunk (stage order A0, A1, B0, A2, B1, ...): the GELU of chunk j-1 is VALU work between the
+// MFMAs of GEMM1 of chunk j.  Four LDS slots, two stages in flight: one s_barrier and one counted s_waitcnt vmcnt per
+// stage, nothing else on the vector-memory counter inside the loop; the refill of a slot is issued piecewise between the
+// MFMA steps of a stage.
+// Work split: persistent-style, every workgroup takes an equal contiguous share of the 16-row tiles and walks it in passes
+// (the weight stream restarts per pass and is served by the XCD's L2: 2 MB [0.5 MB] per parameter pair).
+#include "hfl_common.h"
+#include "x3_math.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpFusedParams {
+  float* out;                 // (M, C) f32
+  const float* x;             // (M, C) f32: LayerNorm input and residual
+  const float* gamma;         // (C)
+  const float* beta;          // (C)
+  const unsigned char* pack;  // hfl_mlp_fused_pack image of (W1, W2)
+  const float* b1;            // (4C)
+  const float* b2;            // (C)
+  int64_t M;
+  float eps;
+  int n_tiles;                // ceil(M / 16)
+};
+
+#define HFL_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// Fragment reads as inline asm: hipcc schedules its own ds_read next to the first use when registers are scarce (here it
+// re-used one fragment set and waited lgkmcnt(0) in front of every other MFMA); written out, the reads of step s + 1 are in
+// flight behind the MFMAs of step s.  Four 16-B reads: (ahi, alo) + o0 and (ahi, alo) + o1.  `pin` is a fragment of the
+// CURRENT step: as a read-write operand it keeps that step's MFMAs behind this statement.  The matching wait names the four
+// destinations read-write, so no consumer can be scheduled above it (cdna_hip_programming.md 5.7, form (ii)).
+#define HFL_LDS_READ4(f0, f1, f2, f3, ahi, alo, o0, o1, pin)                                                         \
+  asm volatile("ds_read_b128 %0, %5 offset:%7\n\tds_read_b128 %1, %6 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\t" \
+               "ds_read_b128 %3, %6 offset:%8"                                                                       \
+               : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3), "+v"(pin)                                                \
+               : "v"(ahi), "v"(alo), "n"(o0), "n"(o1))
+#define HFL_LDS_READ4_FIRST(f0, f1, f2, f3, ahi, alo, o0, o1)                                                        \
+  asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t" \
+               "ds_read_b128 %3, %5 offset:%7"                                                                       \
+               : "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)                                                          \
+               : "v"(ahi), "v"(alo), "n"(o0), "n"(o1))
+#define HFL_LDS_WAIT4(f0, f1, f2, f3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3))
+// ... and `after` = the last accumulator of the current step: the wait stays behind that step's MFMAs (no instruction in the
+// statement touches it)
+#define HFL_LDS_WAIT4_AFTER(f0, f1, f2, f3, after) \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(after))
+
+template <int... Is, class F>
+__device__ __forceinline__ void hfl_static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <int C, int NT>
+__global__ void __launch_bounds__(512, 2)
+ln_mlp_fused_kernel(const MlpFusedParams p) {
+  constexpr int KS = C / 32;               // k-steps of GEMM1
+  constexpr int FT = C / 16;               // 16-feature tiles of the output
+  constexpr int NCH = C / 8;               // chunks of 32 hidden features (hidden = 4 C)
+  constexpr int STAGE_B = C * 128;         // bytes of one stage: C rows x 128 B
+  constexpr int NSLOT = 4;
+  constexpr int DPW = STAGE_B / 1024 / 8;  // LDS-DMA instructions per wave and stage
+  constexpr int NST = 2 * NCH;             // stages per pass
+  constexpr int TPP = 8 * NT;              // 16-row tiles per pass
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  float* b1s = reinterpret_cast<float*>(smem + NSLOT * STAGE_B);       // (4C) fc1 bias | (C) gamma | (C) beta | (C) fc2 bias
+  float* gms = b1s + 4 * C;
+  float* bts = gms + C;
+  float* b2s = bts + C;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- this workgroup's share of the 16-row tiles
+  const int G = gridDim.x, g = blockIdx.x;
+  const int base = p.n_tiles / G, extra = p.n_tiles % G;
+  int tile0 = g * base + (g < extra ? g : extra);
+  const int tile_end = tile0 + base + (g < extra ? 1 : 0);
+
+  // small vectors live in LDS for the whole kernel: read per use with ds_read (a global load per use would be a dependent
+  // L2 round trip each -- the register file has no room to hold them)
+  for (int i = tid; i < C; i += 512) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < C / 4; i += 512) {
+    reinterpret_cast<float4*>(gms)[i] = reinterpret_cast<const float4*>(p.gamma)[i];
+    reinterpret_cast<float4*>(bts)[i] = reinterpret_cast<const float4*>(p.beta)[i];
+    reinterpret_cast<float4*>(b2s)[i] = reinterpret_cast<const float4*>(p.b2)[i];
+  }
+  __syncthreads();
+
+  // ---- stage stream: stage n of a pass lives at pack + n * STAGE_B; wave w copies bytes [w, w+1) * DPW KiB of it
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  uint32_t seq = 0;                         // stages acquired so far (all passes): slot = seq % NSLOT
+  auto issue = [&](int n, uint32_t slot) {
+    const unsigned char* s = p.pack + (int64_t)n * STAGE_B + wave * (DPW * 1024);      // wave-uniform
+    unsigned char* d = smem + slot * STAGE_B + wave * (DPW * 1024);
+#pragma unroll
+    for (int i = 0; i < DPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024 + lane_off),
+                                       (__attribute__((address_space(3))) void*)(d + i * 1024), 16, 0, 0);
+  };
+  // Boundary step of stage n: it has landed for every wave (each waited for its own share, then the barrier) and every
+  // wave has left stage n - 1, hence also stage n - 2, whose slot takes stage n + 2.  That refill is NOT issued here: eight
+  // waves pushing 4 LDS-DMA instructions each through the CU's one address path at the same moment block each other at
+  // issue for hundreds of cycles with the matrix pipe idle; the pieces are issued one at a time between the MFMA steps of
+  // stage n (dma_piece).  Two stages in flight, four slots.
+  int dma_n = 0;                            // stage whose pieces the current stage body issues (NST: none)
+  uint32_t dma_slot = 0;
+  auto acquire = [&](int n) -> const unsigned char* {
+    if (n + 1 < NST) HFL_WAIT_VM(DPW);
+    else HFL_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    dma_n = n + 2;
+    dma_slot = (seq + 2) % NSLOT;
+    const unsigned char* st = smem + (seq % NSLOT) * STAGE_B;
+    ++seq;
+    return st;
+  };
+  auto dma_piece = [&](int i) {
+    if (dma_n < NST)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(p.pack + (int64_t)dma_n * STAGE_B + wave * (DPW * 1024) + i * 1024 +
+                                                          lane_off),
+          (__attribute__((address_space(3))) void*)(smem + dma_slot * STAGE_B + wave * (DPW * 1024) + i * 1024), 16, 0, 0);
+  };
+  constexpr int PPH = DPW / 2;              // pieces per half stage
+
+  // fragment byte offsets inside a stage (rows of 128 B, 16-B slot t of row r stored at slot t ^ ((r >> 1) & 7)):
+  // A fragment of a 16-row block: row = block * 16 + fr, hi chunk fq, lo chunk 4 + fq
+  const int off_hi = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4), off_lo = off_hi ^ 64;
+
+  while (tile0 < tile_end) {
+    const int ntile = tile_end - tile0 < TPP ? tile_end - tile0 : TPP;    // tiles of this pass
+    // ---- LayerNorm of this wave's rows -> B-operand fragments (lane: row fr of the tile, channels 32 ks + 8 fq + j)
+    bf16x8 xh[NT][KS], xl[NT][KS];
+    int64_t row[NT];
+    bool have[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int k = t * 8 + wave;                                   // tile k of the pass -> wave k % 8, slot k / 8
+      have[t] = k < ntile;
+      int64_t r = (int64_t)(tile0 + k) * 16 + fr;
+      row[t] = r;
+      if (r >= p.M) r = p.M - 1;
+      if (!have[t]) r = 0;
+      const float* xr = p.x + r * C + fq * 8;
+      float4 a[KS][2];
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[ks][0] = *reinterpret_cast<const float4*>(xr + ks * 32);
+        a[ks][1] = *reinterpret_cast<const float4*>(xr + ks * 32 + 4);
+        sum += ((a[ks][0].x + a[ks][0].y) + (a[ks][0].z + a[ks][0].w)) + ((a[ks][1].x + a[ks][1].y) + (a[ks][1].z + a[ks][1].w));
+      }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / (float)C);
+      float sq = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          a[ks][h].x -= mean; a[ks][h].y -= mean; a[ks][h].z -= mean; a[ks][h].w -= mean;
+          sq += (a[ks][h].x * a[ks][h].x + a[ks][h].y * a[ks][h].y) + (a[ks][h].z * a[ks][h].z + a[ks][h].w * a[ks][h].w);
+        }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      const float rstd = 1.0f / sqrtf(sq * (1.0f / (float)C) + p.eps);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 gm = *reinterpret_cast<const float4*>(gms + ks * 32 + fq * 8 + h * 4);
+          const float4 bt = *reinterpret_cast<const float4*>(bts + ks * 32 + fq * 8 + h * 4);
+          const f32x2 v01 = {fmaf(a[ks][h].x * rstd, gm.x, bt.x), fmaf(a[ks][h].y * rstd, gm.y, bt.y)};
+          const f32x2 v23 = {fmaf(a[ks][h].z * rstd, gm.z, bt.z), fmaf(a[ks][h].w * rstd, gm.w, bt.w)};
+          x3_split_pair(v01, hi[2 * h], lo[2 * h]);
+          x3_split_pair(v23, hi[2 * h + 1], lo[2 * h + 1]);
+        }
+        xh[t][ks] = __builtin_bit_cast(bf16x8, (u32x4){hi[0], hi[1], hi[2], hi[3]});
+        xl[t][ks] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], lo[2], lo[3]});
+      }
+    }
+    const bool active = have[0];                 // wave-uniform: tiles are dealt to the waves slot by slot
+    // The first two stages start moving only now: while an LDS-DMA is in flight hipcc waits vmcnt(0) before every use of
+    // an ordinary load's result, which would turn the row loads above into 16 dependent round trips.
+    // (Every wave has left the previous pass's last stage: the barrier orders it.)
+    __builtin_amdgcn_s_barrier();
+    issue(0, seq % NSLOT);
+    issue(1, (seq + 1) % NSLOT);
+
+    f32x4 oacc[FT][NT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) oacc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 hA[2][NT], hB[2][NT];                  // fc1 accumulators of two consecutive chunks
+    u32x4 gh[NT], gl[NT];                        // gelu(fc1) of one chunk as GEMM2 B fragments, (hi, lo) bf16 pairs per dword
+
+    // one pair of hidden values through bias + GELU + split: dword d of row tile t's fragment = features 2 d, 2 d + 1 of the
+    // lane's 8 (hidden block i = d >> 1, accumulator registers 2 (d & 1), 2 (d & 1) + 1); 4 NT pairs per chunk
+    auto gelu_pair = [&](int pidx, f32x4 (&hp)[2][NT], int chunk) {
+      const int t = pidx >> 2, d = pidx & 3;
+      const int i = d >> 1, r0 = 2 * (d & 1);
+      const float2 b = *reinterpret_cast<const float2*>(b1s + chunk * 32 + i * 16 + fq * 4 + r0);
+      // SCALAR f32 math on purpose (and -fno-slp-vectorize for this file): beside MFMAs a v_pk_*_f32 costs ~12 extra
+      // cycles of the matrix pipe each (MI355X_MICROARCH.md, cycle constants), a plain VALU op hides in the MFMA's shadow
+      const float g0 = x3_gelu(hp[i][t][r0] + b.x), g1 = x3_gelu(hp[i][t][r0 + 1] + b.y);
+      uint32_t hi, lo;
+      x3_split_pair_scalar(g0, g1, hi, lo);
+      gh[t][d] = hi;
+      gl[t][d] = lo;
+    };
+    // half `hf` of GEMM1 of one chunk from stage `st` into h; between its k-steps the GELU of the previous chunk (hp -> gh, gl)
+    auto gemm1_half = [&](const unsigned char* st, auto hfc, f32x4 (&h)[2][NT], f32x4 (&hp)[2][NT], int prev_chunk, bool with_gelu) {
+      constexpr int hf = decltype(hfc)::value;
+      if (hf == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) h[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      // fragments of k-step kk + 1 are requested before the MFMAs of k-step kk (two register sets): the LDS round trip
+      // (~200 cycles) would otherwise be exposed in front of every 6 NT MFMAs
+      const uint32_t ahi = (uint32_t)(uintptr_t)(st + off_hi) + hf * ((KS / 2) * 4096);
+      const uint32_t alo = (uint32_t)(uintptr_t)(st + off_lo) + hf * ((KS / 2) * 4096);
+      bf16x8 wf[2][4];
+      HFL_LDS_READ4_FIRST(wf[0][0], wf[0][1], wf[0][2], wf[0][3], ahi, alo, 0, 2048);
+      HFL_LDS_WAIT4(wf[0][0], wf[0][1], wf[0][2], wf[0][3]);
+      hfl_static_for(std::make_integer_sequence<int, KS / 2>{}, [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        constexpr int ks = hf * (KS / 2) + kk;
+        if constexpr (kk + 1 < KS / 2)
+          HFL_LDS_READ4(wf[(kk + 1) & 1][0], wf[(kk + 1) & 1][1], wf[(kk + 1) & 1][2], wf[(kk + 1) & 1][3], ahi, alo,
+                        (kk + 1) * 4096, (kk + 1) * 4096 + 2048, wf[kk & 1][0]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            h[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][2 * i], xl[t][ks], h[i][t], 0, 0, 0);
+            h[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][2 * i + 1], xh[t][ks], h[i][t], 0, 0, 0);
+            h[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kk & 1][2 * i], xh[t][ks], h[i][t], 0, 0, 0);
+          }
+        // the previous chunk's bias + GELU + split, a pair of hidden values at a time between the MFMAs (4 NT pairs over the
+        // KS k-steps of the stage: few live temporaries, the register file is what limits the fragment prefetch)
+        if (with_gelu) {
+          if constexpr (4 * NT >= KS) {
+#pragma unroll
+            for (int u = 0; u < 4 * NT / KS; ++u) gelu_pair(ks * (4 * NT / KS) + u, hp, prev_chunk);
+          } else {
+            if (ks % (KS / (4 * NT)) == 0) gelu_pair(ks / (KS / (4 * NT)), hp, prev_chunk);
+          }
+        }
+        if constexpr ((kk + 1) % ((KS / 2) / PPH) == 0) dma_piece(hf * PPH + (kk + 1) / ((KS / 2) / PPH) - 1);
+        if constexpr (kk + 1 < KS / 2)
+          HFL_LDS_WAIT4_AFTER(wf[(kk + 1) & 1][0], wf[(kk + 1) & 1][1], wf[(kk + 1) & 1][2], wf[(kk + 1) & 1][3], h[1][NT - 1]);
+      });
+    };
+    auto gelu_only = [&](f32x4 (&hp)[2][NT], int prev_chunk) {
+#pragma unroll
+      for (int pidx = 0; pidx < 4 * NT; ++pidx) gelu_pair(pidx, hp, prev_chunk);
+    };
+    auto gemm2_half = [&](const unsigned char* st, auto hfc) {
+      constexpr int hf = decltype(hfc)::value;
+      // two output tiles per step, the next step's 4 fragments requested before this step's MFMAs
+      const uint32_t ahi = (uint32_t)(uintptr_t)(st + off_hi) + hf * ((FT / 2) * 2048);
+      const uint32_t alo = (uint32_t)(uintptr_t)(st + off_lo) + hf * ((FT / 2) * 2048);
+      bf16x8 wf[2][4];
+      HFL_LDS_READ4_FIRST(wf[0][0], wf[0][1], wf[0][2], wf[0][3], ahi, alo, 0, 2048);
+      HFL_LDS_WAIT4(wf[0][0], wf[0][1], wf[0][2], wf[0][3]);
+      hfl_static_for(std::make_integer_sequence<int, FT / 4>{}, [&](auto sc) {
+        constexpr int ss = decltype(sc)::value;
+        if constexpr (ss + 1 < FT / 4)
+          HFL_LDS_READ4(wf[(ss + 1) & 1][0], wf[(ss + 1) & 1][1], wf[(ss + 1) & 1][2], wf[(ss + 1) & 1][3], ahi, alo,
+                        (ss + 1) * 4096, (ss + 1) * 4096 + 2048, wf[ss & 1][0]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          constexpr int i0 = hf * (FT / 2) + 2 * ss;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            oacc[i0 + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ss & 1][2 * u], __builtin_bit_cast(bf16x8, gl[t]), oacc[i0 + u][t], 0, 0, 0);
+            oacc[i0 + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ss & 1][2 * u + 1], __builtin_bit_cast(bf16x8, gh[t]), oacc[i0 + u][t], 0, 0, 0);
+            oacc[i0 + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ss & 1][2 * u], __builtin_bit_cast(bf16x8, gh[t]), oacc[i0 + u][t], 0, 0, 0);
+          }
+        }
+        if constexpr ((ss + 1) % ((FT / 4) / PPH) == 0) dma_piece(hf * PPH + (ss + 1) / ((FT / 4) / PPH) - 1);
+        if constexpr (ss + 1 < FT / 4)
+          HFL_LDS_WAIT4_AFTER(wf[(ss + 1) & 1][0], wf[(ss + 1) & 1][1], wf[(ss + 1) & 1][2], wf[(ss + 1) & 1][3],
+                              oacc[hf * (FT / 2) + 2 * ss + 1][NT - 1]);
+      });
+    };
+
+    // ---- the chunk pipeline: A0 | A1+gelu(0) B0 | A2+gelu(1) B1 | ... | A_{NCH-1}+gelu(NCH-2) B_{NCH-2} | gelu(NCH-1) B_{NCH-1}
+    // (waves without a row tile in this pass still carry their share of the weight stream)
+    int n = 0;
+    const unsigned char* st = acquire(n++);
+    auto idle_pieces = [&]() {
+#pragma unroll
+      for (int i = 0; i < DPW; ++i) dma_piece(i);
+    };
+    auto stage1 = [&](f32x4 (&h)[2][NT], f32x4 (&hp)[2][NT], int prev_chunk, bool with_gelu) {
+      if (active) {
+        gemm1_half(st, std::integral_constant<int, 0>{}, h, hp, prev_chunk, with_gelu);
+        gemm1_half(st, std::integral_constant<int, 1>{}, h, hp, prev_chunk, with_gelu);
+      } else {
+        idle_pieces();
+      }
+      st = acquire(n++);
+    };
+    auto stage2 = [&](bool more) {
+      if (active) {
+        gemm2_half(st, std::integral_constant<int, 0>{});
+        gemm2_half(st, std::integral_constant<int, 1>{});
+      } else {
+        idle_pieces();
+      }
+      if (more) st = acquire(n++);
+    };
+    stage1(hA, hB, 0, false);                                             // A0
+    for (int j = 1; j < NCH; j += 2) {           // NCH is even: j odd here, j + 1 even
+      stage1(hB, hA, j - 1, true);                                        // A_j + gelu(j - 1)
+      stage2(true);                                                       // B_{j-1}
+      if (j + 1 < NCH) {
+        stage1(hA, hB, j, true);                                          // A_{j+1} + gelu(j)
+        stage2(true);                                                     // B_j
+      }
+    }
+    if (active) gelu_only(hB, NCH - 1);          // NCH - 1 is odd: its accumulators are hB
+    stage2(false);                                                        // B_{NCH-1}
+
+    // ---- epilogue: out = acc + b2 + x (lane: row fr of the tile, features 16 i + 4 fq .. + 3)
+    // (tell the compiler's wait-count pass what the inline-asm wait of the last stage did: nothing is in flight any more,
+    // so the residual loads below get ordinary counted waits)
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (!have[t] || row[t] >= p.M) continue;
+      const float* xr = p.x + row[t] * C + fq * 4;
+      float* orow = p.out + row[t] * C + fq * 4;
+      f32x4 res[FT];               // every residual load in flight before the first store (the compiler cannot prove that
+#pragma unroll                     // out and x do not alias and would not hoist them itself)
+      for (int i = 0; i < FT; ++i) res[i] = *reinterpret_cast<const f32x4*>(xr + i * 16);
+#pragma unroll
+      for (int i = 0; i < FT; ++i) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(b2s + i * 16 + fq * 4);
+        *reinterpret_cast<f32x4*>(orow + i * 16) = oacc[i][t] + b + res[i];
+      }
+    }
+    tile0 += ntile;
+  }
+}
+
+// ---- host-side pack builder kernel: fp32 weights -> the stage stream --------------------------------------------------
+// Stage order of a pass (NCH = C / 8 chunks): A0, A1, B0, A2, B1, ..., A_{NCH-1}, B_{NCH-2}, B_{NCH-1}.
+// Stage A_j, row (ks * 32 + r):  W1[32 j + r][32 ks .. 32 ks + 31]              as [32 hi | 32 lo] bf16
+// Stage B_j, row n:              W2[n][32 j + perm(0 .. 31)]                    as [32 hi | 32 lo] bf16,
+//   perm: position 8 q + e  <->  hidden offset 16 (e >> 2) + 4 q + (e & 3)   (the accumulator layout of GEMM1 read as a
+//   B fragment of GEMM2).  16-B slot t of a row is stored at slot t ^ ((row >> 1) & 7).
+__global__ void __launch_bounds__(256)
+mlp_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w1, const float* __restrict__ w2, int C) {
+  const int nch = C / 8;
+  const int64_t cells = (int64_t)2 * nch * C * 8;                 // 16-B slots of the pack
+  for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (int64_t)gridDim.x * blockDim.x) {
+    const int slot = (int)(cell & 7);
+    const int r = (int)((cell >> 3) % C);
+    const int stage = (int)(cell / ((int64_t)C * 8));
+    // stage index -> (kind, chunk)
+    int kind, j;
+    if (stage == 0) { kind = 0; j = 0; }
+    else if (stage == 2 * nch - 1) { kind = 1; j = nch - 1; }
+    else if (stage & 1) { kind = 0; j = (stage + 1) / 2; }
+    else { kind = 1; j = stage / 2 - 1; }
+    const int t = slot ^ ((r >> 1) & 7);                           // logical 16-B chunk: 0..3 hi, 4..7 lo; 8 elements each
+    const int q = t & 3;
+    float v[8];
+    if (kind == 0) {
+      const int ks = r >> 5, rr = r & 31;
+      const float* src = w1 + (int64_t)(32 * j + rr) * C + ks * 32 + q * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[e];
+    } else {
+      const float* src = w2 + (int64_t)r * (4 * C) + 32 * j;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[16 * (e >> 2) + 4 * q + (e & 3)];
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t a = x3_bf16_rne(v[2 * e]), b = x3_bf16_rne(v[2 * e + 1]);
+      if (t >= 4) {
+        a = x3_bf16_rne(v[2 * e] - __uint_as_float(a << 16));
+        b = x3_bf16_rne(v[2 * e + 1] - __uint_as_float(b << 16));
+      }
+      o[e] = a | (b << 16);
+    }
+    *reinterpret_cast<uint4*>(pack + cell * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t hfl_mlp_fused_pack_bytes(int channels) {
+  if (channels != 128 && channels != 256) return 0;
+  return (int64_t)2 * (channels / 8) * channels * 128;
+}
+
+int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channels, hfl_stream_t stream) {
+  if (pack == nullptr || w1 == nullptr || w2 == nullptr || hfl_mlp_fused_pack_bytes(channels) == 0) return HFL_EINVAL;
+  const int64_t cells = hfl_mlp_fused_pack_bytes(channels) / 16;
+  mlp_pack_kernel<<<(unsigned)hfl_cdiv(cells, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<unsigned char*>(pack), w1, w2, channels);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                     const float* b1, const float* b2, int64_t n_rows, int channels, hfl_stream_t stream) {
+  if (out == nullptr || x == nullptr || gamma == nullptr || beta == nullptr || pack == nullptr || b1 == nullptr ||
+      b2 == nullptr || n_rows < 0)
+    return HFL_EINVAL;
+  if (channels != 128 && channels != 256) return HFL_EINVAL;
+  if (out == x) return HFL_EINVAL;                       // rows are re-read for the residual after other rows were written
+  if (n_rows == 0) return HFL_OK;
+  if (hfl_cdiv(n_rows, 16) > 0x7fffffffLL) return HFL_ECAPACITY;
+  MlpFusedParams p;
+  p.out = out; p.x = x; p.gamma = gamma; p.beta = beta; p.pack = static_cast<const unsigned char*>(pack);
+  p.b1 = b1; p.b2 = b2; p.M = n_rows; p.eps = eps;
+  p.n_tiles = (int)hfl_cdiv(n_rows, 16);
+  const int cus = hfl_num_cus();
+  const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
+#define HFL_MLP_LAUNCH(CC, NT)                                                                                  \
+  {                                                                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT>),              \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+    if (e != hipSuccess) return (int)e;                                                                         \
+    ln_mlp_fused_kernel<CC, NT><<<grid, 512, lds, s>>>(p);                                                      \
+  }
+  if (channels == 256) HFL_MLP_LAUNCH(256, 1) else HFL_MLP_LAUNCH(128, 2)
+#undef HFL_MLP_LAUNCH
+  HFL_RETURN_LAST_ERROR();
+}
+
+}  // extern "C"

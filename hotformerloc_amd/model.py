@@ -87,7 +87,8 @@ _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 # at 191 ms/step (B=32, Wild-Places) still slower than the fp32 hipBLASLt route (145 ms) because the operand
 # splits of the backward are torch element-wise passes; needs fused split kernels to pay off.
 _TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
-# training-path Linear layers on the hand-written split GEMM (autograd.LinearX3Fn: forward + dx; dW stays fp32)
+# training-path Linear layers on the hand-written split GEMMs (autograd.LinearX3Fn: forward + dx on hfl_linear_x3, dW / db
+# on hfl_wgrad_x3)
 _TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
 _ATTN_F16 = os.environ.get('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
 _TRAIN_LN = os.environ.get('HFL_TRAIN_LN', '1') != '0'    # training-path LayerNorm: HIP forward + backward kernels
@@ -143,15 +144,49 @@ def _w2(lin: nn.Linear):
     key = ('x3', id(w))
     hit = _W3_CACHE.get(key)
     if hit is None or hit[0]() is not w or hit[1] != w._version or hit[3] != w.data_ptr():
+        if hit is None or hit[0]() is not w:
+            # the split copy is as large as the weight: release it with the parameter (a model that ran inference must
+            # not leak its Linear bytes for the life of the process)
+            weakref.finalize(w, _W3_CACHE.pop, key, None)
         hit = (weakref.ref(w), w._version, ops.split2_weight(w), w.data_ptr())
         _W3_CACHE[key] = hit
     return hit[2]
 
 
+# LN2 -> fc1 -> GELU -> fc2 -> residual as ONE launch (csrc/mlp_fused.hip) from this many rows on: below it the launch cannot
+# fill the chip with its 128 / 256-row workgroup passes and the three-launch form is as fast (tools/mlp_fused_probe.py)
+_MLP_FUSED = os.environ.get('HFL_MLP_FUSED', '1') != '0'
+_MLP_FUSED_MIN_ROWS = int(os.environ.get('HFL_MLP_FUSED_MIN_ROWS', '24576'))
+
+
+def _mlp_pack(mlp: 'MLP', rows: int):
+    """Weight image of the fused MLP launch for this block, or None when the launch does not apply (channel width, row count,
+    missing biases).  Cached per (fc1, fc2) parameter pair like `_w2`."""
+    f1, f2 = mlp.fc1, mlp.fc2
+    c = f1.in_features
+    if not (_MLP_FUSED and rows >= _MLP_FUSED_MIN_ROWS and c in (128, 256) and f1.out_features == 4 * c
+            and f2.in_features == 4 * c and f2.out_features == c and f1.bias is not None and f2.bias is not None):
+        return None
+    w1, w2 = f1.weight, f2.weight
+    key = ('mlp', id(w1), id(w2))
+    hit = _W3_CACHE.get(key)
+    stamp = (w1._version, w2._version, w1.data_ptr(), w2.data_ptr())
+    if hit is None or hit[0]() is not w1 or hit[1]() is not w2 or hit[2] != stamp:
+        if hit is None or hit[0]() is not w1:
+            weakref.finalize(w1, _W3_CACHE.pop, key, None)
+        hit = (weakref.ref(w1), weakref.ref(w2), stamp, ops.mlp_fused_pack(w1, w2))
+        _W3_CACHE[key] = hit
+    return hit[3]
+
+
 def _block_tail_x3(x, attn_out2, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
-    """proj (+bias +residual) -> LN2 -> fc1 (+bias, GELU, re-split) -> fc2 (+bias +residual): four launches of the
-    hand-written GEMM and one LayerNorm; the M x 4C hidden activation crosses HBM once each way as 4 B per element."""
+    """proj (+bias +residual) -> LN2 -> fc1 (+bias, GELU, re-split) -> fc2 (+bias +residual): the proj launch of the
+    hand-written GEMM, then the MLP branch as one fused launch (hidden activation in registers) or, for small row counts,
+    as LayerNorm + two GEMM launches (the M x 4C hidden activation crosses HBM once each way as 4 B per element)."""
     x = ops.linear_x3(attn_out2, _w2(attn.proj), bias=attn.proj.bias, residual=x)
+    pack = _mlp_pack(mlp, x.shape[0])
+    if pack is not None:
+        return ops.ln_mlp_fused(x, norm2.weight, norm2.bias, norm2.eps, pack, mlp.fc1.bias, mlp.fc2.bias)
     h2 = ops.layer_norm_split2(x, norm2.weight, norm2.bias, norm2.eps)
     g2 = ops.linear_x3(h2, _w2(mlp.fc1), bias=mlp.fc1.bias, gelu_split_out=True)
     return ops.linear_x3(g2, _w2(mlp.fc2), bias=mlp.fc2.bias, residual=x)
@@ -165,6 +200,8 @@ def _w3(lin: nn.Linear):
         if len(_W3_CACHE) > 4096:                     # drop entries whose weight is gone
             for k in [k for k, v in _W3_CACHE.items() if v[0]() is None]:
                 del _W3_CACHE[k]
+        if hit is None or hit[0]() is not w:
+            weakref.finalize(w, _W3_CACHE.pop, id(w), None)
         hit = (weakref.ref(w), w._version, ops.split_weight(w), w.data_ptr())
         _W3_CACHE[id(w)] = hit
     return hit[2]
@@ -579,13 +616,24 @@ def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
     if table is not None and expanded is None:
         return None
     mlp, cpe = block.mlp, block.cpe
-    keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2), expanded)
+    # the native call reads raw pointers: every parameter must be what the Python wrappers would have checked (fp32,
+    # contiguous, on this device), the biases must exist and the three LayerNorms must share one eps
+    plist = (cpe.conv.weights, cpe.norm.weight, cpe.norm.bias, block.norm1.weight, block.norm1.bias, block.norm2.weight,
+             block.norm2.bias, att.qkv.bias, att.proj.bias, mlp.fc1.bias, mlp.fc2.bias, table)
+    if any(p is None for p in plist[:-1]) or not (block.norm1.eps == block.norm2.eps == cpe.norm.eps):
+        return None
+    if any(p is not None and (p.dtype != torch.float32 or not p.is_contiguous() or p.device != x_in.device) for p in plist):
+        return None
+    pack = _mlp_pack(mlp, rows)
+    keep = (_w2(att.qkv), _w2(att.proj), None if pack is not None else _w2(mlp.fc1),
+            None if pack is not None else _w2(mlp.fc2), expanded, pack)
     w = BlockWeights(channels=C, eps=block.norm1.eps, q_scale=16 ** -0.5 * 1.4426950408889634,
                      cpe_weight=cpe.conv.weights.data_ptr(), cpe_gamma=cpe.norm.weight.data_ptr(),
                      cpe_beta=cpe.norm.bias.data_ptr(), norm1_gamma=block.norm1.weight.data_ptr(),
                      norm1_beta=block.norm1.bias.data_ptr(), norm2_gamma=block.norm2.weight.data_ptr(),
                      norm2_beta=block.norm2.bias.data_ptr(), qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(),
-                     fc1_w=keep[2].data_ptr(), fc2_w=keep[3].data_ptr(), qkv_b=att.qkv.bias.data_ptr(),
+                     fc1_w=None if pack is not None else keep[2].data_ptr(), fc2_w=None if pack is not None else keep[3].data_ptr(),
+                     mlp_pack=None if pack is None else pack.data_ptr(), qkv_b=att.qkv.bias.data_ptr(),
                      proj_b=att.proj.bias.data_ptr(), fc1_b=mlp.fc1.bias.data_ptr(), fc2_b=mlp.fc2.bias.data_ptr(),
                      rpe_table=None if table is None else table.data_ptr())
     desc = WindowAttnDesc(n_tokens=nt, rt_row0=nt, n_windows=plan.n_windows[depth], patch_size=att.patch_size,

@@ -492,6 +492,45 @@ def linear_x3_grouped(x2: torch.Tensor, w2: torch.Tensor, tiles: torch.Tensor, o
     return out
 
 
+def mlp_fused_ok(channels: int) -> bool:
+    """Channel widths `ln_mlp_fused` takes (hfl_mlp_fused_pack_bytes > 0)."""
+    return int(_native.load().hfl_mlp_fused_pack_bytes(int(channels))) > 0
+
+
+def mlp_fused_pack(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Weight image of `ln_mlp_fused` from the fp32 Linear weights fc1 (4C, C) and fc2 (C, 4C) (hfl_mlp_fused_pack): the
+    (hi, lo) bf16 split of both, cut into the 32-hidden-feature stages the kernel streams through LDS.  Once per parameter."""
+    _dev(w1, w2)
+    w1, w2 = _f32c(w1.detach()), _f32c(w2.detach())
+    c = w1.shape[1]
+    assert tuple(w1.shape) == (4 * c, c) and tuple(w2.shape) == (c, 4 * c)
+    lib = _native.load()
+    n = int(lib.hfl_mlp_fused_pack_bytes(c))
+    if n <= 0:
+        raise _native.NativeLibraryError('hfl_mlp_fused_pack: unsupported channel count %d' % c)
+    pack = torch.empty(n, dtype=torch.uint8, device=w1.device)
+    check(lib.hfl_mlp_fused_pack(pack.data_ptr(), w1.data_ptr(), w2.data_ptr(), c, _stream()), 'hfl_mlp_fused_pack')
+    return pack
+
+
+def ln_mlp_fused(x, gamma, beta, eps: float, pack, b1, b2, out=None):
+    """out = x + fc2(gelu(fc1(LN(x)) + b1)) + b2 in ONE launch (hfl_ln_mlp_fused); `pack` from `mlp_fused_pack`."""
+    _dev(x, gamma, beta, pack, b1, b2)
+    x = _f32c(x)
+    m, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        assert out.shape == x.shape and out.dtype == torch.float32 and out.is_contiguous()
+    assert out.data_ptr() != x.data_ptr(), 'the residual rows are re-read: cannot run in place'
+    # algorithmic bytes: read x, write out (the LayerNorm input doubles as the residual); 2 * 2 * M * C * 4C flop
+    with _timed('hfl_ln_mlp_fused', m * c * 8, 16 * m * c * c):
+        check(_native.load().hfl_ln_mlp_fused(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                              float(eps), pack.data_ptr(), _f32c(b1).data_ptr(), _f32c(b2).data_ptr(), m, c,
+                                              _stream()), 'hfl_ln_mlp_fused')
+    return out
+
+
 def block_forward_x3(weights, keep_alive, x_in, relay, neigh, tok_meta, n_tokens: int, desc: WindowAttnDesc):
     """One transformer block of the inference path in ONE native call (hfl_block_forward_x3): CPE -> [relay rows] -> LN1 ->
     qkv -> window attention -> proj + residual -> LN2 -> fc1 + GELU -> fc2 + residual.  `weights` = a filled
@@ -650,7 +689,9 @@ def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int):
         return None
     key = (id(rpe_table), depth)
     hit = _RPE2_CACHE.get(key)
-    if hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version:
+    # data_ptr / device: `module.to(...)` swaps `.data` without bumping the version counter
+    if (hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version and hit[3] == rpe_table.data_ptr()
+            and hit[2].device == rpe_table.device):
         return hit[2]
     out = torch.empty(n, dtype=torch.float32, device=rpe_table.device)
     src = _f32c(rpe_table.detach())
@@ -658,7 +699,7 @@ def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int):
           'hfl_window_rpe_expand')
     if len(_RPE2_CACHE) > 512:
         _RPE2_CACHE.clear()
-    _RPE2_CACHE[key] = (weakref.ref(rpe_table), rpe_table._version, out)
+    _RPE2_CACHE[key] = (weakref.ref(rpe_table), rpe_table._version, out, rpe_table.data_ptr())
     return out
 
 

@@ -395,6 +395,20 @@ int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_spl
 int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, const float* beta,
                           int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
 
+/* 9c. The pre-norm MLP branch of a transformer block as ONE launch (csrc/mlp_fused.hip):
+ *       out (n_rows, C) = x + fc2(gelu(fc1(LayerNorm(x; gamma, beta, eps)) + b1)) + b2        fc1: C -> 4C, fc2: 4C -> C
+ * Replaces norm2 -> mlp.fc1 -> GELU -> mlp.fc2 -> residual add (models/octformer_backbone.py:275-278,
+ * models/hotformerloc_backbone.py:213-216, models/layers/octformer_layers.py:38-59).  Same split-precision arithmetic as
+ * hfl_linear_x3 (three-term bf16 products, fp32 accumulation, exact-erf GELU); the 4C-wide hidden activation never leaves the
+ * register file.  C in {128, 256}; out must not alias x.
+ * `pack` is the weight image hfl_mlp_fused_pack writes ONCE per parameter pair from the fp32 weights w1 (4C, C) and w2 (C, 4C)
+ * (hfl_mlp_fused_pack_bytes(C) bytes; 0 = unsupported C): the (hi, lo) bf16 split of both matrices cut into 32-hidden-feature
+ * stages in the order the kernel streams them through LDS. */
+int64_t hfl_mlp_fused_pack_bytes(int channels);
+int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channels, hfl_stream_t stream);
+int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                     const float* b1, const float* b2, int64_t n_rows, int channels, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 10. Backward kernels (training path; autograd glue in hotformerloc_amd/autograd.py).
  *     The reference gets these from PyTorch autograd over its materialised formulation and from
@@ -429,6 +443,9 @@ typedef struct hfl_block_weights {
   const uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;     /* split2 */
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
   const float* rpe_table;                              /* (3 (2 pos_bnd + 1), H) or NULL */
+  const void* mlp_pack;                                /* hfl_mlp_fused_pack image of (fc1, fc2) or NULL: when set, LN2 -> fc1 ->
+                                                          GELU -> fc2 -> residual run as ONE launch (hfl_ln_mlp_fused) and fc1_w /
+                                                          fc2_w are not read */
 } hfl_block_weights;
 typedef struct hfl_block_io {
   const float* x_in;

@@ -882,3 +882,59 @@ def test_layer_norm_backward_matches_torch_autograd():
     a = ops.layer_norm_bwd(dyd, xd, wd)
     b2 = ops.layer_norm_bwd(dyd, xd, wd)
     assert all(torch.equal(u, v) for u, v in zip(a, b2))
+
+
+def _mlp_ref(x, gamma, beta, eps, w1, b1, w2, b2):
+    x = x.double()
+    h = torch.nn.functional.layer_norm(x, (x.shape[1],), gamma.double(), beta.double(), eps)
+    h = torch.nn.functional.gelu(h @ w1.double().t() + b1.double())
+    return x + h @ w2.double().t() + b2.double()
+
+
+@pytest.mark.parametrize('C', [256, 128])
+def test_ln_mlp_fused_matches_fp64_and_the_unfused_launches(C):
+    """x + fc2(gelu(fc1(LN(x)))) in one launch (hfl_ln_mlp_fused: hidden activation kept in registers) against fp64 and
+    against the three launches it replaces (LayerNorm -> split2, fc1 + GELU, fc2 + residual), over row counts that hit
+    every tail: single row, partial 16-row tiles, fewer tiles than workgroups, several passes per workgroup."""
+    g = torch.Generator().manual_seed(77 + C)
+    w1 = (torch.randn(4 * C, C, generator=g) * 0.05).to(DEV)
+    w2 = (torch.randn(C, 4 * C, generator=g) * 0.05).to(DEV)
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).to(DEV)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    pack = ops.mlp_fused_pack(w1, w2)
+    w1s, w2s = ops.split2_weight(w1), ops.split2_weight(w2)
+    for n in (1, 15, 16, 17, 129, 2092, 4099, 40000, 70001):
+        x = (torch.randn(n, C, generator=g) * 2).to(DEV)
+        got = ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2)
+        ref = _mlp_ref(x.cpu(), gamma.cpu(), beta.cpu(), 1e-5, w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu())
+        err = ((got.cpu().double() - ref).norm() / ref.norm()).item()
+        assert err < 1e-5, (C, n, err)
+        h2 = ops.layer_norm_split2(x, gamma, beta, 1e-5)
+        unf = ops.linear_x3(ops.linear_x3(h2, w1s, bias=b1, gelu_split_out=True), w2s, bias=b2, residual=x)
+        assert (got - unf).abs().max().item() <= 2e-5 * ref.abs().max().item(), (C, n)
+        assert torch.equal(got, ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2))     # deterministic
+
+
+def test_ln_mlp_fused_layout_exact_on_small_integers():
+    """Fragment / stage layout check with exactly representable data: an identity-like LayerNorm (constant rows are avoided;
+    gamma = 1, beta = 0 on rows whose statistics are exact is not available, so the LayerNorm is bypassed by feeding rows with
+    mean 0 and unit variance built from +-1 entries) and integer weights make every product exact."""
+    C = 256
+    g = torch.Generator().manual_seed(5)
+    # rows of +-1 with equal counts: mean 0, variance 1 exactly -> LN(x) = x / sqrt(1 + eps) with eps = 0
+    x = torch.ones(300, C)
+    x[:, ::2] = -1
+    perm = torch.stack([torch.randperm(C, generator=g) for _ in range(300)])
+    x = torch.gather(x, 1, perm)
+    w1 = torch.randint(-2, 3, (4 * C, C), generator=g).float()
+    w2 = torch.randint(-2, 3, (C, 4 * C), generator=g).float()
+    b1 = torch.randint(-3, 4, (4 * C,), generator=g).float()
+    b2 = torch.randint(-3, 4, (C,), generator=g).float()
+    pack = ops.mlp_fused_pack(w1.to(DEV), w2.to(DEV))
+    got = ops.ln_mlp_fused(x.to(DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV), 0.0, pack, b1.to(DEV),
+                           b2.to(DEV)).cpu()
+    ref = _mlp_ref(x, torch.ones(C), torch.zeros(C), 0.0, w1, b1, w2, b2)
+    # GELU of integers is not an integer: compare to fp64 at the (hi, lo) bf16 resolution of the hidden activation
+    assert (got.double() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()

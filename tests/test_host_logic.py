@@ -169,3 +169,23 @@ def test_split_ranges_matches_the_python_loop():
             rid, first, length = _split_ranges(e, step)
             want = [(k, a, min(step, e[k + 1] - a)) for k in range(cnt.size) for a in range(e[k], e[k + 1], step)]
             assert [(int(a), int(b), int(c)) for a, b, c in zip(rid, first, length)] == [tuple(int(v) for v in w) for w in want]
+
+
+def test_split_weight_cache_releases_with_the_parameter():
+    """The split2 / split3 copies of a Linear weight are as large as the weight: they must go when the parameter goes
+    (the 'x3' entries were never evicted)."""
+    import gc
+    import torch
+    from hotformerloc_amd import model as M
+    before = len(M._W3_CACHE)
+    lin = torch.nn.Linear(64, 32)
+    w2 = M._w2(lin)
+    assert w2.shape == (32, 128) and M._w2(lin) is w2            # cached
+    w3 = M._w3(lin)
+    assert w3.shape == (32, 192) and len(M._W3_CACHE) == before + 2
+    with torch.no_grad():
+        lin.weight.add_(1.0)                                      # in-place update: version bump -> re-split, no new entry
+    assert M._w2(lin) is not w2 and len(M._W3_CACHE) == before + 2
+    del lin, w2, w3
+    gc.collect()
+    assert len(M._W3_CACHE) == before
