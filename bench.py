@@ -248,6 +248,8 @@ def main():
         neg_mask = (lab[:, None] != lab[None, :]).to(dev)
         loss_fn = TruncatedSmoothAP(tau1=0.01, positives_per_query=4)
         optim = torch.optim.AdamW(model.parameters(), lr=1e-5)
+        from hotformerloc_amd.training import OverlappedGradReducer
+        reducer = OverlappedGradReducer(model.parameters())     # gradient all-reduce bucket by bucket behind the backward
 
     collective = use_dist and not args.no_collective and not args.train
     state = {'fresh_plan': not args.resident_plan}
@@ -257,7 +259,7 @@ def main():
         if state['fresh_plan']:
             octree.drop_forward_caches()
         if args.train and args.multistaged:
-            multistaged_training_step(model, [batch], pos_mask, neg_mask, loss_fn, optim, n_total=n_tot)
+            multistaged_training_step(model, [batch], pos_mask, neg_mask, loss_fn, optim, n_total=n_tot, reducer=reducer)
             return torch.ones(1, device=dev)
         if args.train:
             model.zero_grad(set_to_none=True)

@@ -69,6 +69,8 @@ SIGNATURES = {
     'hfl_prepare_clouds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'hfl_tap_lists_workspace': (c_int64, [c_int64, c_int]),
     'hfl_tap_lists': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    'hfl_tap_tiles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'hfl_pad_index': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
     'hfl_window_attention_fwd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -595,4 +595,61 @@ int hfl_tap_lists(int32_t* src, int32_t* slot, int32_t* edges, const int32_t* ta
   HFL_RETURN_LAST_ERROR();
 }
 
+/* Row-tile table of the grouped tap GEMM (hfl_linear_x3_grouped) built on the device from the tap edges hfl_tap_lists wrote:
+ * tiles (n_tiles, 3) int32 = {first pair, pairs (<= tile_rows), tap * w_rows}, tap-major, no tile straddles a tap; n_tiles =
+ * sum over taps of ceil(pairs_k / tile_rows) (the caller knows it from its host copy of the edges).  Replaces a host-side
+ * numpy table + a blocking pageable copy per convolution and forward. */
+__global__ void __launch_bounds__(64) tap_tiles_kernel(int32_t* __restrict__ tiles, const int32_t* __restrict__ edges, int taps,
+                                                       int tile_rows, int w_rows) {
+  __shared__ int first[kTapMax + 1];
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int k = 0; k < taps; ++k) {
+      first[k] = acc;
+      acc += (edges[k + 1] - edges[k] + tile_rows - 1) / tile_rows;
+    }
+    first[taps] = acc;
+  }
+  __syncthreads();
+  for (int k = 0; k < taps; ++k) {
+    const int a = edges[k], b = edges[k + 1];
+    for (int t = threadIdx.x; t < first[k + 1] - first[k]; t += blockDim.x) {
+      const int r0 = a + t * tile_rows;
+      int32_t* o = tiles + 3 * (int64_t)(first[k] + t);
+      o[0] = r0;
+      o[1] = b - r0 < tile_rows ? b - r0 : tile_rows;
+      o[2] = k * w_rows;
+    }
+  }
+}
+
+int hfl_tap_tiles(int32_t* tiles, const int32_t* edges, int taps, int tile_rows, int w_rows, hfl_stream_t stream) {
+  if (tiles == nullptr || edges == nullptr || taps < 1 || taps > kTapMax || tile_rows < 1) return HFL_EINVAL;
+  tap_tiles_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(tiles, edges, taps, tile_rows, w_rows);
+  HFL_RETURN_LAST_ERROR();
+}
+
+/* Gather index of a ragged row stream padded per cloud (attentional pooling head, models/layers/pooling.py:209-233):
+ * out (B * nmax) int64, out[b * nmax + j] = row_off[b] + j for j < row_off[b+1] - row_off[b], else row_off[B] (the caller's
+ * zero row).  row_off (B + 1) int64 on the device. */
+__global__ void __launch_bounds__(256) pad_index_kernel(int64_t* __restrict__ out, const int64_t* __restrict__ row_off, int B,
+                                                        int64_t nmax) {
+  const int64_t total = (int64_t)B * nmax;
+  const int64_t sentinel = row_off[B];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nmax);
+    const int64_t j = i - (int64_t)b * nmax;
+    const int64_t a = row_off[b];
+    out[i] = j < row_off[b + 1] - a ? a + j : sentinel;
+  }
+}
+
+int hfl_pad_index(int64_t* out, const int64_t* row_off, int batch, int64_t nmax, hfl_stream_t stream) {
+  if (out == nullptr || row_off == nullptr || batch < 0 || nmax < 0) return HFL_EINVAL;
+  if (batch == 0 || nmax == 0) return HFL_OK;
+  const int64_t need = hfl_cdiv((int64_t)batch * nmax, 256);
+  pad_index_kernel<<<(unsigned)(need < 1024 ? need : 1024), 256, 0, static_cast<hipStream_t>(stream)>>>(out, row_off, batch, nmax);
+  HFL_RETURN_LAST_ERROR();
+}
+
 }  // extern "C"

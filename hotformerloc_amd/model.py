@@ -61,7 +61,7 @@ def training_numerics():
 
 def _ln(x, m: nn.LayerNorm):
     """LayerNorm over channels: HIP kernel in inference, torch (autograd) when grads are needed."""
-    if x.is_cuda and not _grad_path(x):
+    if x.is_cuda and not _grad_path(x) and x.shape[-1] in ops._LN_CHANNELS:
         return ops.layer_norm(x, m.weight, m.bias, m.eps)
     if x.is_cuda and _TRAIN_LN and x.numel() > 0 and x.shape[-1] in ops._LN_CHANNELS and x.dtype == torch.float32:
         return ag.layer_norm(x, m.weight, m.bias, m.eps)            # HIP forward + backward
@@ -70,7 +70,7 @@ def _ln(x, m: nn.LayerNorm):
 
 def _add_ln(x, y, m: nn.LayerNorm):
     """(x + y, LN(x + y)): one fused pass in inference."""
-    if x.is_cuda and not _grad_path(x):
+    if x.is_cuda and not _grad_path(x) and x.shape[-1] in ops._LN_CHANNELS:
         return ops.add_layer_norm(x, y, m.weight, m.bias, m.eps)
     x = x + y
     return x, _ln(x, m)
@@ -135,7 +135,8 @@ def get_gemm_mode() -> str:
 
 
 def _split_path(x) -> bool:
-    return _GEMM_MODE in ('bf16x3', 'x3') and x.is_cuda and not _grad_path()
+    # (channel widths that are not a multiple of the GEMM tile, e.g. 192 in per-level-width configs: fp32 library path)
+    return _GEMM_MODE in ('bf16x3', 'x3') and x.is_cuda and not _grad_path() and x.shape[-1] % 128 == 0
 
 
 def _w2(lin: nn.Linear):
@@ -412,11 +413,16 @@ class OctreeConvNormRelu(nn.Module):
 
 
 class PatchEmbed(nn.Module):
-    """models/octformer_backbone.py:424-461 (downsample_input_embeddings=True)"""
+    """models/octformer_backbone.py:424-461"""
 
-    def __init__(self, in_channels=3, dim=96, num_down=2, conv_norm='layernorm'):
+    def __init__(self, in_channels=3, dim=96, num_down=2, conv_norm='layernorm', downsample_input_embeddings=True):
         super().__init__()
         self.num_stages = num_down
+        self.downsample_input_embeddings = downsample_input_embeddings
+        if not downsample_input_embeddings:            # num_down 3x3x3 convolutions at the input depth (:449-452)
+            self.convs = nn.ModuleList([OctreeConvNormRelu(in_channels if i == 0 else dim, dim, [3], 1, conv_norm)
+                                        for i in range(num_down)])
+            return
         ch = [int(dim * 2 ** i) for i in range(-num_down, 1)]
         self.convs = nn.ModuleList([OctreeConvNormRelu(in_channels if i == 0 else ch[i], ch[i], [3], 1,
                                                        conv_norm) for i in range(num_down)])
@@ -425,6 +431,10 @@ class PatchEmbed(nn.Module):
         self.proj = OctreeConvNormRelu(ch[-1], dim, [3], 1, conv_norm)
 
     def forward(self, data, octree, depth):
+        if not self.downsample_input_embeddings:
+            for i in range(self.num_stages):
+                data = self.convs[i](data, octree, depth)
+            return data
         for i in range(self.num_stages):
             data = self.convs[i](data, octree, depth - i)
             data = self.downsamples[i](data, octree, depth - i)
@@ -498,9 +508,15 @@ class CPE(nn.Module):
                 out.copy_(y)
                 return out
             return y
-        if _grad_path(data):      # dwconv (HIP fwd/bwd, libs/dwconv semantics) -> LayerNorm -> residual
+        if _grad_path(data) or data.shape[1] not in (32, 64, 128, 256):
+            # dwconv (HIP fwd/bwd, libs/dwconv semantics) -> LayerNorm -> residual (also the inference path of channel
+            # widths the fused kernel is not instantiated for, e.g. 192 in per-level-width configurations)
             y = _ln(hdw.octree_dwconv(data, self.conv.weights, plan.neigh(depth)), self.norm)
-            return data + y if residual else y
+            y = data + y if residual else y
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         return ops.cpe_forward(data, self.conv.weights, self.norm.weight, self.norm.bias,
                                plan.neigh(depth), residual, self.norm.eps, out=out)
 
@@ -705,7 +721,7 @@ class HOTFormerBlock(nn.Module):
     [tokens | relay tokens] buffer of one depth."""
 
     def __init__(self, dim, num_heads, patch_size, disable_RPE=False, conv_norm='layernorm',
-                 drop_path=0.0, layer_scale=None, xcpe=False):
+                 drop_path=0.0, layer_scale=None, xcpe=False, rt_propagation=False, rt_propagation_scale=None, last=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim)
         self.attention = OctreeAttention(dim, patch_size, num_heads, 1, 1, not disable_RPE)
@@ -714,10 +730,28 @@ class HOTFormerBlock(nn.Module):
         self.drop_path = OctreeDropPath(drop_path)
         self.cpe = CPE(dim, conv_norm, xcpe)
         _init_layer_scale(self, dim, layer_scale)
+        # relay-token propagation (hotformerloc_backbone.py:183-193,224-235): the LAST block of a level adds every window's
+        # relay token, times a scalar, to the local features of that window
+        self.propagate = bool(last and rt_propagation)
+        if self.propagate:
+            self.upsampler = nn.Upsample(scale_factor=patch_size, mode='nearest')      # parameter-free; kept for the module tree
+            self.rt_gamma_propagate = (nn.Parameter(torch.tensor(float(rt_propagation_scale)))
+                                       if rt_propagation_scale is not None and type(rt_propagation_scale) in (int, float) else 1)
 
     def forward(self, buf, plan: WindowPlan, depth: int, relay=None):
         """buf: [tokens | relay rows] of this depth; `relay` (optional): this depth's relay rows as RTSA just produced
         them -- they replace buf's relay rows without a separate copy into buf first."""
+        out = self._forward(buf, plan, depth, relay)
+        if not self.propagate:
+            return out
+        # data + gamma * rt[window of the token], zero where the token's cloud is not the window's owner (rt_init_mask,
+        # models/octree.py:143-145): a gather over the relay rows, differentiable torch ops (last block of a level only)
+        nt = plan.n_tokens[depth]
+        win, keep = plan.token_window(depth)
+        tok = out[:nt] + self.rt_gamma_propagate * (out[nt:].index_select(0, win) * keep)
+        return torch.cat([tok, out[nt:]], 0)
+
+    def _forward(self, buf, plan: WindowPlan, depth: int, relay=None):
         nt = plan.n_tokens[depth]
         if _grad_path(buf):
             buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:] if relay is None else relay], 0)
@@ -823,40 +857,65 @@ class ADaPE(nn.Module):
 
 
 class HOTFormerStage(nn.Module):
-    """models/hotformerloc_backbone.py:366-635 (one channel width for all levels)."""
+    """models/hotformerloc_backbone.py:366-635: one channel width for all pyramid levels (shipped configs), or one per level
+    with linear projections between each level's width and the relay-token width (the widest level)."""
 
     def __init__(self, channels, num_heads, num_blocks, num_pyramid_levels, patch_size,
                  disable_RPE=False, ADaPE_mode=None, conv_norm='layernorm', drop_path=0.0, grad_checkpoint=False,
-                 dilation=4, disable_rt=False, layer_scale=None, xcpe=False):
+                 dilation=4, disable_rt=False, layer_scale=None, xcpe=False, rt_propagation=False,
+                 rt_propagation_scale=None):
         super().__init__()
         self.grad_checkpoint = grad_checkpoint
         self.disable_rt = disable_rt
-        if len(channels) != 1 or len(num_heads) != 1:
-            raise NotImplementedError('per-level channel widths (projection layers) are not used '
-                                      'by any shipped config')
-        C, H = channels[0], num_heads[0]
+        channels, num_heads = list(channels), list(num_heads)
+        self.use_projections = len(channels) != 1 and not disable_rt          # :384-400
+        if len(channels) == 1:
+            channels = channels * num_pyramid_levels
+        if len(num_heads) == 1:
+            num_heads = num_heads * num_pyramid_levels
+        assert len(channels) == num_pyramid_levels, 'Invalid num channels specified'
+        assert len(num_heads) == num_pyramid_levels, 'Invalid num heads specified'
+        self.channels, self.num_heads = channels, num_heads
+        Cm = self.max_rt_channels = max(channels)
+        Hm = self.max_rt_num_heads = num_heads[channels.index(Cm)]
         self.num_pyramid_levels, self.num_blocks = num_pyramid_levels, num_blocks
         self.use_ADaPE = ADaPE_mode is not None
         dp = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * num_blocks
+        L = num_pyramid_levels
         if disable_rt:
             # ablation without relay tokens (hotformerloc_backbone.py:396-397,440-458,477): plain local-attention
             # blocks with the dilation re-enabled, no RTSA, no relay-token initialiser
             self.hosa_blocks = nn.ModuleList([
-                nn.ModuleList([OctFormerBlock(C, H, patch_size, 1 if i % 2 == 0 else dilation, disable_RPE, conv_norm,
-                                              dp[i], layer_scale, xcpe)
-                               for i in range(num_blocks)]) for _ in range(num_pyramid_levels)])
+                nn.ModuleList([OctFormerBlock(channels[j], num_heads[j], patch_size, 1 if i % 2 == 0 else dilation,
+                                              disable_RPE, conv_norm, dp[i], layer_scale, xcpe)
+                               for i in range(num_blocks)]) for j in range(L)])
         else:
             self.hosa_blocks = nn.ModuleList([
-                nn.ModuleList([HOTFormerBlock(C, H, patch_size, disable_RPE, conv_norm, dp[i], layer_scale, xcpe)
-                               for i in range(num_blocks)]) for _ in range(num_pyramid_levels)])
-            self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(C, H, dp[i], layer_scale)
+                nn.ModuleList([HOTFormerBlock(channels[j], num_heads[j], patch_size, disable_RPE, conv_norm, dp[i],
+                                              layer_scale, xcpe, rt_propagation, rt_propagation_scale,
+                                              last=(i == num_blocks - 1))
+                               for i in range(num_blocks)]) for j in range(L)])
+            if self.use_projections:                                          # :406-408,461-475 (registration order)
+                self.up_projections = nn.ModuleList([
+                    nn.ModuleList([nn.Linear(channels[j], Cm) for _ in range(num_blocks)]) for j in range(L)])
+                self.down_projections = nn.ModuleList([
+                    nn.ModuleList([nn.Linear(Cm, channels[j]) for _ in range(num_blocks)]) for j in range(L)])
+                self.init_up_projections = nn.ModuleList([nn.Linear(channels[j], Cm) for j in range(L)])
+            self.rtsa_blocks = nn.ModuleList([RelayTokenTransformerBlock(Cm, Hm, dp[i], layer_scale)
                                               for i in range(num_blocks)])
-            self.relay_tokeniser = RelayTokenInitialiser(C, patch_size, conv_norm,
-                                                         use_cpe=not self.use_ADaPE, xcpe=xcpe)
+            if self.use_projections:
+                self.relay_tokeniser = nn.ModuleList([
+                    RelayTokenInitialiser(channels[j], patch_size, conv_norm, use_cpe=not self.use_ADaPE, xcpe=xcpe)
+                    for j in range(L)])
+            else:
+                self.relay_tokeniser = RelayTokenInitialiser(Cm, patch_size, conv_norm,
+                                                             use_cpe=not self.use_ADaPE, xcpe=xcpe)
             if self.use_ADaPE:
-                self.rt_adape = ADaPE(C, ADaPE_mode)
-        self.downsamples = nn.ModuleList([Downsample(C, C, conv_norm)
-                                          for _ in range(num_pyramid_levels - 1)])
+                self.rt_adape = ADaPE(Cm, ADaPE_mode)
+                if self.use_projections:
+                    self.rt_adape_projections = nn.ModuleList([nn.Linear(Cm, channels[j]) for j in range(L)])
+        self.downsamples = nn.ModuleList([Downsample(channels[j], channels[j + 1], conv_norm)
+                                          for j in range(L - 1)])
         self._streams = None
 
     def _side_streams(self, device):
@@ -882,17 +941,32 @@ class HOTFormerStage(nn.Module):
         octree = plan.octree
         feats = {depths[0]: data}
         bufs: Dict[int, torch.Tensor] = {}
+        proj = self.use_projections
         for j, d in enumerate(depths):                                  # init_pyramid_feats, 540-572
-            rt = self.relay_tokeniser(feats[d], plan, d)
+            tokeniser = self.relay_tokeniser[j] if proj else self.relay_tokeniser
+            rt = tokeniser(feats[d], plan, d)
             if self.use_ADaPE:
-                rt = rt + self.rt_adape(plan, d)
+                pe = self.rt_adape(plan, d)
+                rt = rt + (self.rt_adape_projections[j](pe) if proj else pe)
             bufs[d] = torch.cat([feats[d], rt], 0)
             if j < self.num_pyramid_levels - 1:
                 feats[d - 1] = self.downsamples[j](feats[d], octree, d)
         nts = [plan.n_tokens[d] for d in depths]
+        # relay rows as RTSA sees them: each level's own rows, or (per-level widths) their projection to the widest level
+        rts = {d: (self.init_up_projections[j](bufs[d][nt:]) if proj else bufs[d][nt:])          # 585-591
+               for j, (d, nt) in enumerate(zip(depths, nts))}
         ckpt = _use_checkpoint(self)
+
+        def hosa(j, d, i, buf, fresh_d):
+            """down-projection -> H-OSA block -> up-projection of one level (610-630); returns (buffer, relay rows for RTSA)"""
+            blk = self.hosa_blocks[j][i]
+            rin = self.down_projections[j][i](fresh_d) if proj else fresh_d
+            out = checkpoint(blk, buf, plan, d, rin, use_reentrant=False) if ckpt else blk(buf, plan, d, rin)
+            nt = plan.n_tokens[d]
+            return out, (self.up_projections[j][i](out[nt:]) if proj else out[nt:])
+
         for i in range(self.num_blocks):                                # 593-633
-            rt_all = torch.cat([bufs[d][nt:] for d, nt in zip(depths, nts)], 0)
+            rt_all = torch.cat([rts[d] for d in depths], 0)
             if ckpt:                                                    # 596-601
                 rt_all = checkpoint(self.rtsa_blocks[i], rt_all, plan, use_reentrant=False)
             else:
@@ -916,23 +990,19 @@ class HOTFormerStage(nn.Module):
                     side[j - 1].wait_stream(main)
                     keep.append((bufs[d], rt_all))
                     with torch.cuda.stream(side[j - 1]):
-                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d, fresh[d])
+                        bufs[d], rts[d] = hosa(j, d, i, bufs[d], fresh[d])
                     used.append(j)
                 for j, d in enumerate(depths):
                     if j not in used:
-                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d, fresh[d])
+                        bufs[d], rts[d] = hosa(j, d, i, bufs[d], fresh[d])
                 for j in used:
                     main.wait_stream(side[j - 1])
                 del keep
             else:
                 for j, d in enumerate(depths):
-                    if ckpt:                                            # 610-618
-                        bufs[d] = checkpoint(self.hosa_blocks[j][i], bufs[d], plan, d, fresh[d], use_reentrant=False)
-                    else:
-                        bufs[d] = self.hosa_blocks[j][i](bufs[d], plan, d, fresh[d])
+                    bufs[d], rts[d] = hosa(j, d, i, bufs[d], fresh[d])
         local = {d: bufs[d][:nt] for d, nt in zip(depths, nts)}
-        relay = {d: bufs[d][nt:] for d, nt in zip(depths, nts)}
-        return local, relay
+        return local, rts
 
 
 class HOTFormerBase(nn.Module):
@@ -940,8 +1010,10 @@ class HOTFormerBase(nn.Module):
 
     def __init__(self, in_channels, channels, num_blocks, num_heads, num_pyramid_levels,
                  num_octf_levels, patch_size, dilation, stem_down, ADaPE_mode, disable_RPE, conv_norm,
-                 drop_path=0.0, grad_checkpoint=False, disable_rt=False, layer_scale=None, xcpe=False):
+                 drop_path=0.0, grad_checkpoint=False, disable_rt=False, layer_scale=None, xcpe=False,
+                 rt_propagation=False, rt_propagation_scale=None, downsample_input_embeddings=True):
         super().__init__()
+        self.downsample_input_embeddings = downsample_input_embeddings
         # stochastic depth per block (hotformerloc_backbone.py:669-700)
         drop_ratio = torch.linspace(0, drop_path, sum(num_blocks)).tolist()
         self.patch_size, self.dilation = patch_size, dilation
@@ -951,7 +1023,7 @@ class HOTFormerBase(nn.Module):
         self.ADaPE_mode = ADaPE_mode
         if num_heads is None:
             num_heads = [c // 16 for c in channels]
-        self.patch_embed = PatchEmbed(in_channels, channels[0], stem_down, conv_norm)
+        self.patch_embed = PatchEmbed(in_channels, channels[0], stem_down, conv_norm, downsample_input_embeddings)
         self.octf_stage = nn.ModuleList([
             OctFormerStage(channels[i], num_heads[i], patch_size, dilation, num_blocks[i], disable_RPE,
                            conv_norm, drop_ratio[sum(num_blocks[:i]):sum(num_blocks[:i + 1])], grad_checkpoint,
@@ -963,15 +1035,19 @@ class HOTFormerBase(nn.Module):
                                          list(num_heads[num_octf_levels:]), num_blocks[-1],
                                          num_pyramid_levels, patch_size, disable_RPE, ADaPE_mode,
                                          conv_norm, drop_ratio[sum(num_blocks[:-1]):sum(num_blocks)],
-                                         grad_checkpoint, dilation, disable_rt, layer_scale, xcpe)
+                                         grad_checkpoint, dilation, disable_rt, layer_scale, xcpe, rt_propagation,
+                                         rt_propagation_scale)
 
     def forward(self, data, octree, depth):
-        data = self.patch_embed(data, octree, depth)
-        depth = depth - self.stem_down
-        plan = WindowPlan.for_octree(octree, self.patch_size, self.dilation, max_depth=depth,
-                                     start_depth=depth - self.num_stages + 1,
+        # the plan depends on the octree only: built first, so that its host work hides the round trip of the tap counts
+        # that `construct_all_neigh()` started (the stem convolutions below are the first to need them)
+        top = depth - self.stem_down if self.downsample_input_embeddings else depth         # :707-708
+        plan = WindowPlan.for_octree(octree, self.patch_size, self.dilation, max_depth=top,
+                                     start_depth=top - self.num_stages + 1,
                                      num_pyramid_levels=self.num_pyramid_levels,
                                      num_octf_levels=self.num_octf_levels, adape_mode=self.ADaPE_mode)
+        data = self.patch_embed(data, octree, depth)
+        depth = top
         for i in range(self.num_octf_levels):
             data = self.octf_stage[i](data, plan, depth)
             data = self.downsample[i](data, octree, depth)
@@ -987,13 +1063,21 @@ class HOTFormer(nn.Module):
                  num_octf_levels=1, patch_size=32, dilation=4, drop_path=0.5, stem_down=2,
                  ADaPE_mode=None, disable_RPE=False, conv_norm='layernorm',
                  qkv_init=('trunc_normal', 0.02), grad_checkpoint=False, disable_rt=False, layer_scale=None,
-                 xcpe=False):
+                 xcpe=False, rt_size=1, rt_propagation=False, rt_propagation_scale=None,
+                 downsample_input_embeddings=True):
         super().__init__()
+        if rt_size != 1:
+            # the reference's own model cannot run this option: RelayTokenInitialiser views the windows as (-1, K // G, C)
+            # against a (windows, K) mask and raises (models/hotformerloc_backbone.py:354-357, "TODO: Make this work with
+            # rt_size > 1"); tests/test_variants.py::test_ct_size_other_than_one_is_rejected_like_the_reference
+            raise NotImplementedError('ct_size != 1: the reference model itself fails on it '
+                                      '(models/hotformerloc_backbone.py:354-357)')
         self.backbone = HOTFormerBase(in_channels, list(channels), list(num_blocks),
                                       None if num_heads is None else list(num_heads),
                                       num_pyramid_levels, num_octf_levels, patch_size, dilation,
                                       stem_down, ADaPE_mode, disable_RPE, conv_norm, drop_path, grad_checkpoint,
-                                      disable_rt, layer_scale, xcpe)
+                                      disable_rt, layer_scale, xcpe, rt_propagation, rt_propagation_scale,
+                                      downsample_input_embeddings)
         for m in self.modules():
             if isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=0.02)
@@ -1068,13 +1152,19 @@ class PyramidAttnPoolWrapper(nn.Module):
     def __init__(self, feature_size, output_dim, channels, num_pyramid_levels, k_pooled_tokens,
                  mlp_ratio=1, mix_depth=4):
         super().__init__()
-        if len(channels) != 1:
-            raise NotImplementedError('per-level channel widths are not used by any shipped config')
+        channels = list(channels)
+        self.use_projections = len(channels) != 1                               # pooling.py:123-129
+        if len(channels) == 1:
+            channels = channels * num_pyramid_levels
+        assert len(channels) == num_pyramid_levels, 'Incorrect num channels'
         assert len(k_pooled_tokens) == num_pyramid_levels, \
             'k_pooled_tokens must be list of k for each pyramid level'
         self.k_pooled_tokens = list(k_pooled_tokens)
         total = sum(k_pooled_tokens)
-        self.attpool = nn.ModuleList([AdaptivePooling(channels[0], k) for k in k_pooled_tokens])
+        self.attpool = nn.ModuleList([AdaptivePooling(channels[j], k) for j, k in enumerate(k_pooled_tokens)])
+        if self.use_projections:                                                # pooling.py:143-152
+            self.local_projections = nn.ModuleList([nn.Linear(c, feature_size) if c != feature_size else nn.Identity()
+                                                    for c in channels])
         k_out = total // 4
         out_d = output_dim // k_out
         assert k_out * out_d == output_dim, \
@@ -1082,8 +1172,10 @@ class PyramidAttnPoolWrapper(nn.Module):
         self.descriptor_extractor = Mixer(total, k_out, feature_size, mix_depth, mlp_ratio, out_d)
 
     def forward(self, local_feat_dict, plan: WindowPlan, depth=None):
-        toks = [self.attpool[j](local_feat_dict[d], plan, d)
-                for j, d in enumerate(local_feat_dict.keys())]
+        toks = []
+        for j, d in enumerate(local_feat_dict.keys()):
+            t = self.attpool[j](local_feat_dict[d], plan, d)
+            toks.append(self.local_projections[j](t) if self.use_projections else t)
         return self.descriptor_extractor(torch.cat(toks, 1))
 
 
@@ -1145,12 +1237,15 @@ class PyramidOctGeMWrapper(nn.Module):
                  add_batch_norm=True):
         super().__init__()
         assert num_pyramid_levels > 0, 'Minimum 1 pyramid layer'
-        if len(channels) != 1:
-            raise NotImplementedError('per-level channel widths are not used by any shipped config')
+        if len(channels) == 1:                                                  # pooling.py:66-70
+            concat_dim = input_dim * num_pyramid_levels
+        else:
+            assert len(channels) == num_pyramid_levels, 'Incorrect num channels'
+            concat_dim = sum(channels)
         self.input_dim, self.output_dim, self.num_pyramid_levels = input_dim, output_dim, num_pyramid_levels
         self.p = nn.Parameter(torch.ones(num_pyramid_levels) * p)
         self.eps, self.gating = eps, gating
-        self.linear_bn = nn.Sequential(nn.Linear(input_dim * num_pyramid_levels, output_dim, bias=False),
+        self.linear_bn = nn.Sequential(nn.Linear(concat_dim, output_dim, bias=False),
                                        nn.BatchNorm1d(input_dim))
         if gating:
             self.context_gating = GatingContext(output_dim, add_batch_norm=add_batch_norm)

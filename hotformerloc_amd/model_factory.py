@@ -18,21 +18,16 @@ def get_in_channels(input_features: str) -> int:
 
 def _unsupported(params: ModelParams):
     bad = []
-    if not params.downsample_input_embeddings:
-        bad.append('downsample_input_embeddings=False')
     if params.ct_size != 1:
+        # not an omission: the reference's own model raises on it (models/hotformerloc_backbone.py:354-357)
         bad.append('ct_size != 1')
-    if params.ct_propagation:
-        bad.append('ct_propagation=True')
     if params.qkv_init[0] not in ('trunc_normal', 'torch_default'):
         bad.append('qkv_init=%s' % params.qkv_init[0])
     if bad:
-        raise NotImplementedError('options not built (SURVEY section 8f rank 4, remaining part): '
-                                  + ', '.join(bad))
+        raise NotImplementedError('options the reference model does not run either: ' + ', '.join(bad))
 
 
-# constructor argument <- ModelParams field (the reads of models/model_factory.py:27-70 that the shipped
-# configs exercise; the remaining ones are checked by _unsupported above)
+# constructor argument <- ModelParams field (the reads of models/model_factory.py:27-70)
 _BACKBONE_ARGS = {
     'channels': 'channels', 'num_blocks': 'num_blocks', 'num_heads': 'num_heads',
     'num_pyramid_levels': 'num_pyramid_levels', 'num_octf_levels': 'num_octf_levels',
@@ -40,6 +35,8 @@ _BACKBONE_ARGS = {
     'stem_down': 'num_input_downsamples', 'ADaPE_mode': 'ADaPE_mode', 'disable_RPE': 'disable_RPE',
     'conv_norm': 'conv_norm', 'qkv_init': 'qkv_init', 'grad_checkpoint': 'grad_checkpoint',
     'disable_rt': 'disable_rt', 'layer_scale': 'layer_scale', 'xcpe': 'xcpe',
+    'rt_size': 'ct_size', 'rt_propagation': 'ct_propagation', 'rt_propagation_scale': 'ct_propagation_scale',
+    'downsample_input_embeddings': 'downsample_input_embeddings',
 }
 _POOLING_ARGS = {
     'pool_method': 'pooling', 'in_dim': 'feature_size', 'output_dim': 'output_dim',

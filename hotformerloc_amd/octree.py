@@ -180,9 +180,9 @@ class Octree:
         if (fresh or '_sparse_taps' not in self.__dict__) and self.device.type == 'cuda':
             lo = max(self.full_depth + 1, 3)
             keys = [(d, '333', 1) for d in range(lo, self.depth)] + [(d, '222', 2) for d in range(lo, self.depth + 1)]
-            self._build_tap_lists(keys)
+            self._start_tap_lists(keys)          # asynchronous: the first sparse_taps() of the forward collects the counts
 
-    _FORWARD_CACHES = ('_window_plans', '_sparse_taps', '_tap_tiles', '_sparse_taps_bwd')
+    _FORWARD_CACHES = ('_window_plans', '_sparse_taps', '_tap_tiles', '_sparse_taps_bwd', '_tap_edges_dev', '_taps_pending')
 
     def drop_forward_caches(self):
         """Forget everything `model(batch)` derives from the octree and keeps on it between calls: the window / relay-token
@@ -257,19 +257,22 @@ class Octree:
         cache = self.__dict__.setdefault('_sparse_taps', {})
         key = (depth, kernel, stride)
         if key not in cache:
-            self._build_tap_lists([key])
+            if self.__dict__.get('_taps_pending'):
+                self._finish_tap_lists()
+            if key not in cache:
+                self._build_tap_lists([key])
         return cache[key]
 
     def tap_tiles(self, depth: int, kernel: str, stride: int, w_rows: int):
         """Row tiles of the grouped tap GEMM (ops.linear_x3_grouped) over the pair list of `sparse_taps`: (n, 3) int32
-        {first pair, pairs (<= 128), tap * w_rows}; no tile straddles a tap.  Host-built from the tap edges, cached."""
+        {first pair, pairs (<= 128), tap * w_rows}; no tile straddles a tap.  Device-built from the tap edges, cached."""
         cache = self.__dict__.setdefault('_tap_tiles', {})
         key = (depth, kernel, stride, w_rows)
         if key not in cache:
             _, _, edges = self.sparse_taps(depth, kernel, stride)
-            tap, a, rows = _split_ranges(np.asarray(edges, dtype=np.int64), 128)
-            t = np.stack([a, rows, tap * w_rows], 1).astype(np.int32)
-            cache[key] = torch.from_numpy(t).to(self.device)
+            n_tiles = sum((edges[k + 1] - edges[k] + 127) // 128 for k in range(len(edges) - 1))
+            # built on the device from the tap edges already there (hfl_tap_tiles): no host table, no blocking copy
+            cache[key] = ops.tap_tiles(self._tap_edges_dev[(depth, kernel, stride)], n_tiles, len(edges) - 1, w_rows)
         return cache[key]
 
     def sparse_taps_bwd(self, depth: int, kernel: str = '333', stride: int = 1):
@@ -302,11 +305,21 @@ class Octree:
         return cache[key]
 
     def _build_tap_lists(self, keys):
-        """Tap lists for several (depth, kernel, stride) tables: all launches first, then one host read."""
+        """Tap lists for several (depth, kernel, stride) tables: all launches, then ONE device->host read of the per-tap
+        counts.  The read is asynchronous (pinned buffer + event): `construct_all_neigh()` only starts it, the first
+        `sparse_taps()` of the forward waits for it -- by then the host has built the window plan and issued the first
+        layers, so the round trip is hidden."""
+        self._start_tap_lists(keys)
+        self._finish_tap_lists()
+
+    def _start_tap_lists(self, keys):
         cache = self.__dict__.setdefault('_sparse_taps', {})
-        todo = [k for k in keys if k not in cache]
+        pending = self.__dict__.get('_taps_pending')
+        todo = [k for k in keys if k not in cache and not (pending and k in pending[0])]
         if not todo:
             return
+        if pending:
+            self._finish_tap_lists()
         tables = [self.get_neigh(d, kern, st, nempty=True).contiguous() for d, kern, st in todo]
         taps = [t.shape[1] for t in tables]
         edges_all = torch.empty(sum(n + 1 for n in taps), dtype=torch.int32, device=self.device)
@@ -314,10 +327,25 @@ class Octree:
         for t, n in zip(tables, taps):
             built.append(ops.tap_lists(t, edges_all[off:off + n + 1]))
             off += n + 1
-        host = edges_all.cpu().tolist()                                   # the one host read
+        host = torch.empty(edges_all.numel(), dtype=torch.int32, pin_memory=True)
+        host.copy_(edges_all, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.__dict__['_taps_pending'] = (todo, built, taps, host, ev, edges_all)
+
+    def _finish_tap_lists(self):
+        pending = self.__dict__.pop('_taps_pending', None)
+        if pending is None:
+            return
+        todo, built, taps, host, ev, edges_all = pending
+        ev.synchronize()                                                  # the one host read
+        host = host.tolist()
+        cache = self.__dict__.setdefault('_sparse_taps', {})
+        dev_edges = self.__dict__.setdefault('_tap_edges_dev', {})
         off = 0
         for key, (src, slot, _), n in zip(todo, built, taps):
             edges = host[off:off + n + 1]
+            dev_edges[key] = edges_all[off:off + n + 1]
             off += n + 1
             cache[key] = (src[:edges[-1]].view(-1, 1), slot, edges)
 

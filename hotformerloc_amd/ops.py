@@ -675,6 +675,26 @@ def tap_lists(table: torch.Tensor, edges_out: torch.Tensor = None):
     return src, slot, edges
 
 
+def tap_tiles(edges_dev: torch.Tensor, n_tiles: int, taps: int, w_rows: int, tile_rows: int = 128):
+    """(n_tiles, 3) int32 row-tile table of `linear_x3_grouped` from the device-side tap edges (hfl_tap_tiles)."""
+    _dev(edges_dev)
+    assert edges_dev.dtype == torch.int32 and edges_dev.numel() == taps + 1
+    tiles = torch.empty((n_tiles, 3), dtype=torch.int32, device=edges_dev.device)
+    if n_tiles > 0:
+        check(_native.load().hfl_tap_tiles(tiles.data_ptr(), edges_dev.data_ptr(), taps, tile_rows, w_rows, _stream()),
+              'hfl_tap_tiles')
+    return tiles
+
+
+def pad_index(row_off: torch.Tensor, batch: int, nmax: int):
+    """(batch * nmax) int64 gather index of a ragged per-cloud row stream, sentinel = row_off[batch] (hfl_pad_index)."""
+    _dev(row_off)
+    assert row_off.dtype == torch.int64 and row_off.numel() == batch + 1
+    out = torch.empty(batch * nmax, dtype=torch.int64, device=row_off.device)
+    check(_native.load().hfl_pad_index(out.data_ptr(), row_off.data_ptr(), batch, nmax, _stream()), 'hfl_pad_index')
+    return out
+
+
 # ---------------------------------------------------------------------- attention
 _RPE2_CACHE = {}        # (id(table), depth) -> (weakref to table, version, expanded table)
 

@@ -106,20 +106,20 @@ class WindowPlan:
         self.rt_offset: Dict[int, int] = lay['rt_offset']
         dev = self.device
         self.meta = {d: ops.token_meta(octree.nkeys[d], d) for d in range(start_depth, max_depth + 1)}
-        self.seq_rows = torch.from_numpy(lay['seq_rows']).to(dev, non_blocking=True)
-        self.seq_off = torch.from_numpy(lay['seq_off']).to(dev, non_blocking=True)
+        # the small host-built index arrays travel in two copies (int32 | int64), not one blocking pageable copy each
+        i32 = torch.from_numpy(np.concatenate([lay['seq_rows'], lay['seq_off']])).to(dev, non_blocking=True)
+        self.seq_rows, self.seq_off = i32[:lay['seq_rows'].size], i32[lay['seq_rows'].size:]
         self.max_seq_len = int(np.diff(lay['seq_off']).max()) if self.B > 0 else 0
-        # per-cloud row offsets of the token stream (attentional pooling segments)
+        # per-cloud row offsets of the token stream (attentional pooling segments) and the padded gather index of the
+        # pooling head (built on the device: hfl_pad_index)
         self.cloud_off = {}
         self.pad_index = {}
         nne = octree.batch_nnum_nempty.numpy().astype(np.int64)
-        for d in self.pyramid_depths:
-            off = np.concatenate([[0], np.cumsum(nne[d])])
-            self.cloud_off[d] = torch.from_numpy(off).to(dev, non_blocking=True)
-            nmax = int(nne[d].max())
-            ar = np.arange(nmax, dtype=np.int64)[None, :]
-            idx = np.where(ar < nne[d][:, None], off[:-1, None] + ar, int(off[-1]))   # sentinel = zero row
-            self.pad_index[d] = torch.from_numpy(np.ascontiguousarray(idx.reshape(-1))).to(dev, non_blocking=True)
+        offs = [np.concatenate([[0], np.cumsum(nne[d])]) for d in self.pyramid_depths]
+        i64 = torch.from_numpy(np.concatenate(offs)).to(dev, non_blocking=True) if offs else None
+        for j, d in enumerate(self.pyramid_depths):
+            self.cloud_off[d] = i64[j * (self.B + 1):(j + 1) * (self.B + 1)]
+            self.pad_index[d] = ops.pad_index(self.cloud_off[d], self.B, int(nne[d].max()))
         self.window_stats = {}
         if adape_mode is not None:
             if adape_mode != 'cov':
@@ -147,10 +147,8 @@ class WindowPlan:
         """(B * Nmax) gather index of a depth's rows, cloud by cloud, sentinel = one-past-the-end (a zero row)."""
         if depth not in self.pad_index:
             nne = self.octree.batch_nnum_nempty.numpy().astype(np.int64)[depth]
-            off = np.concatenate([[0], np.cumsum(nne)])
-            ar = np.arange(int(nne.max()), dtype=np.int64)[None, :]
-            idx = np.where(ar < nne[:, None], off[:-1, None] + ar, int(off[-1]))
-            self.pad_index[depth] = torch.from_numpy(np.ascontiguousarray(idx.reshape(-1))).to(self.device)
+            off = torch.from_numpy(np.concatenate([[0], np.cumsum(nne)])).to(self.device)
+            self.pad_index[depth] = ops.pad_index(off, self.B, int(nne.max()))
         return self.pad_index[depth]
 
     def cloud_count(self, depth: int):
@@ -174,6 +172,19 @@ class WindowPlan:
                 tok = torch.cat([tok, own.clamp(max=self.B - 1)])
             cache[key] = tok
         return cache[key]
+
+    def token_window(self, depth: int):
+        """(win (n_tokens,) int64, keep (n_tokens, 1) float): the window of every token (dilation 1) and 1 where the token
+        belongs to the window's owner cloud, 0 elsewhere -- the reference's `~rt_init_mask` (models/octree.py:143-145;
+        the owner is the smallest batch id of the window = that of its first token)."""
+        cache = self.__dict__.setdefault('_token_window', {})
+        if depth not in cache:
+            nt = self.n_tokens[depth]
+            tok = self.meta[depth][:nt, 1].long()
+            win = torch.arange(nt, device=self.device) // self.K
+            keep = (tok == tok[win * self.K]).to(torch.float32).unsqueeze(1)
+            cache[depth] = (win, keep)
+        return cache[depth]
 
     def relay_cloud(self):
         """cloud index of every row of the concatenated relay-token matrix (all pyramid depths)."""

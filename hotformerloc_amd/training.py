@@ -36,20 +36,21 @@ def _stage1_numerics(model, phase):
 
 
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20,
-                        force: bool = False):
+                        force: bool = False, return_flags: bool = False):
     """Sum `p.grad` over the ranks of `group` in flat buckets of ~bucket_bytes (xGMI is point to point:
     a ring all-reduce is per-link bound, so few large messages; the 141 MB of fp32 gradients are 3 buckets).
     Every rank must issue the same collectives, so a parameter without a gradient on this rank contributes
     zeros -- but a parameter that received no gradient on ANY rank keeps `grad = None`, exactly as the
     single-process reference step leaves it (AdamW skips such parameters: no weight decay, no moment update;
-    `training/trainer.py:344-362`).  `force`: issue the collectives at world size 1 too (tests)."""
+    `training/trainer.py:344-362`).  `force`: issue the collectives at world size 1 too (tests).
+    `return_flags`: return the per-parameter "has a gradient on some rank" list (None when nothing was reduced)."""
     if not dist.is_available() or not dist.is_initialized():
-        return
+        return None
     if dist.get_world_size(group) == 1 and not force:
-        return
+        return None
     params = [p for p in params if p.requires_grad]
     if not params:
-        return
+        return None
     dev = params[0].device
     # which parameters have a gradient somewhere: one small all-reduce of a flag vector
     has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=dev)
@@ -80,16 +81,165 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
         if size >= bucket_bytes:
             flush()
     flush()
+    return anywhere if return_flags else None
+
+
+class OverlappedGradReducer:
+    """Sum of the parameter gradients over the ranks, OVERLAPPED with the backward pass that produces them (the seam is
+    `training/trainer.py:344-362`: stage 3 back-propagates minibatch by minibatch, the optimizer steps afterwards; the
+    reference is single-process and has no reduction at all).
+
+    Design for xGMI (point-to-point links: a ring all-reduce is per-link bound, so few, large messages):
+      * static buckets of ~bucket_bytes over the parameters in REVERSE registration order (the order their gradients become
+        final in the backward); a bucket is flattened and all-reduced asynchronously on a side stream as soon as every used
+        parameter in it has its final gradient (`register_post_accumulate_grad_hook`), while the backward continues;
+      * buckets are launched strictly IN ORDER on every rank, whatever the timing, so the sequence of collectives is the
+        same everywhere by construction; what is still missing at `finish()` goes out then, in the same order;
+      * which parameters are "used" (receive a gradient on some rank) is not knowable before a backward: the first step of a
+        reducer runs the non-overlapped `allreduce_gradients` and records the all-reduced has-gradient flags; later steps
+        assume that set, contribute zeros for a used parameter that has no gradient on this rank, keep `grad = None` for
+        the others, and re-check the flags at `finish()` (one small all-reduce): if the set changed, the stragglers are
+        reduced on the spot and the set is updated.
+    Only the LAST backward of a step may launch (`arm()` before it): earlier minibatches only accumulate."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.bucket_bytes = bucket_bytes
+        self.used = None                       # per parameter: receives a gradient on some rank (learnt on the first step)
+        self.buckets: List[List[int]] = []
+        self.armed = False
+        self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
+        self._stream = None
+        self.launched_during_backward = 0      # diagnostics of the last step
+
+    # -- bookkeeping -------------------------------------------------------------------------
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _build_buckets(self):
+        self.buckets, cur, size = [], [], 0
+        for i in reversed(range(len(self.params))):
+            if not self.used[i]:
+                continue
+            cur.append(i)
+            size += self.params[i].numel() * self.params[i].element_size()
+            if size >= self.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if self.armed:
+                self._ready[i] = True
+                self._launch_ready()
+        return hook
+
+    def arm(self):
+        """Call right before the LAST backward of the step: from here on a parameter's gradient is final when its hook fires."""
+        if not self._active() or self.used is None:
+            return
+        self.armed = True
+        self._ready = [False] * len(self.params)
+        self._next = 0
+        self._works = []
+        self.launched_during_backward = 0
+
+    # -- launching ---------------------------------------------------------------------------
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and all(self._ready[i] for i in self.buckets[self._next]):
+            self._launch(self._next)
+            self._next += 1
+            self.launched_during_backward += 1
+
+    def _launch(self, b):
+        idx = self.buckets[b]
+        dev = self.params[idx[0]].device
+        grads = []
+        for i in idx:
+            p = self.params[i]
+            if p.grad is None:                 # used elsewhere, untouched here: zeros
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        if dev.type == 'cuda':
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=dev)
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._stream):
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((work, flat, grads))
+
+    def finish(self):
+        """After the last backward: send what is left (same order on every rank), wait, write the sums back, verify the set."""
+        if not self._active():
+            self.armed = False
+            return
+        if self.used is None:                  # first step: learn the set with the non-overlapped reduction
+            has = allreduce_gradients(self.params, self.group, self.bucket_bytes, return_flags=True)
+            self.used = has
+            self._build_buckets()
+            return
+        if not self.armed:                     # arm() was not called: plain reduction
+            allreduce_gradients(self.params, self.group, self.bucket_bytes)
+            return
+        self.armed = False
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+            self._next += 1
+        dev = self.params[0].device
+        for work, flat, grads in self._works:
+            work.wait()
+            ctx = torch.cuda.stream(self._stream) if dev.type == 'cuda' else _null()
+            with ctx:
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+        if dev.type == 'cuda':
+            torch.cuda.current_stream(dev).wait_stream(self._stream)
+        self._works = []
+        # parameters outside the assumed set that DID get a gradient somewhere this step (the set changed): reduce them now
+        extra = [i for i, u in enumerate(self.used) if not u]
+        if extra:
+            has = torch.tensor([0.0 if self.params[i].grad is None else 1.0 for i in extra], dtype=torch.float32, device=dev)
+            dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.group)
+            late = [i for i, h in zip(extra, (has > 0).tolist()) if h]
+            if late:
+                allreduce_gradients([self.params[i] for i in late], self.group, self.bucket_bytes)
+                for i in late:
+                    self.used[i] = True
+                self._build_buckets()
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def multistaged_training_step(model: torch.nn.Module, minibatches: List[dict], positives_mask: torch.Tensor,
                               negatives_mask: torch.Tensor, loss_fn: Callable, optimizer=None,
                               phase: str = 'train', n_total: Optional[int] = None, group=None,
-                              force_collectives: bool = False) -> dict:
+                              force_collectives: bool = False, reducer: Optional[OverlappedGradReducer] = None) -> dict:
     """One step.  `minibatches`: this rank's batch dicts ({'octree': ...}, already on the device with
     neighbours built), in global order; masks are (B_total, B_total) over the whole batch.  Returns the
     loss statistics (identical on every rank).  `n_total`: global batch size (default B_local * world).
-    `force_collectives`: issue the all-gather and the gradient all-reduce at world size 1 too (single-GPU RCCL test)."""
+    `force_collectives`: issue the all-gather and the gradient all-reduce at world size 1 too (single-GPU RCCL test).
+    `reducer`: an `OverlappedGradReducer` over model.parameters() kept across steps: the gradient all-reduce then runs bucket
+    by bucket behind the last minibatch's backward instead of after it."""
     assert phase in ('train', 'val')
     model.train() if phase == 'train' else model.eval()
     # ---- stage 1 ------------------------------------------------------------------------------
@@ -119,11 +269,16 @@ def multistaged_training_step(model: torch.nn.Module, minibatches: List[dict], p
     else:
         model.zero_grad(set_to_none=True)
     i = 0
-    for mb in minibatches:
+    for k, mb in enumerate(minibatches):
         y = model(mb)['global']
+        if reducer is not None and k == len(minibatches) - 1:
+            reducer.arm()                                  # gradients are final from here on: buckets may leave
         y.backward(gradient=grad_local[i:i + y.shape[0]])
         i += y.shape[0]
-    allreduce_gradients(model.parameters(), group, force=force_collectives)
+    if reducer is not None:
+        reducer.finish()
+    else:
+        allreduce_gradients(model.parameters(), group, force=force_collectives)
     if optimizer is not None:
         optimizer.step()
     return stats

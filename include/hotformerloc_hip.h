@@ -169,6 +169,12 @@ int hfl_octree_gather(float* out, const float* data, const int32_t* neigh, int64
 int64_t hfl_tap_lists_workspace(int64_t rows, int taps);
 int hfl_tap_lists(int32_t* src, int32_t* slot, int32_t* edges, const int32_t* table, int64_t rows, int taps,
                   void* workspace, hfl_stream_t stream);
+/* Row tiles of the grouped tap GEMM (section 9b, hfl_linear_x3_grouped) from the device-side tap edges hfl_tap_lists wrote:
+ * tiles (n_tiles, 3) int32 = {first pair, pairs (<= tile_rows), tap * w_rows}, n_tiles = sum_k ceil(pairs_k / tile_rows). */
+int hfl_tap_tiles(int32_t* tiles, const int32_t* edges, int taps, int tile_rows, int w_rows, hfl_stream_t stream);
+/* Padded gather index of a ragged per-cloud row stream (pooling head, models/layers/pooling.py:209-233): out (batch * nmax)
+ * int64, row_off[b] + j inside cloud b, row_off[batch] (a zero row the caller appends) beyond it. */
+int hfl_pad_index(int64_t* out, const int64_t* row_off, int batch, int64_t nmax, hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Windowed multi-head attention over z-order octree windows

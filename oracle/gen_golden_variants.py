@@ -32,6 +32,15 @@ VARIANTS = {
     'disable_rt':      ('wild-places', {'disable_rt': 'True'}, [(3000, 'ball'), (2500, 'forest')], 66),
     'xcpe':            ('cs-wild-places', {'xCPE': 'True'}, [(3000, 'forest'), (2000, 'ball')], 67),
     'layer_scale':     ('wild-places', {'layer_scale': '0.1'}, [(3000, 'ball'), (2500, 'forest')], 68),
+    # round 3: the rest of SURVEY 8 f4
+    'ct_prop':         ('wild-places', {'ct_propagation': 'True'}, [(3000, 'ball'), (2500, 'forest')], 69),
+    'ct_prop_scale':   ('cs-wild-places', {'ct_propagation': 'True', 'ct_propagation_scale': '0.5'},
+                        [(4096, 'forest'), (3000, 'ball')], 70),
+    'level_channels':  ('wild-places', {'channels': '128,256,192,128', 'num_heads': '8,16,12,8', 'feature_size': '256'},
+                        [(3000, 'ball'), (2500, 'forest'), (1800, 'ball')], 71),
+    'level_channels_gem': ('wild-places', {'channels': '128,256,192,128', 'num_heads': '8,16,12,8', 'feature_size': '256',
+                                           'pooling': 'PyramidOctGeM'}, [(3000, 'ball'), (2500, 'forest')], 72),
+    'no_input_downsample': ('wild-places', {'downsample_input_embeddings': 'False'}, [(1500, 'ball'), (1200, 'forest')], 73),
 }
 DEPTH = {'wild-places': 7, 'cs-wild-places': 7}
 

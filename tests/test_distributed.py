@@ -187,3 +187,88 @@ def test_allreduce_keeps_grad_none_for_parameters_unused_on_every_rank(tmp_path)
     assert r0['never'] is None and r1['never'] is None
     assert r0['sometimes'] is not None and torch.equal(r0['sometimes'], r1['sometimes'])
     assert r0['sometimes'].abs().sum() > 0
+
+
+# ---------------------------------------------------------------- overlapped gradient reduction (round 3)
+def _overlap_worker(rank, world, port, n_total, result_dir):
+    from hotformerloc_amd.training import OverlappedGradReducer, multistaged_training_step
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        x, pos, neg = _toy_data(n_total)
+        lo, hi = shard_bounds(n_total, rank, world)
+        mine = x[lo:hi]
+        half = (hi - lo + 1) // 2
+        minibatches = [{'x': mine[:half]}, {'x': mine[half:]}] if hi - lo > 1 else [{'x': mine}]
+        model = _ToyEncoderWithUnused()
+        model.use_sometimes = rank == 0
+        reducer = OverlappedGradReducer(model.parameters(), bucket_bytes=64)     # tiny buckets: several per step
+        out = []
+        for step in range(3):
+            if step == 2:
+                model.use_sometimes = rank == world - 1          # the set of touched parameters moves to another rank
+            stats = multistaged_training_step(model, minibatches, pos, neg, _toy_listwise_loss, n_total=n_total,
+                                              reducer=reducer)
+            out.append({'grads': [None if p.grad is None else p.grad.clone() for p in model.parameters()],
+                        'loss': stats['loss'], 'during_backward': reducer.launched_during_backward,
+                        'buckets': len(reducer.buckets)})
+        reducer.close()
+        torch.save(out, os.path.join(result_dir, 'ov_%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_total', [(2, 8), (4, 10)])
+def test_overlapped_gradient_reduction_matches_single_process(tmp_path, world, n_total):
+    """OverlappedGradReducer behind the multi-staged step (gloo; world 4 with UNEVEN shards 3,3,2,2): step 0 learns which
+    parameters receive gradients (plain reduction), steps 1-2 reduce bucket by bucket from the gradient hooks of the last
+    backward -- same sums as one process back-propagating the whole batch, identical on every rank, `grad = None` kept for a
+    parameter no rank uses, zeros contributed for one only some ranks use."""
+    mp.spawn(_overlap_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, 'ov_%d.pt' % r)) for r in range(world)]
+    x, pos, neg = _toy_data(n_total)
+    for step in range(3):
+        # single-process gradients: `sometimes` is added on the rows of the rank that uses it
+        ref = _ToyEncoderWithUnused()
+        user = 0 if step < 2 else world - 1
+        lo, hi = shard_bounds(n_total, user, world)
+        y = ref.b(torch.tanh(ref.a(x)))
+        y = torch.cat([y[:lo], y[lo:hi] + ref.sometimes, y[hi:]], 0)
+        loss, _ = _toy_listwise_loss(torch.nn.functional.normalize(y, dim=1), pos, neg)
+        loss.backward()
+        want = [p.grad for p in ref.parameters()]
+        for r in range(world):
+            got = res[r][step]
+            assert abs(got['loss'] - loss.item()) < 1e-6
+            for g, w, (name, _) in zip(got['grads'], want, ref.named_parameters()):
+                if name == 'never_used':
+                    assert g is None
+                else:
+                    assert g is not None and torch.allclose(g, w, atol=1e-6), (step, r, name)
+            for g, g0 in zip(got['grads'], res[0][step]['grads']):
+                assert (g is None and g0 is None) or torch.equal(g, g0)
+        if step >= 1:                                   # overlapped steps really launched buckets from the hooks
+            assert res[0][step]['buckets'] >= 2 and res[0][step]['during_backward'] >= 1
+
+
+def test_bench_rank_slices_concatenate_to_the_global_batch():
+    """bench.py gives rank r the clouds [r B, (r + 1) B) of ONE global synthetic batch (weak scaling): the
+    per-rank slices concatenated equal the single-process batch of N B clouds, in order, for both workloads."""
+    import importlib.util
+    import types
+    import numpy as np
+    from hotformerloc_amd import synthetic as syn
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    params = types.SimpleNamespace(coordinates='cylindrical')
+    for pmax in (None, 2048):
+        args = types.SimpleNamespace(batch=3, points=512, points_max=pmax)
+        world = 2
+        parts = [bench.bench_clouds(syn, params, args, r) for r in range(world)]
+        whole = bench.bench_clouds(syn, params, types.SimpleNamespace(batch=6, points=512, points_max=pmax), 0)
+        flat = [c for part in parts for c in part]
+        assert len(flat) == len(whole) == 6
+        for a, b in zip(flat, whole):
+            assert a.shape == b.shape and np.array_equal(a, b)

@@ -153,14 +153,22 @@ def test_tap_lists_match_tap_major_compaction(rows, taps):
 
 
 def test_octree_sparse_taps_built_with_the_neighbour_tables():
-    """construct_all_neigh() prepares the live-tap lists of the octree convolutions (one host read for all of them);
-    nothing is left to build -- and no device->host sync -- inside model(batch)."""
+    """construct_all_neigh() launches the live-tap lists of all octree convolutions and starts ONE asynchronous device->host
+    read of their counts; the first sparse_taps() collects it for every table at once, nothing else is built later."""
     clouds = syn.make_clouds(9, 3, 3000, 'cartesian')
     o = build_batch_octree(clouds, 7, 2, DEV, construct_neigh=True)
+    keys = [(6, '333', 1), (5, '333', 1), (7, '222', 2), (6, '222', 2), (5, '222', 2), (4, '222', 2), (3, '222', 2)]
+    assert set(o.__dict__['_taps_pending'][0]) >= set(keys)
+    o.sparse_taps(*keys[0])
+    assert '_taps_pending' not in o.__dict__
     cache = o.__dict__['_sparse_taps']
-    for key in [(6, '333', 1), (5, '333', 1), (7, '222', 2), (6, '222', 2), (5, '222', 2), (4, '222', 2), (3, '222', 2)]:
+    for key in keys:
         assert key in cache, key
         src, slot, edges = cache[key]
+        tiles = o.tap_tiles(*key, 128).cpu().numpy()              # device-built row tiles of the grouped tap GEMM
+        e = np.asarray(edges)
+        want = [(a, min(128, e[k + 1] - a), k * 128) for k in range(len(e) - 1) for a in range(e[k], e[k + 1], 128)]
+        assert tiles.shape == (len(want), 3) and (tiles == np.asarray(want, dtype=np.int32).reshape(-1, 3)).all(), key
         table = o.get_neigh(key[0], key[1], key[2], nempty=True)
         live = table >= 0
         assert edges[-1] == int(live.sum()) == src.shape[0] and len(edges) == table.shape[1] + 1
