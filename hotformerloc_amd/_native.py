@@ -90,8 +90,6 @@ SIGNATURES = {
     'hfl_octree_gather_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     'hfl_relay_token_init_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                          c_int64, c_void_p]),
-    'hfl_linear_bf16x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                  c_int, c_int, c_int, c_void_p]),
     'hfl_linear_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'hfl_layer_norm_split2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_float, c_void_p]),

@@ -109,160 +109,6 @@ __device__ __forceinline__ void att_store_row4(char* out_b, uint32_t orow, int C
   }
 }
 
-// T = number of 16-wide tiles of the padded sequence (K/16 + G), G = relay tokens
-template <int T, int G>
-__global__ void __launch_bounds__(1024)
-window_attn_kernel(const WinParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int LP = T * 16;                       // padded sequence length
-  const int H = p.H, K = p.K;
-  const int C = H * 16;
-  const int nrpe = 2 * p.bnd + 1;
-  int64_t* s_row = reinterpret_cast<int64_t*>(smem);                   // [LP]  qkv/out row
-  uint32_t* s_xyz = reinterpret_cast<uint32_t*>(s_row + LP);           // [LP]
-  int* s_bid = reinterpret_cast<int*>(s_xyz + LP);                     // [LP]  (-1 = dead)
-  float* s_tab = reinterpret_cast<float*>(s_bid + LP);                 // [H][3*nrpe]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, h = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
-
-  if (p.table)
-    for (int i = tid; i < 3 * nrpe * H; i += blockDim.x) {
-      const int r = i / H, hh = i % H;               // table is (3*nrpe, H) row-major
-      s_tab[hh * 3 * nrpe + r] = p.table[i];
-    }
-  const float* tab = s_tab + h * 3 * nrpe + p.bnd;   // index by clamped delta directly
-
-  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
-    __syncthreads();
-    // sequence position j: j < K window token, j == K relay token (G), else dead
-    for (int j = tid; j < LP; j += blockDim.x) {
-      int bid = -1;
-      uint32_t xyz = 0;
-      int64_t row = 0;
-      if (j < K) {
-        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
-                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
-        if (t < p.n_tokens) {
-          xyz = p.meta[2 * t];
-          bid = (int)p.meta[2 * t + 1];
-          row = t;
-        }
-      } else if (G > 0 && j == K) {
-        const int64_t t0 = (int64_t)w * K;            // owner = batch id of the first token
-        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
-        row = p.rt_row0 + w;
-      }
-      s_xyz[j] = xyz;
-      s_bid[j] = bid;
-      s_row[j] = row;
-    }
-    __syncthreads();
-
-    // ---- K, V fragments of this head ------------------------------------------------
-    float4 kf[T];
-    float vf[T][4];
-#pragma unroll
-    for (int kt = 0; kt < T; ++kt) {
-      const int j = kt * 16 + c;
-      kf[kt] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (s_bid[j] >= 0)
-        kf[kt] = *reinterpret_cast<const float4*>(p.qkv + s_row[j] * 3 * C + C + h * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int jv = kt * 16 + 4 * g + r;
-        vf[kt][r] = s_bid[jv] >= 0 ? p.qkv[s_row[jv] * 3 * C + 2 * C + h * 16 + c] : 0.f;
-      }
-    }
-
-    // ---- one 16-query tile at a time ---------------------------------------------
-#pragma unroll 1
-    for (int qt = 0; qt < T; ++qt) {
-      const int qi = qt * 16 + c;                       // this lane's query
-      const int qbid = s_bid[qi];
-      const uint32_t qxyz = s_xyz[qi];
-      const bool q_is_rt = (G > 0) && qi == K;
-      float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qbid >= 0)
-        qf = *reinterpret_cast<const float4*>(p.qkv + s_row[qi] * 3 * C + h * 16 + 4 * g);
-      const int qx = (int)(qxyz & 1023u), qy = (int)((qxyz >> 10) & 1023u), qz = (int)(qxyz >> 20);
-
-      f32x4 s[T];
-#pragma unroll
-      for (int kt = 0; kt < T; ++kt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf.w, acc, 0, 0, 0);
-        s[kt] = acc;
-      }
-
-      // bias + running max.  s[kt][r] is (key kt*16+4g+r, query qi)
-      float mx = kDeadValue;
-#pragma unroll
-      for (int kt = 0; kt < T; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kj = kt * 16 + 4 * g + r;
-          const int kbid = s_bid[kj];
-          float v = s[kt][r] * p.scale;
-          if (kbid < 0) {
-            v = kDeadValue;
-          } else {
-            if (kbid != qbid) v += kMaskValue;
-            const bool k_is_rt = (G > 0) && kj == K;
-            if (p.table && !k_is_rt && !q_is_rt) {
-              const uint32_t kx = s_xyz[kj];
-              int dx = qx - (int)(kx & 1023u);
-              int dy = qy - (int)((kx >> 10) & 1023u);
-              int dz = qz - (int)(kx >> 20);
-              dx = min(max(dx, -p.bnd), p.bnd);
-              dy = min(max(dy, -p.bnd), p.bnd);
-              dz = min(max(dz, -p.bnd), p.bnd);
-              v += tab[dx] + tab[nrpe + dy] + tab[2 * nrpe + dz];
-            }
-          }
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < T; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(s[kt][r] - mx);
-          s[kt][r] = e;
-          sum += e;
-        }
-      }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      const float inv = 1.0f / sum;
-
-      // O[query, d] = sum_keys P V : A = P (lane: query c, k-slot g), B = V (k-slot g, d = c)
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < T; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(s[kt][r] * inv, vf[kt][r], o, 0, 0, 0);
-      }
-      // o[r] is (query qt*16+4g+r, d = c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int oq = qt * 16 + 4 * g + r;
-        if (s_bid[oq] >= 0) p.out[s_row[oq] * C + h * 16 + c] = o[r];
-      }
-    }
-  }
-}
-
-
 // ----------------------------------------------------------------------------------
 // v2: same decomposition, instruction diet.  The v1 body spends ~44 VALU per score (unpack,
 // six min/max, address math, dead/relay branches) against 2 MFMA per 16 scores, so it is
@@ -1225,11 +1071,7 @@ static int launch_window(const WinParams& p, hipStream_t s) {
   int blocks = p.n_windows;
   const int cap = hfl_num_cus() * 4;
   if (blocks > cap) blocks = cap;
-  if (g_window_variant == 1) {
-    if (p.qkv_f16) return HFL_EINVAL;
-    const size_t lds = (p.table ? (size_t)p.H * 3 * nrpe * 4 : 0) + (size_t)LP * (4 + 4 + 8);
-    window_attn_kernel<T, G><<<blocks, p.H * 64, lds, s>>>(p);
-  } else {
+  {
     int hpw = g_window_heads_per_wg;             // heads (= waves) per workgroup, at most 4
     if (hpw < 1 || hpw > 4 || p.H % hpw != 0) hpw = (p.H % 4 == 0) ? 4 : (p.H % 2 == 0) ? 2 : 1;
     const size_t lds = (p.table ? (size_t)hpw * 3 * nrpe * 4 : 0) + (size_t)LP * (16 + 16 + 4);
@@ -1393,8 +1235,6 @@ relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
 extern "C" {
 
 extern "C" void hfl_internal_set_cpe_chunk(int rows);
-extern "C" void hfl_internal_set_cpe_variant(int v, int wgs);
-extern "C" void hfl_internal_set_linear_ablate(int v);
 /* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
 void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
@@ -1410,12 +1250,8 @@ int hfl_set_variant(const char* key, int value) {
     g_window_v2_wgs_per_cu = 16;
     g_window_heads_per_wg = 4;
     hfl_internal_set_window_bwd(2);
-    hfl_internal_set_linear_ablate(0);
     hfl_internal_set_x3_dbg(0);
     hfl_internal_set_x3_dbg(0x100);
-    hfl_internal_set_x3_dbg(0x200);
-    hfl_internal_set_x3_dbg(0x400);
-    hfl_internal_set_cpe_variant(0, 3);
     hfl_internal_set_cpe_chunk(0);
     return HFL_OK;
   }
@@ -1433,32 +1269,11 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_window_bwd(value);
     return HFL_OK;
   }
-  const char* k4 = "linear_ablate";
-  i = 0;
-  while (k4[i] != 0 && key[i] == k4[i]) ++i;
-  if (k4[i] == 0 && key[i] == 0) {
-    hfl_internal_set_linear_ablate(value);
-    return HFL_OK;
-  }
   const char* kx = "x3_dbg";
   i = 0;
   while (kx[i] != 0 && key[i] == kx[i]) ++i;
   if (kx[i] == 0 && key[i] == 0) {
     hfl_internal_set_x3_dbg(value);
-    return HFL_OK;
-  }
-  const char* k9 = "cpe_variant";
-  i = 0;
-  while (k9[i] != 0 && key[i] == k9[i]) ++i;
-  if (k9[i] == 0 && key[i] == 0) {
-    hfl_internal_set_cpe_variant(value, 0);
-    return HFL_OK;
-  }
-  const char* k10 = "cpe_lds_wgs_per_cu";
-  i = 0;
-  while (k10[i] != 0 && key[i] == k10[i]) ++i;
-  if (k10[i] == 0 && key[i] == 0) {
-    hfl_internal_set_cpe_variant(-1, value);
     return HFL_OK;
   }
   const char* k3 = "cpe_chunk_rows";

@@ -351,202 +351,6 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
 }
 
 
-// ------------------------------------------------------------------ fused CPE, LDS-staged gathers
-// The kernel above pulls 27 neighbour rows per output row through L2 (17.7 live taps x 1 KiB per row
-// at depth 4): it is bound by L2->L1 gather bandwidth, not HBM (PMC: 1.5x the algorithmic HBM bytes,
-// profiles/r01_c_summary.md).  Neighbours of z-order-adjacent rows overlap heavily: the 64 x 27 taps of
-// 64 consecutive rows touch ~186 distinct rows at depth 4 (6.1x fewer), ~116 at depth 5 (3.1x).
-// Here a workgroup owns 64 consecutive rows:
-//   1. de-duplicates their neighbour indices in an LDS hash table (atomicCAS insert, slot = arrival order);
-//   2. per 32-channel slice: stages the distinct rows' slice in LDS once (coalesced 128-B segments), then
-//      every (row, tap) reads its operand from LDS; taps without a neighbour use weight 0 (no divergence);
-//   3. keeps the C conv outputs of a row in the registers of its 4 lanes, then LayerNorm + residual.
-// Rows beyond the LDS capacity (never at the shipped configs: max 240 of 256 slots) are read from global.
-constexpr int kCpeRows = 64;          // rows per workgroup pass
-constexpr int kCpeSlice = 32;         // channels per LDS pass
-constexpr int kCpeCap = 256;          // distinct neighbour rows kept in LDS
-constexpr int kCpeHash = 1024;        // hash table entries (load factor <= 0.25)
-constexpr int kCpeStride = kCpeSlice + 4;   // floats per staged row (+16 B pad against bank conflicts)
-
-template <int C>
-__global__ void __launch_bounds__(256) cpe_fwd_lds_kernel(float* __restrict__ out, const float* __restrict__ x,
-                                   const float* __restrict__ weight, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, const int32_t* __restrict__ neigh,
-                                   int64_t n_rows, int K, float eps, int residual) {
-  constexpr int NS = C / kCpeSlice;                 // slices
-  __shared__ __attribute__((aligned(16))) float s_buf[kCpeCap * kCpeStride];
-  __shared__ __attribute__((aligned(16))) float s_w[kMaxTaps * kCpeSlice];
-  __shared__ int s_key[kCpeHash];
-  __shared__ unsigned short s_hslot[kCpeHash];
-  __shared__ unsigned short s_slot[kCpeRows * kMaxTaps];
-  __shared__ int s_list[kCpeCap];
-  __shared__ int s_count;
-
-  const int tid = threadIdx.x;
-  const int r = tid >> 2, q = tid & 3;              // row inside the pass, quarter of the slice (8 channels)
-  const int64_t n_pass = (n_rows + kCpeRows - 1) / kCpeRows;
-  const int entries = kCpeRows * K;
-
-  for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
-    const int64_t base = pass * kCpeRows;
-    const int64_t live_entries = (n_rows - base < kCpeRows ? n_rows - base : kCpeRows) * K;
-    __syncthreads();                                 // previous pass is done with every LDS array
-    for (int i = tid; i < kCpeHash; i += 256) s_key[i] = -1;
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-    // ---- 1. distinct neighbour rows of this pass --------------------------------------------------
-    int pos[(kCpeRows * kMaxTaps + 255) / 256];
-#pragma unroll
-    for (int i = 0; i < (kCpeRows * kMaxTaps + 255) / 256; ++i) {
-      const int e = tid + 256 * i;
-      pos[i] = -1;
-      if (e < entries && e < live_entries) {
-        const int idx = neigh[base * K + e];
-        if (idx >= 0) {
-          unsigned h = ((unsigned)idx * 2654435761u) >> 22;      // top 10 bits
-          for (;;) {
-            const int prev = atomicCAS(&s_key[h], -1, idx);
-            if (prev == -1) {
-              const int slot = atomicAdd(&s_count, 1);
-              if (slot < kCpeCap) {
-                s_list[slot] = idx;
-                s_hslot[h] = (unsigned short)slot;
-              } else {
-                s_hslot[h] = 0xFFFEu;                            // no room: that row stays in global
-              }
-              break;
-            }
-            if (prev == idx) break;
-            h = (h + 1) & (kCpeHash - 1);
-          }
-          pos[i] = (int)h;
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < (kCpeRows * kMaxTaps + 255) / 256; ++i) {
-      const int e = tid + 256 * i;
-      if (e < entries) s_slot[e] = pos[i] >= 0 ? s_hslot[pos[i]] : (unsigned short)0xFFFFu;
-    }
-    __syncthreads();
-    unsigned slots[kMaxTaps];                        // this row's 27 operand slots, for every slice
-#pragma unroll
-    for (int k = 0; k < kMaxTaps; ++k) slots[k] = k < K ? s_slot[r * K + k] : 0xFFFFu;
-    const int n_uniq = s_count < kCpeCap ? s_count : kCpeCap;
-    const int64_t h_row = base + r;
-    const bool live = h_row < n_rows;
-
-    // ---- 2. per channel slice: stage once, then 27 taps from LDS ----------------------------------
-    float4 acc[NS][2];
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl) {
-      __syncthreads();                               // slot table ready / previous slice consumed
-      {
-        // all requests of the slice first (one round trip), LDS stores after
-        float wv[(kMaxTaps * kCpeSlice + 255) / 256];
-        float4 xv[kCpeCap / 32];
-#pragma unroll
-        for (int i = 0; i < (kMaxTaps * kCpeSlice + 255) / 256; ++i) {
-          const int e = tid + 256 * i;
-          wv[i] = e < K * kCpeSlice ? weight[(e / kCpeSlice) * C + sl * kCpeSlice + (e % kCpeSlice)] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < kCpeCap / 32; ++i) {
-          const int u = (tid >> 3) + 32 * i;
-          const int src = u < n_uniq ? s_list[u] : 0;          // unconditional: keeps xv[] in registers
-          xv[i] = *reinterpret_cast<const float4*>(x + (int64_t)src * C + sl * kCpeSlice + 4 * (tid & 7));
-        }
-#pragma unroll
-        for (int i = 0; i < (kMaxTaps * kCpeSlice + 255) / 256; ++i) {
-          const int e = tid + 256 * i;
-          if (e < K * kCpeSlice) s_w[e] = wv[i];
-        }
-#pragma unroll
-        for (int i = 0; i < kCpeCap / 32; ++i) {
-          const int u = (tid >> 3) + 32 * i;
-          if (u < n_uniq) *reinterpret_cast<float4*>(&s_buf[u * kCpeStride + 4 * (tid & 7)]) = xv[i];
-        }
-      }
-      __syncthreads();
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-#pragma unroll
-      for (int k = 0; k < kMaxTaps; ++k) {
-        if (k >= K) break;
-        const unsigned slot = slots[k];
-        float4 w0 = *reinterpret_cast<const float4*>(&s_w[k * kCpeSlice + 8 * q]);
-        float4 w1 = *reinterpret_cast<const float4*>(&s_w[k * kCpeSlice + 8 * q + 4]);
-        float4 v0, v1;
-        if (slot == 0xFFFEu) {                       // overflow row (rare): straight from global
-          const int64_t ni = neigh[h_row * K + k];
-          v0 = *reinterpret_cast<const float4*>(x + ni * C + sl * kCpeSlice + 8 * q);
-          v1 = *reinterpret_cast<const float4*>(x + ni * C + sl * kCpeSlice + 8 * q + 4);
-        } else {
-          const unsigned a = slot < (unsigned)kCpeCap ? slot : 0u;
-          v0 = *reinterpret_cast<const float4*>(&s_buf[a * kCpeStride + 8 * q]);
-          v1 = *reinterpret_cast<const float4*>(&s_buf[a * kCpeStride + 8 * q + 4]);
-          if (slot == 0xFFFFu) { w0 = make_float4(0.f, 0.f, 0.f, 0.f); w1 = w0; }
-        }
-        a0 = hfl_fma4(w0, v0, a0);
-        a1 = hfl_fma4(w1, v1, a1);
-      }
-      acc[sl][0] = a0;
-      acc[sl][1] = a1;
-    }
-
-    // ---- 3. LayerNorm over the row (4 lanes x NS x 8 channels) + residual ---------------------------
-    float sum = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-      sum += ((acc[sl][0].x + acc[sl][0].y) + (acc[sl][0].z + acc[sl][0].w)) +
-             ((acc[sl][1].x + acc[sl][1].y) + (acc[sl][1].z + acc[sl][1].w));
-    const float inv_c = 1.0f / (float)C;
-    const float mean = hfl_group_sum<4>(sum) * inv_c;
-    float sq = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < NS; ++sl)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float4& a = acc[sl][j];
-        a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean;
-        sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-      }
-    const float rstd = 1.0f / sqrtf(hfl_group_sum<4>(sq) * inv_c + eps);
-    if (live) {
-#pragma unroll
-      for (int sl = 0; sl < NS; ++sl)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int ch = sl * kCpeSlice + 8 * q + 4 * j;
-          const float4 gm = *reinterpret_cast<const float4*>(gamma + ch);
-          const float4 bt = *reinterpret_cast<const float4*>(beta + ch);
-          const float4 a = acc[sl][j];
-          float4 y = make_float4(fmaf(a.x * rstd, gm.x, bt.x), fmaf(a.y * rstd, gm.y, bt.y),
-                                 fmaf(a.z * rstd, gm.z, bt.z), fmaf(a.w * rstd, gm.w, bt.w));
-          if (residual) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + h_row * C + ch);
-            y.x += xv.x; y.y += xv.y; y.z += xv.z; y.w += xv.w;
-          }
-          *reinterpret_cast<float4*>(out + h_row * C + ch) = y;
-        }
-    }
-  }
-}
-
-static int g_cpe_variant = 0;          // 0: direct gathers (default), 1: LDS-staged gathers (C = 128 / 256)
-static int g_cpe_lds_wgs_per_cu = 3;
-
-template <int C>
-static int launch_cpe_lds(float* out, const float* x, const float* w, const float* gamma,
-                          const float* beta, const int32_t* neigh, int64_t n, int K, float eps,
-                          int residual, hipStream_t s) {
-  const int64_t need = hfl_cdiv(n, kCpeRows);
-  const int64_t cap = (int64_t)hfl_num_cus() * g_cpe_lds_wgs_per_cu;
-  const int blocks = (int)(need < cap ? need : cap);
-  cpe_fwd_lds_kernel<C><<<blocks, 256, 0, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual);
-  HFL_RETURN_LAST_ERROR();
-}
-
 static int g_cpe_chunk_rows = 0;   // 0: rows interleaved over blocks; >0: contiguous chunk per block
 
 template <int TPR>
@@ -621,10 +425,6 @@ int hfl_cpe_forward(float* out, const float* x, const float* weight, const float
   if (n_rows < 0 || kngh <= 0 || kngh > kMaxTaps) return HFL_EINVAL;
   if (n_rows == 0) return HFL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (g_cpe_variant == 1 && channels == 256)
-    return launch_cpe_lds<256>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-  if (g_cpe_variant == 1 && channels == 128)
-    return launch_cpe_lds<128>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
   switch (channels) {
     case 256: return launch_cpe<64>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
     case 128: return launch_cpe<32>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
@@ -649,9 +449,4 @@ int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table
 
 /* internal tuning hook used by hfl_set_variant("cpe_chunk_rows", n) */
 void hfl_internal_set_cpe_chunk(int rows) { g_cpe_chunk_rows = rows; }
-void hfl_internal_set_cpe_variant(int v, int wgs) {
-  if (v >= 0) g_cpe_variant = v;
-  if (wgs > 0) g_cpe_lds_wgs_per_cu = wgs;
-}
-
 }  // extern "C"

@@ -61,9 +61,6 @@ struct X3Params {
 };
 
 static int g_x3_dbg = 0;
-static int g_x3_mt = 0;      // 8: force the 256-row tile (tools/x3_ablate.py); anything else: 128-row tile
-static int g_x3_wide = 0;     // 1: 128 x 256 tiles, 8 waves, two LDS stages, where out_features % 256 == 0
-static int g_x3_wide_min_tiles = 256;
 static int g_x3_nt = 0;     // measured: no end-to-end difference (the consumer kernel re-reads the output anyway)
 
 // Epilogue shared by the kernels below.  acc[i][j]: features 16 i + 4 fq .. +3 (registers) of row 16 j + frow of the
@@ -284,106 +281,6 @@ gemm_x3_kernel(const X3Params p) {
   x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
 }
 
-// ---- wide variant: 128 x 256 tile, 8 waves (2 x 4 of 64 x 64), TWO LDS stages, one barrier per k-step -----------------
-// Per k-step the workgroup fetches (128 + 256) x 128 B = 48 KiB for 128 x 256 x 32 MACs: 25 % less operand traffic per
-// MAC than the 128 x 128 tile, and the MFMA work of a step (2 waves per SIMD x 48 MFMAs x 16 cycles = 1536 cycles) is level
-// with its LDS-DMA time (~1650 cycles at the ~70 GB/s per CU an XCD's L2 serves).  One workgroup per CU (96 KiB of LDS):
-// the DMA of step t+1 is issued right after the barrier of step t into the other stage and has the whole step to land.
-template <int EPI>
-__global__ void __launch_bounds__(512, 1)
-gemm_x3_wide_kernel(const X3Params p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // 2 stages x (x tile 16 KiB | w tile 32 KiB)
-  constexpr int STAGE_B = (128 + 256) * 128;
-  constexpr int XTILE_B = 128 * 128;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wm = wave & 1;
-
-  int64_t wg = blockIdx.x;
-  {
-    const int64_t q = p.n_wg >> 3, r = p.n_wg & 7;
-    const int64_t xcd = wg & 7, loc = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int64_t m0 = (wg / p.tiles_n) * 128;
-  const int n0 = (int)(wg % p.tiles_n) * 256;
-  const int K = p.K;
-  const int nk = K >> 5;
-  const int64_t row_b = (int64_t)K * 4;
-
-  // staging: wave w moves rows [16w, 16w+16) of the x tile (2 instructions) and [32w, 32w+32) of the w tile (4)
-  const int srow = lane >> 3, sslot = lane & 7;
-  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
-  const int rows_valid = (int)((p.M - m0) < 128 ? (p.M - m0) : 128);
-  uint32_t xoff[2], woff[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 16 + i * 8 + srow;
-    const int t = sslot ^ ((row >> 1) & 7);
-    const int xr = row < rows_valid ? row : rows_valid - 1;
-    xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + srow;
-    woff[i] = (uint32_t)row * (uint32_t)row_b + (sslot ^ ((row >> 1) & 7)) * 16;
-  }
-  auto stage = [&](int kt) {
-    const unsigned char* xk = xbase + (int64_t)kt * 128;
-    const unsigned char* wk = wbase + (int64_t)kt * 128;
-    unsigned char* st = smem + (kt & 1) * STAGE_B;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
-                                       (__attribute__((address_space(3))) void*)(st + (wave * 16 + i * 8) * 128), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
-                                       (__attribute__((address_space(3))) void*)(st + XTILE_B + (wave * 32 + i * 8) * 128),
-                                       16, 0, 0);
-  };
-
-  const int frow = lane & 15, fq = lane >> 4;
-  const int rn0 = wn * 64 + frow, rm0 = wm * 64 + frow;
-  const int offw_hi = XTILE_B + rn0 * 128 + ((fq ^ ((rn0 >> 1) & 7)) << 4), offw_lo = offw_hi ^ 64;
-  const int offx_hi = rm0 * 128 + ((fq ^ ((rm0 >> 1) & 7)) << 4), offx_lo = offx_hi ^ 64;
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  stage(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();                       // stage kt has landed for every wave; everyone is done reading stage kt-1
-    if (kt + 1 < nk) stage(kt + 1);        // ... which is therefore free: refill it behind this step's reads and MFMAs
-    const unsigned char* st = smem + (kt & 1) * STAGE_B;
-    bf16x8 wh[4], wl[4], xh[4], xl[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      wh[i] = *reinterpret_cast<const bf16x8*>(st + offw_hi + i * 2048);
-      wl[i] = *reinterpret_cast<const bf16x8*>(st + offw_lo + i * 2048);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xh[j] = *reinterpret_cast<const bf16x8*>(st + offx_hi + j * 2048);
-      xl[j] = *reinterpret_cast<const bf16x8*>(st + offx_lo + j * 2048);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
-      }
-  }
-  __syncthreads();                         // the last stage is read: the epilogue reuses the LDS
-  x3_epilogue<EPI, 4>(p, acc, smem + wave * 8192, m0 + wm * 64, n0 + wn * 64, lane, p.M);
-}
-
 // fp32 (rows, C) [* row_scale[row]] -> split2 (rows, C/32, 2, 32) bf16
 __global__ void __launch_bounds__(256)
 split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const float* __restrict__ row_scale, int64_t n_rows,
@@ -414,9 +311,8 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const flo
 extern "C" {
 
 void hfl_internal_set_x3_dbg(int v) {
-  if (v >= 0x400) g_x3_wide = v & 1;        // 0x400 | 0 / 1
-  else if (v >= 0x200) g_x3_mt = v & 15;    // 0x200 | 0 / 4 / 8
-  else if (v >= 0x100) g_x3_nt = v & 3;     // 0x100 | nt bits
+  if (v >= 0x200) return;                   // (knobs of removed tile variants)
+  if (v >= 0x100) g_x3_nt = v & 3;          // 0x100 | nt bits
   else g_x3_dbg = v;
 }
 
@@ -485,17 +381,15 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   p.tiles = tiles;
   p.M = n_rows; p.N = out_features; p.K = in_features;
   p.tiles_n = narrow ? 1 : out_features / XT;
-  // 128-row tiles (3 workgroups per CU).  The 256-row instantiation moves 25 % fewer operand bytes per flop but holds
-  // 256 VGPRs (2 workgroups per CU) and measured 10 - 120 % slower on every shape of the model (tools/x3_ablate.py,
-  // DESIGN.md); it is only reachable through the probe knob.
-  const int mt = (g_x3_mt == 8 && tiles == nullptr) ? 8 : 4;
-  p.n_wg = (tiles != nullptr ? n_tiles : hfl_cdiv(n_rows, 32 * mt)) * p.tiles_n;
+  // 128-row tiles, 3 workgroups per CU.  (A 256-row tile and a 128 x 256 eight-wave tile were built and measured 10 - 120 %
+  // slower on every shape of the model: DESIGN.md section 4; they are gone from the library.)
+  p.n_wg = (tiles != nullptr ? n_tiles : hfl_cdiv(n_rows, 128)) * p.tiles_n;
   p.dbg = g_x3_dbg;
   p.nt = g_x3_nt;
   p.qk_channels = out_features / 3;
   p.q_scale = q_scale;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
-  const size_t lds = (size_t)(32 * mt + XT) * 128 + (size_t)(g_x3_dbg & 0xFF) * 1024;   // (+ probe: extra KiB to cut occupancy)
+  const size_t lds = (size_t)(128 + XT) * 128 + (size_t)(g_x3_dbg & 0xFF) * 1024;   // (+ probe: extra KiB to cut occupancy)
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define HFL_X3_LAUNCH(E, M)                                                                              \
   {                                                                                                      \
@@ -504,29 +398,8 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
     if (e != hipSuccess) return (int)e;                                                                  \
     gemm_x3_kernel<E, M><<<(unsigned)p.n_wg, 256, lds, s>>>(p);                                          \
   }
-  if (g_x3_wide && tiles == nullptr && out_features % 256 == 0 && hfl_cdiv(n_rows, 128) * (out_features / 256) >= g_x3_wide_min_tiles) {
-    p.tiles_n = out_features / 256;
-    p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
-    const size_t ldsw = (size_t)2 * (128 + 256) * 128;
-#define HFL_X3_WIDE(E)                                                                                   \
-  {                                                                                                      \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_wide_kernel<E>),            \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);           \
-    if (e != hipSuccess) return (int)e;                                                                  \
-    gemm_x3_wide_kernel<E><<<(unsigned)p.n_wg, 512, ldsw, s>>>(p);                                       \
-  }
-    if (epi == 4) HFL_X3_WIDE(4) else if (epi == 3) HFL_X3_WIDE(3) else if (epi == 2) HFL_X3_WIDE(2)
-    else if (epi == 1) HFL_X3_WIDE(1) else HFL_X3_WIDE(0)
-#undef HFL_X3_WIDE
-    HFL_RETURN_LAST_ERROR();
-  }
-  if (mt == 8 && epi <= 2) {
-    if (epi == 2) HFL_X3_LAUNCH(2, 8) else if (epi == 1) HFL_X3_LAUNCH(1, 8) else HFL_X3_LAUNCH(0, 8)
-  } else {
-    if (tiles == nullptr) p.n_wg = hfl_cdiv(n_rows, 128) * p.tiles_n;
-    if (epi == 4) HFL_X3_LAUNCH(4, 4) else if (epi == 3) HFL_X3_LAUNCH(3, 4) else if (epi == 2) HFL_X3_LAUNCH(2, 4)
-    else if (epi == 1) HFL_X3_LAUNCH(1, 4) else HFL_X3_LAUNCH(0, 4)
-  }
+  if (epi == 4) HFL_X3_LAUNCH(4, 4) else if (epi == 3) HFL_X3_LAUNCH(3, 4) else if (epi == 2) HFL_X3_LAUNCH(2, 4)
+  else if (epi == 1) HFL_X3_LAUNCH(1, 4) else HFL_X3_LAUNCH(0, 4)
 #undef HFL_X3_LAUNCH
   HFL_RETURN_LAST_ERROR();
 }

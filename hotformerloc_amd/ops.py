@@ -317,35 +317,6 @@ def split_weight(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
-def split_weight_pair(w: torch.Tensor):
-    """(N, K) fp32 -> (w_hi, w_lo) bf16 (N, K) each, for `linear_bf16x3`."""
-    w = w.detach().float()
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    return hi.contiguous(), lo.contiguous()
-
-
-def linear_bf16x3(x, w_hi, w_lo, bias=None, residual=None, gelu: bool = False):
-    """act(x W^T + bias) + residual with the hand-written split-bf16 GEMM (hfl_linear_bf16x3)."""
-    _dev(x, w_hi, w_lo, bias, residual)
-    k = x.shape[-1]
-    x2 = _f32c(x).view(-1, k)
-    n = w_hi.shape[0]
-    assert w_hi.dtype == torch.bfloat16 and w_hi.shape == (n, k) and w_lo.shape == (n, k)
-    out = torch.empty((x2.shape[0], n), dtype=torch.float32, device=x.device)
-    res_ptr = None
-    if residual is not None:
-        residual = _f32c(residual).view(-1, n)
-        res_ptr = residual.data_ptr()
-    with _timed('hfl_linear_bf16x3', x2.numel() * 4 + out.numel() * (8 if residual is not None else 4),
-                2 * x2.shape[0] * k * n):
-        check(_native.load().hfl_linear_bf16x3(
-            out.data_ptr(), x2.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(),
-            None if bias is None else _f32c(bias).data_ptr(), res_ptr, x2.shape[0], k, n,
-            int(bool(gelu)), _stream()), 'hfl_linear_bf16x3')
-    return out.view(x.shape[:-1] + (n,))
-
-
 def split_mm(a3: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     """fp32 (rows, N) = A3 @ W3^T: one hipBLASLt bf16 GEMM, fp32 accumulate and output,
     computing x_hi w_hi + x_hi w_lo + x_lo w_hi."""

@@ -332,17 +332,6 @@ int hfl_bias_gelu_split3(uint16_t* out, const float* x, const float* bias, int64
 /* A3 = split3(x) */
 int hfl_split3(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
 
-/* ------------------------------------------------------------------------
- * 9b. Fused fp32 Linear on the bf16 matrix cores (hand-written GEMM, csrc/linear.hip):
- *     out = act(x W^T + bias) + residual, x (rows, K) fp32 split to bf16 (hi, lo) in registers,
- *     W pre-split into w_hi / w_lo (N, K) bf16, three MFMAs per product, fp32 accumulate/output.
- *     K % 32 == 0, N % 128 == 0.  gelu != 0 applies the exact erf GELU before the residual add.
- *     bias / residual may be NULL; out may alias residual.
- * ---------------------------------------------------------------------- */
-int hfl_linear_bf16x3(float* out, const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
-                      const float* bias, const float* residual, int64_t n_rows, int in_features,
-                      int out_features, int gelu, hfl_stream_t stream);
-
 /* 9b. Hand-written split-precision Linear (csrc/gemm_x3.hip): y = x W^T [+ bias] [GELU] [+ residual] with
  * fp32-equivalent accuracy on the bf16 matrix cores (x_lo w_hi + x_hi w_lo + x_hi w_hi, fp32 accumulation).
  * Replaces torch.nn.Linear and the element-wise op after it (models/octformer_backbone.py:70,91,275-278;

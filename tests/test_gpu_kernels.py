@@ -826,27 +826,6 @@ def test_gather_and_relay_init_backward():
         (rd * wgt.to(DEV)).sum().backward()
         assert torch.allclose(xd.grad.cpu(), x.grad, atol=1e-6, rtol=1e-5)
 
-
-def test_linear_bf16x3_kernel():
-    """Hand-written split-bf16 GEMM with fused epilogues vs fp64 reference of F.linear."""
-    g = torch.Generator().manual_seed(11)
-    for n, cin, cout in ((1000, 256, 768), (4097, 128, 384), (777, 1024, 256), (130, 256, 1024), (5, 32, 128)):
-        x = torch.randn(n, cin, generator=g)
-        w = torch.randn(cout, cin, generator=g) * 0.05
-        b = torch.randn(cout, generator=g) * 0.1
-        r = torch.randn(n, cout, generator=g)
-        wh, wl = ops.split_weight_pair(w.to(DEV))
-        ref = x.double() @ w.double().t()
-        y = ops.linear_bf16x3(x.to(DEV), wh, wl).cpu().double()
-        assert ((y - ref).norm() / ref.norm()).item() < 1e-5, (n, cin, cout)
-        y = ops.linear_bf16x3(x.to(DEV), wh, wl, bias=b.to(DEV), residual=r.to(DEV)).cpu().double()
-        ref2 = ref + b.double() + r.double()
-        assert ((y - ref2).norm() / ref2.norm()).item() < 1e-5
-        y = ops.linear_bf16x3(x.to(DEV), wh, wl, bias=b.to(DEV), gelu=True).cpu().double()
-        ref3 = torch.nn.functional.gelu(ref + b.double())
-        assert ((y - ref3).norm() / ref3.norm()).item() < 1e-5
-
-
 def test_relay_attention_backward():
     from hotformerloc_amd import autograd as ag
     clouds = [syn.unit_ball_cloud(1500 + i, n) for i, n in enumerate([4096, 50, 3000])]

@@ -50,9 +50,12 @@ def test_unsupported_options_raise(tmp_path):
     from hotformerloc_amd.params import ModelParams
     with pytest.raises(NotImplementedError):
         model_factory(ModelParams(str(bad)))
-    bad.write_text(src.replace('ct_propagation = False', 'ct_propagation = True'))                                             # not built here
+    assert 'ct_size = 1' in src
+    bad.write_text(src.replace('ct_size = 1', 'ct_size = 2'))            # the reference's own model raises on it too
     with pytest.raises(NotImplementedError):
         model_factory(ModelParams(str(bad)))
+    bad.write_text(src.replace('ct_propagation = False', 'ct_propagation = True'))       # built since round 3
+    assert model_factory(ModelParams(str(bad))) is not None
 
 
 @pytest.mark.parametrize('case', ['wild_places_ragged', 'cs_wild_places_b2', 'oxford_b2', 'wild_places_b3'])

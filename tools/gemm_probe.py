@@ -38,11 +38,11 @@ for (M, K, N) in [(68167, 256, 768), (68167, 256, 256), (68167, 256, 1024), (681
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from hotformerloc_amd import ops
         if K % 32 == 0 and N % 128 == 0:
-            wh2, wl2 = ops.split_weight_pair(w)
-            fh = lambda: ops.linear_bf16x3(x, wh2, wl2, bias=b)
+            x2, w2 = ops.split2(x), ops.split2_weight(w)
+            fh = lambda: ops.linear_x3(x2, w2, bias=b)
             yh = fh(); th = timeit(fh)
             refb = torch.nn.functional.linear(x.double(), w.double(), b.double())
-            res['hfl_linear_bf16x3'] = (th, ((yh.double() - refb).norm() / refb.norm()).item())
+            res['hfl_linear_x3'] = (th, ((yh.double() - refb).norm() / refb.norm()).item())
     except Exception as ex:
         print('hfl linear failed', repr(ex)[:200])
     print('M=%d K=%d N=%d  fp32 %.3f ms (%.0f TF/s, err %.1e)' % (M, K, N, t32, fl / t32 / 1e9, e32), end='')
