@@ -41,7 +41,8 @@ class BlockWeights(ctypes.Structure):
 class BlockIO(ctypes.Structure):
     """hfl_block_io"""
     _fields_ = [('x_in', c_void_p), ('relay', c_void_p), ('out', c_void_p), ('arena', c_void_p),
-                ('neigh', c_void_p), ('tok_meta', c_void_p), ('n_rows', c_int64), ('n_tokens', c_int64)]
+                ('neigh', c_void_p), ('tok_meta', c_void_p), ('n_rows', c_int64), ('n_tokens', c_int64),
+                ('phase', c_int32)]
 
 
 # name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
@@ -84,6 +85,9 @@ SIGNATURES = {
     'hfl_split3': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_window_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
+    'hfl_window_attention_bwd_workspace': (c_int64, [ctypes.POINTER(WindowAttnDesc)]),
+    'hfl_window_attention_bwd_det': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             ctypes.POINTER(WindowAttnDesc), c_void_p, c_void_p]),
     'hfl_relay_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),
     'hfl_inverse_table': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),

@@ -21,6 +21,22 @@ def _desc(n_tokens, n_windows, patch_size, dilation, n_relay, n_heads, batch_siz
                           scale=16 ** -0.5, depth=depth)
 
 
+def _window_attention_bwd(dqkv, dtable, qkv, dout, tok_meta, table, desc):
+    """hfl_window_attention_bwd with the reproducible table gradient when the launch has one (partial tables in a workspace,
+    fixed-order sum), the float-atomic form otherwise (tables too large for the second-generation kernel)."""
+    lib = _native.load()
+    tp = None if table is None else table.data_ptr()
+    dp = None if dtable is None else dtable.data_ptr()
+    nbytes = int(lib.hfl_window_attention_bwd_workspace(ctypes.byref(desc))) if dtable is not None else 0
+    if nbytes > 0:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        check(lib.hfl_window_attention_bwd_det(dqkv.data_ptr(), dp, qkv.data_ptr(), dout.data_ptr(), tok_meta.data_ptr(), tp,
+                                               ctypes.byref(desc), ws.data_ptr(), ops._stream()), 'hfl_window_attention_bwd_det')
+    else:
+        check(lib.hfl_window_attention_bwd(dqkv.data_ptr(), dp, qkv.data_ptr(), dout.data_ptr(), tok_meta.data_ptr(), tp,
+                                           ctypes.byref(desc), ops._stream()), 'hfl_window_attention_bwd')
+
+
 class WindowAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, rpe_table, tok_meta, cfg):
@@ -40,10 +56,7 @@ class WindowAttentionFn(torch.autograd.Function):
         dtable = torch.zeros_like(table) if ctx.has_table else None
         d = _desc(cfg['n_tokens'], cfg['n_windows'], cfg['patch_size'], cfg['dilation'], cfg['n_relay'],
                   cfg['n_heads'], cfg['batch_size'], cfg.get('rt_row0', 0), cfg.get('depth', 0))
-        check(_native.load().hfl_window_attention_bwd(
-            dqkv.data_ptr(), dtable.data_ptr() if ctx.has_table else None, qkv.data_ptr(),
-            dout.data_ptr(), tok_meta.data_ptr(), table.data_ptr() if ctx.has_table else None,
-            ctypes.byref(d), ops._stream()), 'hfl_window_attention_bwd')
+        _window_attention_bwd(dqkv, dtable, qkv, dout, tok_meta, table if ctx.has_table else None, d)
         return dqkv, dtable, None, None
 
 
@@ -481,10 +494,7 @@ class LnAttnResidualX3Fn(torch.autograd.Function):
         dtable = torch.zeros_like(table) if ctx.has_table else None
         d = _desc(cfg['n_tokens'], cfg['n_windows'], cfg['patch_size'], cfg['dilation'], cfg['n_relay'],
                   cfg['n_heads'], cfg['batch_size'], cfg.get('rt_row0', 0), cfg.get('depth', 0))
-        check(_native.load().hfl_window_attention_bwd(
-            dqkv.data_ptr(), dtable.data_ptr() if ctx.has_table else None, qkv.data_ptr(), do.data_ptr(),
-            tok_meta.data_ptr(), table.data_ptr() if ctx.has_table else None, ctypes.byref(d), ops._stream()),
-            'hfl_window_attention_bwd')
+        _window_attention_bwd(dqkv, dtable, qkv, do, tok_meta, table if ctx.has_table else None, d)
         dqs = ops.split2(dqkv)
         dh = ops.linear_x3(dqs, _w2_cached(wqkv, True))
         dwqkv, dbqkv = _wgrad(dqs, hs, need[4], ctx.has_qkv_bias and need[5])

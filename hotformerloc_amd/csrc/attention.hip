@@ -1441,6 +1441,8 @@ struct WinBwdParams {
   int64_t rt_row0;
   int n_windows, K, D, H, bnd, batch;
   float scale;
+  float* dtable_part;     // second-generation kernel: per (grid column, head) partial tables (gridDim.x, H, 3*nrpe) instead of
+                          // float atomics into dtable (fixed-order reduction afterwards: reproducible); null = atomics
 };
 
 template <int T, int G>
@@ -2061,14 +2063,45 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
   }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
-  if (rpe && p.dtable != nullptr)
+  if (rpe && p.dtable_part != nullptr) {          // this wave's whole partial table, zeros included: summed in a fixed order
+    float* part = p.dtable_part + ((int64_t)blockIdx.x * H + h) * (3 * nrpe);
+    for (int i = lane; i < 3 * nrpe; i += 64) part[i] = dtabx[i];
+  } else if (rpe && p.dtable != nullptr)
     for (int i = lane; i < 3 * nrpe; i += 64) {
       const float v = dtabx[i];
       if (v != 0.f) atomicAdd(p.dtable + i * H + h, v);
     }
 }
 
+// dtable (3 nrpe, H) = sum over the grid columns of the partial tables, in column order
+__global__ void __launch_bounds__(256) window_dtable_reduce_kernel(float* __restrict__ dtable, const float* __restrict__ part,
+                                                                   int n_part, int H, int n3) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n3 * H) return;
+  const int i = idx / H, h = idx % H;
+  float acc = 0.f;
+  for (int b = 0; b < n_part; ++b) acc += part[((int64_t)b * H + h) * n3 + i];
+  dtable[idx] = acc;
+}
+
 static int g_window_bwd_variant = 2;
+
+// grid columns of the second-generation backward (must equal what launch_window_bwd2 computes)
+template <int T, int G, int NREP>
+static int window_bwd2_columns(int n_windows, int H, int bnd) {
+  constexpr int LP = T * 16, NP = (T + 1) / 2, LR = NP * 32, NHW = 2;
+  const int nrpe = 2 * bnd + 1;
+  const int tabf = (3 * nrpe + 3) & ~3;
+  const size_t scr_bytes = (size_t)NREP * tabf * 8 > 4096 ? (size_t)NREP * tabf * 8 : 4096;
+  const size_t lds = (size_t)LP * 36 + (size_t)NHW * (3 * LR * 64 + scr_bytes + 2 * tabf * 4);
+  if (H % NHW != 0) return 0;
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu < 1) return 0;
+  if (per_cu > 8) per_cu = 8;
+  int bx = n_windows;
+  const int capx = hfl_num_cus() * per_cu / (H / NHW) + 1;
+  return bx > capx ? capx : bx;
+}
 
 template <int T, int G, int NREP>
 static int launch_window_bwd2(const WinBwdParams& p, hipStream_t s) {
@@ -2089,6 +2122,10 @@ static int launch_window_bwd2(const WinBwdParams& p, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   window_attn_bwd2_kernel<T, G, NREP><<<grid, NHW * 64, lds, s>>>(p);
+  if (p.dtable_part != nullptr && p.dtable != nullptr && p.table != nullptr) {
+    const int n3 = 3 * nrpe;
+    window_dtable_reduce_kernel<<<(n3 * p.H + 255) / 256, 256, 0, s>>>(p.dtable, p.dtable_part, bx, p.H, n3);
+  }
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -2121,10 +2158,55 @@ static int launch_window_bwd(const WinBwdParams& p, hipStream_t s) {
 
 extern "C" void hfl_internal_set_window_bwd(int v) { g_window_bwd_variant = v; }
 
+static int window_bwd_columns(const hfl_window_attn_desc* d) {
+  if (d == nullptr || d->n_heads <= 0 || d->patch_size % 16 != 0 || d->n_relay < 0 || d->n_relay > 1) return 0;
+  if (g_window_bwd_variant < 2 || 3 * (2 * d->pos_bnd + 1) > 1023) return 0;
+  const int T = d->patch_size / 16 + d->n_relay;
+  const int W = d->n_windows, H = d->n_heads, b = d->pos_bnd;
+  if (d->n_relay == 0) {
+    switch (T) {
+      case 1: return window_bwd2_columns<1, 0, 1>(W, H, b);
+      case 2: return window_bwd2_columns<2, 0, 1>(W, H, b);
+      case 3: return window_bwd2_columns<3, 0, 1>(W, H, b);
+      case 4: return window_bwd2_columns<4, 0, 1>(W, H, b);
+      default: return 0;
+    }
+  }
+  switch (T) {
+    case 2: return window_bwd2_columns<2, 1, 1>(W, H, b);
+    case 3: return window_bwd2_columns<3, 1, 1>(W, H, b);
+    case 4: return window_bwd2_columns<4, 1, 1>(W, H, b);
+    case 5: return window_bwd2_columns<5, 1, 1>(W, H, b);
+    default: return 0;
+  }
+}
+
+extern "C" int64_t hfl_window_attention_bwd_workspace(const hfl_window_attn_desc* d) {
+  const int cols = window_bwd_columns(d);
+  return cols <= 0 ? 0 : (int64_t)cols * d->n_heads * 3 * (2 * d->pos_bnd + 1) * (int64_t)sizeof(float);
+}
+
+static int window_attention_bwd_impl(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
+                                     const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* d,
+                                     void* workspace, hfl_stream_t stream);
+
 extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv,
                                         const float* dout, const uint32_t* tok_meta,
                                         const float* rpe_table, const hfl_window_attn_desc* d,
                                         hfl_stream_t stream) {
+  return window_attention_bwd_impl(dqkv, drpe_table, qkv, dout, tok_meta, rpe_table, d, nullptr, stream);
+}
+
+extern "C" int hfl_window_attention_bwd_det(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
+                                            const uint32_t* tok_meta, const float* rpe_table,
+                                            const hfl_window_attn_desc* d, void* workspace, hfl_stream_t stream) {
+  if (workspace == nullptr || hfl_window_attention_bwd_workspace(d) <= 0) return HFL_EINVAL;
+  return window_attention_bwd_impl(dqkv, drpe_table, qkv, dout, tok_meta, rpe_table, d, workspace, stream);
+}
+
+static int window_attention_bwd_impl(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
+                                     const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* d,
+                                     void* workspace, hfl_stream_t stream) {
   if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
   if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
   if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
@@ -2134,6 +2216,7 @@ extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const fl
   p.n_tokens = d->n_tokens; p.rt_row0 = d->rt_row0; p.n_windows = d->n_windows;
   p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd; p.batch = d->batch_size;
   p.scale = d->scale;
+  p.dtable_part = static_cast<float*>(workspace);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int T = d->patch_size / 16 + d->n_relay;
   if (d->n_relay == 0) {

@@ -28,20 +28,38 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   uint16_t* h2 = reinterpret_cast<uint16_t*>(a + 7 * unit);
   uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
   int rc;
-  if (nt > 0) {
+  const int phase = io->phase;
+  if (phase < 0 || phase > 2) return HFL_EINVAL;
+  // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention)
+  if (phase != 2 && nt > 0) {
     rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
     if (rc != HFL_OK) return rc;
+    if (phase == 1) {           // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
+      rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, nt, C, w->eps, stream);
+      if (rc != HFL_OK) return rc;
+      rc = hfl_linear_x3_qkv(qkv, a2, w->qkv_w, w->qkv_b, nt, (int)C, (int)(3 * C), w->q_scale, stream);
+      if (rc != HFL_OK) return rc;
+    }
   }
+  if (phase == 1) return HFL_OK;
+  // ---- phase 2 (or the whole block)
   if (rows > nt) {
     const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
     hipError_t e = hipMemcpyAsync(x0 + nt * C, src, (size_t)(rows - nt) * C * 4, hipMemcpyDeviceToDevice,
                                   static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return (int)e;
   }
-  rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, rows, C, w->eps, stream);
-  if (rc != HFL_OK) return rc;
-  rc = hfl_linear_x3_qkv(qkv, a2, w->qkv_w, w->qkv_b, rows, (int)C, (int)(3 * C), w->q_scale, stream);
-  if (rc != HFL_OK) return rc;
+  {
+    // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phase 2)
+    const int64_t r0 = phase == 2 ? nt : 0, nr = rows - r0;
+    if (nr > 0) {
+      rc = hfl_layer_norm_split2(a2 + r0 * 2 * C, x0 + r0 * C, w->norm1_gamma, w->norm1_beta, nr, C, w->eps, stream);
+      if (rc != HFL_OK) return rc;
+      rc = hfl_linear_x3_qkv(qkv + r0 * 3 * C, a2 + r0 * 2 * C, w->qkv_w, w->qkv_b, nr, (int)C, (int)(3 * C), w->q_scale,
+                             stream);
+      if (rc != HFL_OK) return rc;
+    }
+  }
   rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);

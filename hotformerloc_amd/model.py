@@ -96,6 +96,7 @@ _TRAIN_MLP = os.environ.get('HFL_TRAIN_MLP', '1') != '0'          # fused fc1 ->
 _GROUPED_TAPS = os.environ.get('HFL_GROUPED_TAPS', '1') != '0'     # live-tap convolutions: one grouped x3 launch for all taps
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
+_EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
 
 
 def set_train_split(enabled: bool):
@@ -612,9 +613,10 @@ def _init_layer_scale(block, dim, layer_scale):
 _NATIVE_BLOCK = os.environ.get('HFL_NATIVE_BLOCK', '1') != '0'     # inference blocks as one native call (hfl_block_forward_x3)
 
 
-def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
-    """The block's inference forward as ONE native call, or None when this block / launch is not eligible (then the Python
-    sequence of the same kernels runs).  Same kernels, same order, same results; only the host work differs."""
+def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
+    """A prepared native call for the block's inference forward (ops.BlockCall), or None when this block / launch is not
+    eligible (then the Python sequence of the same kernels runs).  Same kernels, same order, same results; only the host
+    work differs."""
     att = block.attention
     C = att.dim
     if not (_NATIVE_BLOCK and _GEMM_MODE == 'x3' and _ATTN_F16 and _split_path(x_in) and ops.KernelTimer.active is None
@@ -656,7 +658,13 @@ def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
                           dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
                           batch_size=plan.B, scale=16 ** -0.5, depth=depth,
                           rpe_expanded=None if expanded is None else expanded.data_ptr())
-    return ops.block_forward_x3(w, keep, x_in, relay, plan.neigh(depth), plan.meta[depth], nt, desc)
+    return ops.BlockCall(w, keep, x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
+
+
+def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
+    """The block's inference forward as ONE native call, or None when not eligible (see _native_block_call)."""
+    call = _native_block_call(block, x_in, plan, depth)
+    return None if call is None else call.run(0, relay)
 
 
 class OctFormerBlock(nn.Module):
@@ -741,7 +749,9 @@ class HOTFormerBlock(nn.Module):
     def forward(self, buf, plan: WindowPlan, depth: int, relay=None):
         """buf: [tokens | relay rows] of this depth; `relay` (optional): this depth's relay rows as RTSA just produced
         them -- they replace buf's relay rows without a separate copy into buf first."""
-        out = self._forward(buf, plan, depth, relay)
+        return self._tail(self._forward(buf, plan, depth, relay), plan, depth)
+
+    def _tail(self, out, plan: WindowPlan, depth: int):
         if not self.propagate:
             return out
         # data + gamma * rt[window of the token], zero where the token's cloud is not the window's owner (rt_init_mask,
@@ -923,6 +933,11 @@ class HOTFormerStage(nn.Module):
             self._streams = [torch.cuda.Stream(device=device) for _ in range(self.num_pyramid_levels - 1)]
         return self._streams
 
+    def _rtsa_stream(self, device):
+        if self.__dict__.get('_rtsa_st') is None:
+            self.__dict__['_rtsa_st'] = torch.cuda.Stream(device=device)
+        return self.__dict__['_rtsa_st']
+
     def _forward_without_relay_tokens(self, data, plan: WindowPlan, depths):
         feats = {depths[0]: data}
         for j, d in enumerate(depths[:-1]):
@@ -965,7 +980,44 @@ class HOTFormerStage(nn.Module):
             nt = plan.n_tokens[d]
             return out, (self.up_projections[j][i](out[nt:]) if proj else out[nt:])
 
+        early = _EARLY_PHASE and _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda and not ckpt
         for i in range(self.num_blocks):                                # 593-633
+            if early:
+                # RTSA of iteration i only feeds the relay rows: what a block does with its TOKEN rows before the window
+                # attention (CPE, LN1, qkv projection: a third of the block) does not wait for it.  Every level issues that
+                # part on its own stream first, RTSA runs beside it on a stream of its own, the rest of the block follows
+                # once both are done -- the ~120 us chain of eight tiny RTSA launches leaves the critical path.
+                main = torch.cuda.current_stream()
+                side = self._side_streams(data.device)
+                rs = self._rtsa_stream(data.device)
+                sts = [main if (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) else side[j - 1]
+                       for j, d in enumerate(depths)]
+                calls = {}
+                for j, d in enumerate(depths):
+                    if sts[j] is not main:
+                        sts[j].wait_stream(main)
+                    with torch.cuda.stream(sts[j]):
+                        calls[d] = _native_block_call(self.hosa_blocks[j][i], bufs[d], plan, d)
+                        if calls[d] is not None:
+                            calls[d].run(1)
+                rs.wait_stream(main)
+                with torch.cuda.stream(rs):
+                    rt_all = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
+                fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
+                old = (dict(bufs), dict(rts))        # buffers other streams still read stay alive until the join
+                for j, d in enumerate(depths):
+                    sts[j].wait_stream(rs)
+                    with torch.cuda.stream(sts[j]):
+                        blk = self.hosa_blocks[j][i]
+                        rin = self.down_projections[j][i](fresh[d]) if proj else fresh[d]
+                        out = blk._tail(calls[d].run(2, rin), plan, d) if calls[d] is not None else blk(bufs[d], plan, d, rin)
+                        bufs[d] = out
+                        rts[d] = self.up_projections[j][i](out[nts[j]:]) if proj else out[nts[j]:]
+                for j in range(len(depths)):
+                    if sts[j] is not main:
+                        main.wait_stream(sts[j])
+                del calls, old, fresh, rt_all
+                continue
             rt_all = torch.cat([rts[d] for d in depths], 0)
             if ckpt:                                                    # 596-601
                 rt_all = checkpoint(self.rtsa_blocks[i], rt_all, plan, use_reentrant=False)

@@ -506,17 +506,35 @@ def block_forward_x3(weights, keep_alive, x_in, relay, neigh, tok_meta, n_tokens
     """One transformer block of the inference path in ONE native call (hfl_block_forward_x3): CPE -> [relay rows] -> LN1 ->
     qkv -> window attention -> proj + residual -> LN2 -> fc1 + GELU -> fc2 + residual.  `weights` = a filled
     `_native.BlockWeights` (see model._block_weights), `keep_alive` the tensors its pointers refer to."""
-    _dev(x_in, relay, neigh, tok_meta)
-    rows, c = x_in.shape
-    lib = _native.load()
-    out = torch.empty((rows, c), dtype=torch.float32, device=x_in.device)
-    arena = torch.empty(int(lib.hfl_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=x_in.device)
-    io = _native.BlockIO(x_in=x_in.data_ptr(), relay=None if relay is None else relay.data_ptr(), out=out.data_ptr(),
-                         arena=arena.data_ptr(), neigh=neigh.data_ptr(), tok_meta=tok_meta.data_ptr(), n_rows=rows,
-                         n_tokens=n_tokens)
-    check(lib.hfl_block_forward_x3(ctypes.byref(weights), ctypes.byref(io), ctypes.byref(desc), _stream()),
-          'hfl_block_forward_x3')
-    return out
+    call = BlockCall(weights, keep_alive, x_in, neigh, tok_meta, n_tokens, desc)
+    return call.run(0, relay)
+
+
+class BlockCall:
+    """The same block in two phases (hfl_block_io.phase): `run(1)` issues what reads token rows only (CPE, their LN1 and
+    qkv projection) -- the caller may do that while the relay-token self-attention of the iteration is still running on
+    another stream -- `run(2, relay)` the rest, on whatever stream is current at that call; `run(0, relay)` = both."""
+
+    def __init__(self, weights, keep_alive, x_in, neigh, tok_meta, n_tokens: int, desc: WindowAttnDesc):
+        _dev(x_in, neigh, tok_meta)
+        rows, c = x_in.shape
+        self.lib = _native.load()
+        self.weights, self.keep, self.desc = weights, (keep_alive, x_in, neigh, tok_meta), desc
+        self.out = torch.empty((rows, c), dtype=torch.float32, device=x_in.device)
+        self.arena = torch.empty(int(self.lib.hfl_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=x_in.device)
+        self.io = _native.BlockIO(x_in=x_in.data_ptr(), relay=None, out=self.out.data_ptr(), arena=self.arena.data_ptr(),
+                                  neigh=neigh.data_ptr(), tok_meta=tok_meta.data_ptr(), n_rows=rows, n_tokens=n_tokens,
+                                  phase=0)
+
+    def run(self, phase: int, relay=None):
+        if relay is not None:
+            _dev(relay)
+            self.keep = self.keep + (relay,)
+        self.io.relay = None if relay is None else relay.data_ptr()
+        self.io.phase = phase
+        check(self.lib.hfl_block_forward_x3(ctypes.byref(self.weights), ctypes.byref(self.io), ctypes.byref(self.desc),
+                                            _stream()), 'hfl_block_forward_x3')
+        return self.out
 
 
 def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):

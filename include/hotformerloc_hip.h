@@ -415,6 +415,13 @@ int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float
 int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
                              const uint32_t* tok_meta, const float* rpe_table,
                              const hfl_window_attn_desc* desc, hfl_stream_t stream);
+/* The same with a REPRODUCIBLE RPE-table gradient: every grid column writes its partial table to `workspace`
+ * (hfl_window_attention_bwd_workspace(desc) bytes; 0 = this launch configuration has no deterministic form, use the entry
+ * above) and a second launch adds the partials in a fixed order -- no float atomics; drpe_table need not be zeroed. */
+int64_t hfl_window_attention_bwd_workspace(const hfl_window_attn_desc* desc);
+int hfl_window_attention_bwd_det(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
+                                 const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* desc,
+                                 void* workspace, hfl_stream_t stream);
 /* Gradient of hfl_relay_attention_fwd.  dqkv (rows, 3*H*16): rows listed in seq_rows are written, the
  * others left untouched (the caller zero-fills).  max_seq_len * 268 B of LDS per workgroup: returns
  * HFL_ECAPACITY beyond 611 relay tokens per cloud. */
@@ -450,6 +457,11 @@ typedef struct hfl_block_io {
   const int32_t* neigh;                                /* (n_tokens, 27) */
   const uint32_t* tok_meta;
   int64_t n_rows, n_tokens;
+  int32_t phase;                                       /* 0: the whole block.  1: only what does not depend on the relay rows --
+                                                          CPE, LN1 and the qkv projection of the TOKEN rows (may run while the
+                                                          relay-token self-attention of the iteration is still in flight);
+                                                          2: the rest -- relay rows in, their LN1 / qkv, window attention, proj,
+                                                          MLP.  Phases 1 and 2 of a block share `arena`. */
 } hfl_block_io;
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels);
 int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, const hfl_window_attn_desc* desc,

@@ -796,6 +796,13 @@ def test_window_attention_backward_matches_autograd():
                 assert (gq[nt:nt + real] - qkv_rt.grad[:real]).abs().max().item() < 3e-5 * max(scale, 1)
             tscale = table.grad.abs().max().item()
             assert (td.grad.cpu() - table.grad).abs().max().item() < 1e-4 * max(tscale, 1), (cfg, depth, G, dil)
+            # the table gradient is reproducible: partial tables per grid column, fixed-order sum (no float atomics)
+            qd2 = qd.detach().clone().requires_grad_()
+            td2 = table.detach().to(DEV).requires_grad_()
+            od2 = ag.window_attention(qd2, td2, plan.meta[depth], n_tokens=nt, n_windows=W, patch_size=K,
+                                      dilation=dil, n_relay=G, n_heads=H, batch_size=B, rt_row0=nt, depth=depth)
+            ((od2 * wd).sum() if G else (od2[:nt] * wd[:nt]).sum()).backward()
+            assert torch.equal(td2.grad, td.grad) and torch.equal(qd2.grad, qd.grad), (cfg, depth, G, dil)
 
 
 def test_gather_and_relay_init_backward():
