@@ -38,6 +38,20 @@ class BlockWeights(ctypes.Structure):
                 ('rpe_table', c_void_p), ('mlp_pack', c_void_p)]
 
 
+class RelayBlockWeights(ctypes.Structure):
+    """hfl_relay_block_weights"""
+    _fields_ = [('channels', c_int64), ('n_heads', c_int32), ('eps', c_float),
+                ('norm1_gamma', c_void_p), ('norm1_beta', c_void_p), ('norm2_gamma', c_void_p), ('norm2_beta', c_void_p),
+                ('qkv_w', c_void_p), ('proj_w', c_void_p), ('fc1_w', c_void_p), ('fc2_w', c_void_p),
+                ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p)]
+
+
+class RelayBlockIO(ctypes.Structure):
+    """hfl_relay_block_io"""
+    _fields_ = [('x_in', c_void_p), ('out', c_void_p), ('arena', c_void_p), ('seq_rows', c_void_p), ('seq_off', c_void_p),
+                ('n_rows', c_int64), ('batch', c_int32), ('max_seq_len', c_int32)]
+
+
 class BlockIO(ctypes.Structure):
     """hfl_block_io"""
     _fields_ = [('x_in', c_void_p), ('relay', c_void_p), ('out', c_void_p), ('arena', c_void_p),
@@ -102,6 +116,8 @@ SIGNATURES = {
     'hfl_split2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_block_forward_x3_arena': (c_int64, [c_int64, c_int64]),
     'hfl_block_forward_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hfl_relay_block_forward_x3_arena': (c_int64, [c_int64, c_int64]),
+    'hfl_relay_block_forward_x3': (c_int, [c_void_p, c_void_p, c_void_p]),
     'hfl_linear_x3_grouped': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     'hfl_split2_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_linear_x3_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

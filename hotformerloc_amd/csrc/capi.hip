@@ -76,4 +76,42 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
 
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) { return n_rows * channels * 4 * 12; }
 
+// The relay-token transformer block as one call (see include/hotformerloc_hip.h): the same launches, in the same order, as
+// model.RelayTokenTransformerBlock issues through the Python wrappers.
+int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay_block_io* io, hfl_stream_t stream) {
+  if (w == nullptr || io == nullptr) return HFL_EINVAL;
+  const int64_t C = w->channels, rows = io->n_rows;
+  if (C <= 0 || C % 128 != 0 || rows < 0 || w->n_heads * 16 != C) return HFL_EINVAL;
+  if (rows == 0) return HFL_OK;
+  // arena carve: a2 split2 | qkv f32 (3C) | att f32 | o2 split2 | x1 f32 | h2 split2 | g2 split2 (4C)
+  unsigned char* a = static_cast<unsigned char*>(io->arena);
+  const size_t unit = (size_t)rows * C * 4;
+  uint16_t* a2 = reinterpret_cast<uint16_t*>(a);
+  float* qkv = reinterpret_cast<float*>(a + unit);
+  float* att = reinterpret_cast<float*>(a + 4 * unit);
+  uint16_t* o2 = reinterpret_cast<uint16_t*>(a + 5 * unit);
+  float* x1 = reinterpret_cast<float*>(a + 6 * unit);
+  uint16_t* h2 = reinterpret_cast<uint16_t*>(a + 7 * unit);
+  uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
+  int rc = hfl_layer_norm_split2(a2, io->x_in, w->norm1_gamma, w->norm1_beta, rows, C, w->eps, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_linear_x3(qkv, a2, w->qkv_w, w->qkv_b, nullptr, rows, (int)C, (int)(3 * C), 0, stream);
+  if (rc != HFL_OK) return rc;
+  hipError_t e = hipMemsetAsync(att, 0, unit, static_cast<hipStream_t>(stream));      // rows in no sequence -> 0
+  if (e != hipSuccess) return (int)e;
+  rc = hfl_relay_attention_fwd(att, qkv, io->seq_rows, io->seq_off, io->batch, w->n_heads, 0.25f, io->max_seq_len, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_split2(o2, att, rows, C, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, io->x_in, rows, (int)C, (int)C, 0, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
+  if (rc != HFL_OK) return rc;
+  rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);
+  if (rc != HFL_OK) return rc;
+  return hfl_linear_x3(io->out, g2, w->fc2_w, w->fc2_b, x1, rows, (int)(4 * C), (int)C, 0, stream);
+}
+
+int64_t hfl_relay_block_forward_x3_arena(int64_t n_rows, int64_t channels) { return n_rows * channels * 4 * 12; }
+
 }  // extern "C"

@@ -613,6 +613,53 @@ def _init_layer_scale(block, dim, layer_scale):
 _NATIVE_BLOCK = os.environ.get('HFL_NATIVE_BLOCK', '1') != '0'     # inference blocks as one native call (hfl_block_forward_x3)
 
 
+_F16_OK_CACHE = {}
+
+
+def _attn_f16_ok(rows, att, depth) -> bool:
+    key = (rows, att.patch_size, att.dilation, att.rt_per_window, att.num_heads, depth)
+    hit = _F16_OK_CACHE.get(key)
+    if hit is None:
+        if len(_F16_OK_CACHE) > 4096:
+            _F16_OK_CACHE.clear()
+        hit = _F16_OK_CACHE[key] = ops.window_attention_f16_ok(*key)
+    return hit
+
+
+def _native_block_static(block, device):
+    """(BlockWeights, tensors it points to) of a block, or None when the block's parameters do not qualify for the native
+    call; cached on the block and revalidated by the (version, pointer) stamp of every parameter (a few microseconds instead
+    of rebuilding a 20-field ctypes structure per block and forward: the host runs only just ahead of the GPU)."""
+    att, mlp, cpe = block.attention, block.mlp, block.cpe
+    table = None if att.rpe is None else att.rpe.rpe_table
+    plist = (cpe.conv.weights, cpe.norm.weight, cpe.norm.bias, block.norm1.weight, block.norm1.bias, block.norm2.weight,
+             block.norm2.bias, att.qkv.bias, att.proj.bias, mlp.fc1.bias, mlp.fc2.bias, att.qkv.weight, att.proj.weight,
+             mlp.fc1.weight, mlp.fc2.weight, table)
+    stamp = tuple((p._version, p.data_ptr()) if p is not None else None for p in plist)
+    hit = block.__dict__.get('_native_static')
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    from ._native import BlockWeights
+    res = None
+    # the native call reads raw pointers: every parameter must be what the Python wrappers would have checked (fp32,
+    # contiguous, on this device), the biases must exist and the three LayerNorms must share one eps
+    ok = (all(p is not None for p in plist[:-1]) and block.norm1.eps == block.norm2.eps == cpe.norm.eps
+          and all(p is None or (p.dtype == torch.float32 and p.is_contiguous() and p.device == device) for p in plist))
+    if ok:
+        keep = [_w2(att.qkv), _w2(att.proj), None, None]
+        w = BlockWeights(channels=att.dim, eps=block.norm1.eps, q_scale=16 ** -0.5 * 1.4426950408889634,
+                         cpe_weight=cpe.conv.weights.data_ptr(), cpe_gamma=cpe.norm.weight.data_ptr(),
+                         cpe_beta=cpe.norm.bias.data_ptr(), norm1_gamma=block.norm1.weight.data_ptr(),
+                         norm1_beta=block.norm1.bias.data_ptr(), norm2_gamma=block.norm2.weight.data_ptr(),
+                         norm2_beta=block.norm2.bias.data_ptr(), qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(),
+                         fc1_w=None, fc2_w=None, mlp_pack=None, qkv_b=att.qkv.bias.data_ptr(),
+                         proj_b=att.proj.bias.data_ptr(), fc1_b=mlp.fc1.bias.data_ptr(), fc2_b=mlp.fc2.bias.data_ptr(),
+                         rpe_table=None if table is None else table.data_ptr())
+        res = (w, keep)
+    block.__dict__['_native_static'] = (stamp, res)
+    return res
+
+
 def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     """A prepared native call for the block's inference forward (ops.BlockCall), or None when this block / launch is not
     eligible (then the Python sequence of the same kernels runs).  Same kernels, same order, same results; only the host
@@ -625,40 +672,31 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
         return None
     nt = plan.n_tokens[depth]
     rows = x_in.shape[0]
-    if not ops.window_attention_f16_ok(rows, att.patch_size, att.dilation, att.rt_per_window, att.num_heads, depth):
+    if not _attn_f16_ok(rows, att, depth):
         return None
-    from ._native import BlockWeights, WindowAttnDesc
+    static = _native_block_static(block, x_in.device)
+    if static is None:
+        return None
+    w, keep = static
+    from ._native import WindowAttnDesc
     table = None if att.rpe is None else att.rpe.rpe_table
     bnd = int(0.8 * att.patch_size * att.dilation ** 0.5)
     expanded = None if table is None else ops.rpe_expand(table, att.num_heads, bnd, depth)
     if table is not None and expanded is None:
         return None
-    mlp, cpe = block.mlp, block.cpe
-    # the native call reads raw pointers: every parameter must be what the Python wrappers would have checked (fp32,
-    # contiguous, on this device), the biases must exist and the three LayerNorms must share one eps
-    plist = (cpe.conv.weights, cpe.norm.weight, cpe.norm.bias, block.norm1.weight, block.norm1.bias, block.norm2.weight,
-             block.norm2.bias, att.qkv.bias, att.proj.bias, mlp.fc1.bias, mlp.fc2.bias, table)
-    if any(p is None for p in plist[:-1]) or not (block.norm1.eps == block.norm2.eps == cpe.norm.eps):
-        return None
-    if any(p is not None and (p.dtype != torch.float32 or not p.is_contiguous() or p.device != x_in.device) for p in plist):
-        return None
+    mlp = block.mlp
     pack = _mlp_pack(mlp, rows)
-    keep = (_w2(att.qkv), _w2(att.proj), None if pack is not None else _w2(mlp.fc1),
-            None if pack is not None else _w2(mlp.fc2), expanded, pack)
-    w = BlockWeights(channels=C, eps=block.norm1.eps, q_scale=16 ** -0.5 * 1.4426950408889634,
-                     cpe_weight=cpe.conv.weights.data_ptr(), cpe_gamma=cpe.norm.weight.data_ptr(),
-                     cpe_beta=cpe.norm.bias.data_ptr(), norm1_gamma=block.norm1.weight.data_ptr(),
-                     norm1_beta=block.norm1.bias.data_ptr(), norm2_gamma=block.norm2.weight.data_ptr(),
-                     norm2_beta=block.norm2.bias.data_ptr(), qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(),
-                     fc1_w=None if pack is not None else keep[2].data_ptr(), fc2_w=None if pack is not None else keep[3].data_ptr(),
-                     mlp_pack=None if pack is None else pack.data_ptr(), qkv_b=att.qkv.bias.data_ptr(),
-                     proj_b=att.proj.bias.data_ptr(), fc1_b=mlp.fc1.bias.data_ptr(), fc2_b=mlp.fc2.bias.data_ptr(),
-                     rpe_table=None if table is None else table.data_ptr())
+    if pack is not None:
+        w.mlp_pack, w.fc1_w, w.fc2_w = pack.data_ptr(), None, None
+    else:
+        if keep[2] is None:
+            keep[2], keep[3] = _w2(mlp.fc1), _w2(mlp.fc2)
+        w.mlp_pack, w.fc1_w, w.fc2_w = None, keep[2].data_ptr(), keep[3].data_ptr()
     desc = WindowAttnDesc(n_tokens=nt, rt_row0=nt, n_windows=plan.n_windows[depth], patch_size=att.patch_size,
                           dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
                           batch_size=plan.B, scale=16 ** -0.5, depth=depth,
                           rpe_expanded=None if expanded is None else expanded.data_ptr())
-    return ops.BlockCall(w, keep, x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
+    return ops.BlockCall(w, (keep, expanded, pack), x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
 
 
 def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
@@ -822,8 +860,37 @@ class RelayTokenTransformerBlock(nn.Module):
         self.drop_path = OctreeDropPath(drop_path)
         _init_layer_scale(self, dim, layer_scale)                       # hotformerloc_backbone.py:260-272
 
+    def _native_static(self, device):
+        """(RelayBlockWeights, tensors it points to) or None, cached and revalidated like _native_block_static."""
+        att, mlp = self.rt_attention, self.mlp
+        plist = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, att.qkv.bias, att.proj.bias,
+                 mlp.fc1.bias, mlp.fc2.bias, att.qkv.weight, att.proj.weight, mlp.fc1.weight, mlp.fc2.weight)
+        stamp = tuple((p._version, p.data_ptr()) if p is not None else None for p in plist)
+        hit = self.__dict__.get('_native_cache')
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        res = None
+        if (all(p is not None and p.dtype == torch.float32 and p.is_contiguous() and p.device == device for p in plist)
+                and self.norm1.eps == self.norm2.eps and att.dim % 128 == 0 and att.num_heads * 16 == att.dim):
+            from ._native import RelayBlockWeights
+            keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2))
+            w = RelayBlockWeights(channels=att.dim, n_heads=att.num_heads, eps=self.norm1.eps,
+                                  norm1_gamma=self.norm1.weight.data_ptr(), norm1_beta=self.norm1.bias.data_ptr(),
+                                  norm2_gamma=self.norm2.weight.data_ptr(), norm2_beta=self.norm2.bias.data_ptr(),
+                                  qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(), fc1_w=keep[2].data_ptr(),
+                                  fc2_w=keep[3].data_ptr(), qkv_b=att.qkv.bias.data_ptr(), proj_b=att.proj.bias.data_ptr(),
+                                  fc1_b=mlp.fc1.bias.data_ptr(), fc2_b=mlp.fc2.bias.data_ptr())
+            res = (w, keep)
+        self.__dict__['_native_cache'] = (stamp, res)
+        return res
+
     def forward(self, rt, plan):
         if _GEMM_MODE == 'x3' and _split_path(rt) and not self.use_layer_scale and not _drops(self) and rt.shape[0] > 0:
+            if _NATIVE_BLOCK and ops.KernelTimer.active is None and rt.dtype == torch.float32 and rt.is_contiguous():
+                static = self._native_static(rt.device)          # the same nine launches from ONE native call
+                if static is not None:
+                    return ops.relay_block_forward_x3(static[0], static[1], rt, plan.seq_rows, plan.seq_off, plan.B,
+                                                      plan.max_seq_len)
             att = self.rt_attention
             a2 = ops.layer_norm_split2(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             qkv = ops.linear_x3(a2, _w2(att.qkv), bias=att.qkv.bias)
@@ -935,7 +1002,9 @@ class HOTFormerStage(nn.Module):
 
     def _rtsa_stream(self, device):
         if self.__dict__.get('_rtsa_st') is None:
-            self.__dict__['_rtsa_st'] = torch.cuda.Stream(device=device)
+            # high priority: RTSA is a chain of eight tiny launches that must slip in between the chip-filling kernels of the
+            # token-row phase; at equal priority each of them queues behind a full round of workgroups
+            self.__dict__['_rtsa_st'] = torch.cuda.Stream(device=device, priority=-1)
         return self.__dict__['_rtsa_st']
 
     def _forward_without_relay_tokens(self, data, plan: WindowPlan, depths):
@@ -992,21 +1061,33 @@ class HOTFormerStage(nn.Module):
                 rs = self._rtsa_stream(data.device)
                 sts = [main if (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) else side[j - 1]
                        for j, d in enumerate(depths)]
+                # issue order = critical path first (the host runs only just ahead of the GPU here): the finest level's
+                # token phase, RTSA, then the small levels
+                order = sorted(range(len(depths)), key=lambda j: -bufs[depths[j]].shape[0])
+                ev0 = main.record_event()
                 calls = {}
-                for j, d in enumerate(depths):
+
+                def phase1(j):
+                    d = depths[j]
                     if sts[j] is not main:
-                        sts[j].wait_stream(main)
+                        sts[j].wait_event(ev0)
                     with torch.cuda.stream(sts[j]):
                         calls[d] = _native_block_call(self.hosa_blocks[j][i], bufs[d], plan, d)
                         if calls[d] is not None:
                             calls[d].run(1)
-                rs.wait_stream(main)
+
+                phase1(order[0])
+                rs.wait_event(ev0)
                 with torch.cuda.stream(rs):
                     rt_all = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
+                    ev_rt = rs.record_event()
+                for j in order[1:]:
+                    phase1(j)
                 fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
                 old = (dict(bufs), dict(rts))        # buffers other streams still read stay alive until the join
-                for j, d in enumerate(depths):
-                    sts[j].wait_stream(rs)
+                for j in order:
+                    d = depths[j]
+                    sts[j].wait_event(ev_rt)
                     with torch.cuda.stream(sts[j]):
                         blk = self.hosa_blocks[j][i]
                         rin = self.down_projections[j][i](fresh[d]) if proj else fresh[d]

@@ -537,6 +537,19 @@ class BlockCall:
         return self.out
 
 
+def relay_block_forward_x3(weights, keep_alive, rt, seq_rows, seq_off, batch: int, max_seq_len: int):
+    """The relay-token transformer block (RTSA) of the inference path in ONE native call (hfl_relay_block_forward_x3)."""
+    _dev(rt, seq_rows, seq_off)
+    rows, c = rt.shape
+    lib = _native.load()
+    out = torch.empty((rows, c), dtype=torch.float32, device=rt.device)
+    arena = torch.empty(int(lib.hfl_relay_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=rt.device)
+    io = _native.RelayBlockIO(x_in=rt.data_ptr(), out=out.data_ptr(), arena=arena.data_ptr(), seq_rows=seq_rows.data_ptr(),
+                              seq_off=seq_off.data_ptr(), n_rows=rows, batch=batch, max_seq_len=max_seq_len)
+    check(lib.hfl_relay_block_forward_x3(ctypes.byref(weights), ctypes.byref(io), _stream()), 'hfl_relay_block_forward_x3')
+    return out
+
+
 def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):
     """(dW, db) of y = x W^T + b from split2 operands: dW (N, K) = dy^T x, db (N) = dy summed over rows (hfl_wgrad_x3;
     fixed reduction order)."""

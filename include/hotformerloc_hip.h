@@ -467,6 +467,31 @@ int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels);
 int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, const hfl_window_attn_desc* desc,
                          hfl_stream_t stream);
 
+/* The relay-token transformer block (RTSA, models/hotformerloc_backbone.py:239-302) of the inference path as ONE call: LN1 ->
+ * split2, qkv GEMM, ragged relay attention (hfl_relay_attention_fwd), split2, proj GEMM + residual, LN2 -> split2, fc1 GEMM +
+ * GELU, fc2 GEMM + residual -- eight launches and a memset issued back to back from native code (the rows are the few
+ * thousand relay tokens of a batch: the launches are tiny, the Python issue time was the cost).
+ * arena >= hfl_relay_block_forward_x3_arena(n_rows, channels) bytes; out (n_rows, C) must not alias x_in. */
+typedef struct hfl_relay_block_weights {
+  int64_t channels;
+  int32_t n_heads;
+  float eps;
+  const float *norm1_gamma, *norm1_beta, *norm2_gamma, *norm2_beta;
+  const uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;     /* split2 */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+} hfl_relay_block_weights;
+typedef struct hfl_relay_block_io {
+  const float* x_in;
+  float* out;
+  void* arena;
+  const int32_t* seq_rows;                             /* as hfl_relay_attention_fwd */
+  const int32_t* seq_off;
+  int64_t n_rows;
+  int32_t batch, max_seq_len;
+} hfl_relay_block_io;
+int64_t hfl_relay_block_forward_x3_arena(int64_t n_rows, int64_t channels);
+int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay_block_io* io, hfl_stream_t stream);
+
 /* Weight gradient of an octree convolution over its live (row, tap) pairs (csrc/tapconv.hip; replaces autograd over
  * ocnn's octree2col + mm, models/layers/octformer_layers.py:89-95): dw[k] (cin, cout) = g_k^T dpart_k over the pairs of tap
  * k.  g (P, cin), dpart (P, cout) fp32 pair-major; chunks (n_chunks, 3) int32 = {tap, first pair, end pair}, ascending, no

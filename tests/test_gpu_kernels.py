@@ -802,7 +802,9 @@ def test_window_attention_backward_matches_autograd():
             od2 = ag.window_attention(qd2, td2, plan.meta[depth], n_tokens=nt, n_windows=W, patch_size=K,
                                       dilation=dil, n_relay=G, n_heads=H, batch_size=B, rt_row0=nt, depth=depth)
             ((od2 * wd).sum() if G else (od2[:nt] * wd[:nt]).sum()).backward()
-            assert torch.equal(td2.grad, td.grad) and torch.equal(qd2.grad, qd.grad), (cfg, depth, G, dil)
+            rows_ok = nt + real if G else nt                     # rows of padding windows are never written
+            assert torch.equal(td2.grad, td.grad), (cfg, depth, G, dil)
+            assert torch.equal(qd2.grad[:rows_ok], qd.grad[:rows_ok]), (cfg, depth, G, dil)
 
 
 def test_gather_and_relay_init_backward():
