@@ -1238,6 +1238,7 @@ extern "C" void hfl_internal_set_cpe_chunk(int rows);
 /* tuning / A-B hook: select kernel variants at run time (key "window_attention": 1 | 2) */
 void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
+void hfl_internal_set_mlp_stagger(int v);
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
   const char* kr = "reset";                      // every probe knob back to its default (tests call it around each case)
@@ -1253,6 +1254,14 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_x3_dbg(0);
     hfl_internal_set_x3_dbg(0x100);
     hfl_internal_set_cpe_chunk(0);
+    hfl_internal_set_mlp_stagger(1 | (8 << 8));
+    return HFL_OK;
+  }
+  const char* km = "mlp_stagger";
+  i = 0;
+  while (km[i] != 0 && key[i] == km[i]) ++i;
+  if (km[i] == 0 && key[i] == 0) {
+    hfl_internal_set_mlp_stagger(value);
     return HFL_OK;
   }
   const char* k = "window_attention";

@@ -53,7 +53,12 @@ struct MlpFusedParams {
   int64_t M;
   float eps;
   int n_tiles;                // ceil(M / 16)
+  int stagger;                // workgroup g starts (g % stagger_groups) * stagger naps of ~4000 cycles late (0: all together)
+  int stagger_groups;
 };
+
+static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
+static int g_mlp_stagger_groups = 8;
 
 #define HFL_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
@@ -162,6 +167,14 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   // A fragment of a 16-row block: row = block * 16 + fr, hi chunk fq, lo chunk 4 + fq
   const int off_hi = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4), off_lo = off_hi ^ 64;
 
+  // Every workgroup has the same work, so without help they all sit in their memory-only phases (row loads + LayerNorm at
+  // the top of a pass, residual loads + stores at its end: ~67 MB each way per pass over the chip) at the same time, with
+  // every matrix pipe idle, and then all compute with the memory system idle.  Half of them start a fraction of that phase
+  // later: from then on the groups alternate.  (Only when a workgroup has more than one pass: p.stagger = 0 otherwise.)
+  {
+    const int naps = (int)(blockIdx.x % (unsigned)p.stagger_groups) * p.stagger;
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(63);          // ~4000 cycles each
+  }
   while (tile0 < tile_end) {
     const int ntile = tile_end - tile0 < TPP ? tile_end - tile0 : TPP;    // tiles of this pass
     // ---- LayerNorm of this wave's rows -> B-operand fragments (lane: row fr of the tile, channels 32 ks + 8 fq + j)
@@ -433,7 +446,17 @@ mlp_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w1, 
 
 }  // namespace
 
+static int grid_guess(int n_tiles) {
+  const int cus = hfl_num_cus();
+  return n_tiles < cus ? n_tiles : cus;
+}
+
 extern "C" {
+
+void hfl_internal_set_mlp_stagger(int v) {
+  g_mlp_stagger = v & 0xFF;
+  g_mlp_stagger_groups = (v >> 8) > 0 ? (v >> 8) : 2;
+}
 
 int64_t hfl_mlp_fused_pack_bytes(int channels) {
   if (channels != 128 && channels != 256) return 0;
@@ -461,6 +484,9 @@ int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float
   p.out = out; p.x = x; p.gamma = gamma; p.beta = beta; p.pack = static_cast<const unsigned char*>(pack);
   p.b1 = b1; p.b2 = b2; p.M = n_rows; p.eps = eps;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
+  // stagger only launches in which a workgroup walks several passes (a single pass has nothing to alternate with)
+  p.stagger = p.n_tiles > (int64_t)grid_guess(p.n_tiles) * 8 * (channels == 256 ? 1 : 2) ? g_mlp_stagger : 0;
+  p.stagger_groups = g_mlp_stagger_groups;
   const int cus = hfl_num_cus();
   const int grid = p.n_tiles < cus ? p.n_tiles : cus;
   hipStream_t s = static_cast<hipStream_t>(stream);

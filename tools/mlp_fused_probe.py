@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from hotformerloc_amd import ops  # noqa: E402
+from hotformerloc_amd import _native, ops  # noqa: E402
 
 
 def timeit(fn, n=30):
@@ -43,6 +43,13 @@ def main():
             g2 = ops.linear_x3(h2, w1s, bias=b1, gelu_split_out=True)
             ops.linear_x3(g2, w2s, bias=b2, residual=x, out=out)
 
+        lib = _native.load()
+        ts = []
+        for groups, sg in ((2, 0), (2, 4), (2, 6), (2, 8), (4, 2), (4, 3), (4, 4), (8, 1), (8, 2)):
+            lib.hfl_set_variant(b'mlp_stagger', sg | (groups << 8))
+            ts.append(((groups, sg), round(timeit(fused), 1)))
+        lib.hfl_set_variant(b'mlp_stagger', 1 | (8 << 8))
+        print('   stagger sweep ((groups, naps of ~4000 cycles per group step), us):', ts, flush=True)
         tf, tu = timeit(fused), timeit(unfused)
         flop = 16.0 * rows * C * C * 3
         print('rows %6d C %3d: fused %7.1f us (%6.1f TF/s bf16, %5.2f TB/s alg)   unfused %7.1f us   x%.2f'
