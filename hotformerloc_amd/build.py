@@ -60,7 +60,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + os.environ.get('HFL_EXTRA_HIPCC_FLAGS', '').split() + \
+            ['-c', s, '-o', o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (s, r.stderr))

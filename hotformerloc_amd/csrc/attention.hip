@@ -20,7 +20,9 @@
 //     a permutation shared with the V fragment), O is normalised and scattered to the
 //     token rows: window (un)packing, dilation and padding are pure index arithmetic.
 #include "hfl_common.h"
+#include "x3_math.h"
 
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -60,6 +62,37 @@ __device__ __forceinline__ float att_max3_c(float a, float b, float c) {
   return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 }
 
+// max / sum over the four 16-lane rows of a wave (lanes c, c+16, c+32, c+48) on the VALU: `v_permlane32_swap` exchanges the upper
+// half of one register with the lower half of another, `v_permlane16_swap` the odd rows of one with the even rows of the other;
+// fed with two copies of v, a max (add) of the swapped pair is the xor-32 (xor-16) butterfly step.  Replaces two
+// `ds_bpermute_b32` round trips through the LDS crossbar per reduction.  (Inline asm: the builtin's second result is folded
+// into the first by this compiler.  The operands are VALU results, never raw MFMA outputs: see att_max3_c; `s_nop 1` is the
+// VALU-write -> permlane-read wait.)
+__device__ __forceinline__ float att_rows_max(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+  return a;
+}
+__device__ __forceinline__ float att_rows_sum(float v) {
+  float a = v, b = v;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_add_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\t"
+      "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+  return a;
+}
+
+// two floats in [0, 1] -> packed fp16 (hi, lo): hi = RTZ(p), lo = RTZ(p - hi).  The residual is ONE `v_fma_mix_f32` per value
+// (fma(hi as f16, -1, p): the f16 operand is widened by the instruction) instead of v_cvt_f32_f16 + v_sub_f32.  The asm's
+// operands are the results of ordinary VALU instructions (the cvt_pkrtz in front of it), so the trans-use wait state of the
+// v_exp_f32 that produced p has already been served.
+__device__ __forceinline__ void att_split_pair_f16(float p0, float p1, unsigned int& hi, unsigned int& lo) {
+  hi = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(p0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(p1));
+  lo = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+}
+
 // max of three for the softmax row maxima.  (An earlier inline-asm v_max3_f32 saved the canonicalising v_max(x, x) of
 // fmaxf() but hid the operands from the compiler's hazard recogniser: see att_max3_c.)
 __device__ __forceinline__ float att_max3(float a, float b, float c) { return att_max3_c(a, b, c); }
@@ -92,10 +125,9 @@ __device__ __forceinline__ void att_store_row4(char* out_b, uint32_t orow, int C
     *reinterpret_cast<f32x4*>(out_b + ((size_t)orow * (uint32_t)C + (uint32_t)ch) * 4u) = o;
     return;
   }
-  const uint32_t h0 = att_bf16_rne(o[0]), h1 = att_bf16_rne(o[1]), h2 = att_bf16_rne(o[2]), h3 = att_bf16_rne(o[3]);
-  const uint32_t l0 = att_bf16_rne(o[0] - __uint_as_float(h0 << 16)), l1 = att_bf16_rne(o[1] - __uint_as_float(h1 << 16));
-  const uint32_t l2 = att_bf16_rne(o[2] - __uint_as_float(h2 << 16)), l3 = att_bf16_rne(o[3] - __uint_as_float(h3 << 16));
-  const uint2 hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16)), lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  uint2 hi, lo;                       // v_cvt_pk_bf16_f32 (round to nearest even, as att_bf16_rne): 6 instructions per pair
+  x3_split_pair_scalar(o[0], o[1], hi.x, lo.x);
+  x3_split_pair_scalar(o[2], o[3], hi.y, lo.y);
   uint16_t* out16 = reinterpret_cast<uint16_t*>(out_b);
   if (mode == 2) {
     uint16_t* d = out16 + (size_t)orow * (uint32_t)(2 * C) + (uint32_t)((ch >> 5) * 64 + (ch & 31));
@@ -730,9 +762,29 @@ typedef _Float16 att_h8 __attribute__((ext_vector_type(8)));
 typedef short att_s4 __attribute__((ext_vector_type(4)));
 
 // RPE: 0 none, 1 expanded x + y-z tables (two lookups), 2 three clamped 1-D tables (deep octrees, three lookups)
-template <int T, int G, int RPE>
+// probe (window_debug bit 3): s_memtime stamps of ONE wave (workgroup 0, wave 0) at the phase boundaries of its first 16 windows;
+// read back by hfl_internal_read_att_trace (tools/attn_trace.py)
+// (compiled in only with -DHFL_ATT_TRACE=1: `HFL_EXTRA_HIPCC_FLAGS=-DHFL_ATT_TRACE=1 python -m hotformerloc_amd.build`; the
+// branches cost the depth-5 launch 15 % even when the bit is off)
+#ifndef HFL_ATT_TRACE
+#define HFL_ATT_TRACE 0
+#endif
+__device__ unsigned long long g_att_trace[16 * 8];
+__device__ unsigned long long g_att_wg[4096 * 2];      // probe: s_memrealtime at the start and end of every workgroup
+#define HFL_ATT_STAMP(slot)                                                                      \
+  if (HFL_ATT_TRACE && trace_on) {                                                               \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                  \
+    if (it < 16 && lane == 0) g_att_trace[it * 8 + (slot)] = t_;                                 \
+  }
+
+// PF = 1: the fragments and the metadata word of the workgroup's NEXT window are requested into a second register set
+// before the softmax of the current one starts (2 waves per SIMD, <= 256 VGPRs): a wave no longer alternates between a
+// load phase and a compute phase, so the memory latency is hidden inside one wave instead of across three.
+constexpr int v5_waves_per_simd(int T, int G, int PF) { return PF ? 2 : v4_waves_per_simd(T, G); }
+
+template <int T, int G, int RPE, int PF>
 __global__ void __launch_bounds__(256)
-    __attribute__((amdgpu_waves_per_eu(v4_waves_per_simd(T, G), v4_waves_per_simd(T, G))))
+    __attribute__((amdgpu_waves_per_eu(v5_waves_per_simd(T, G, PF), v5_waves_per_simd(T, G, PF))))
 window_attn_kernel_v5(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LP = T * 16;
@@ -785,18 +837,16 @@ window_attn_kernel_v5(const WinParams p) {
   const bool owns = tid < LP;                          // the launcher guarantees blockDim.x >= LP
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
-  int it = 0;
-  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
-    const int tstep = p.D;
+  const int tstep = p.D;
+  // ---- request a window: metadata word + every fragment of this wave's head (index arithmetic only) ----------------
+  auto request = [&](int w, uint2& mt, uint4 (&ka)[T], uint4 (&qh)[T], uint4 (&ql)[T], uint4 (&vr)[T]) {
     const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
     const int rt_row = (int)p.rt_row0 + w;
-    // ---- request the window: metadata word + every fragment of this wave's head (index arithmetic only) ----------
-    uint2 mt = make_uint2(0u, 0xFFFFFFFFu);
+    mt = make_uint2(0u, 0xFFFFFFFFu);
     if (owns && tid < K) {
       const int t = tok0 + tid * tstep;
       if (t < n_tok) mt = *reinterpret_cast<const uint2*>(p.meta + 2 * (int64_t)t);
     }
-    uint4 ka[T], qh[T], ql[T], vr[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       int row;
@@ -816,6 +866,39 @@ window_attn_kernel_v5(const WinParams p) {
         ql[t] = *reinterpret_cast<const uint4*>(base + col_ql);
         vr[t] = *reinterpret_cast<const uint4*>(base + col_v);
       }
+    }
+  };
+  // PF: output rows of the window just finished, stored at the start of the next one
+  f32x4 o_hold[T];
+  int orow_hold[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) orow_hold[t] = -1;
+  auto flush = [&]() {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (orow_hold[t] >= 0) att_store_row4(out_b, (uint32_t)orow_hold[t], C, h * 16 + 4 * g, o_hold[t], p.out_split);
+  };
+  uint2 mt_n = make_uint2(0u, 0xFFFFFFFFu);
+  uint4 ka_n[T], qh_n[T], ql_n[T], vr_n[T];
+  if (PF && (int)blockIdx.x < p.n_windows) request(blockIdx.x, mt_n, ka_n, qh_n, ql_n, vr_n);
+
+  const bool trace_on = HFL_ATT_TRACE && (p.dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && hw == 0;
+  const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+  if (HFL_ATT_TRACE && (p.dbg & 8) && tid == 0 && wg_lin < 4096) g_att_wg[2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
+  int it = 0;
+  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
+    const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
+    const int rt_row = (int)p.rt_row0 + w;
+    uint2 mt;
+    uint4 ka[T], qh[T], ql[T], vr[T];
+    HFL_ATT_STAMP(0)
+    if (HFL_ATT_TRACE && trace_on && it < 16 && lane == 0) g_att_trace[it * 8 + 7] = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+    if (PF) {
+      mt = mt_n;
+#pragma unroll
+      for (int t = 0; t < T; ++t) { ka[t] = ka_n[t]; qh[t] = qh_n[t]; ql[t] = ql_n[t]; vr[t] = vr_n[t]; }
+    } else {
+      request(w, mt, ka, qh, ql, vr);
     }
     int4* s_qry = s_qry0 + (it & 1) * LP;
     int2* s_key = s_key0 + (it & 1) * LP;
@@ -846,6 +929,7 @@ window_attn_kernel_v5(const WinParams p) {
 #pragma unroll
     for (int t = 0; t < T; ++t) *reinterpret_cast<uint4*>(s_v + (t * 16 + c) * 64 + g * 16) = vr[t];
     __syncthreads();
+    HFL_ATT_STAMP(1)
     const int bid0 = s_kbid[0], bidl = s_kbid[K - 1];
     const int rt_bid = bid0 >= 0 ? bid0 : p.batch;     // the relay token carries the id of the window's first token
     const bool homog = __builtin_amdgcn_readfirstlane((bidl >= 0 && bid0 == bidl) ? 1 : 0) != 0;
@@ -877,6 +961,15 @@ window_attn_kernel_v5(const WinParams p) {
           kyza[kt][r] = km.y;
         }
     }
+
+    if (PF) {
+      // the previous window's output rows leave NOW, a whole softmax phase before the next `s_waitcnt vmcnt(0)`: gfx950 has
+      // one counter for loads and stores, and a store issued at the end of a window would make the top of the next one wait
+      // for its acknowledgement (measured: ~3.6 k cycles per window)
+      flush();
+      if (w + (int)gridDim.x < p.n_windows) request(w + (int)gridDim.x, mt_n, ka_n, qh_n, ql_n, vr_n);
+    }
+    HFL_ATT_STAMP(2)
 
     auto body = [&](auto masked_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
@@ -944,8 +1037,7 @@ window_attn_kernel_v5(const WinParams p) {
           mx = att_max3_c(mx, s[kt][0], s[kt][1]);
           mx = att_max3_c(mx, s[kt][2], s[kt][3]);
         }
-        mx = att_max3_c(mx, __shfl_xor(mx, 16, 64), mx);
-        mx = att_max3_c(mx, __shfl_xor(mx, 32, 64), mx);
+        mx = att_rows_max(mx);
         const f32x4 nmx4 = {-mx, -mx, -mx, -mx};
         f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -962,37 +1054,52 @@ window_attn_kernel_v5(const WinParams p) {
           s[T - 1] = (f32x4){ert, 0.f, 0.f, 0.f};         // zero in the lanes g != 0 (rt_add)
           sum += ert;
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = att_rows_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
 
         // O^T = V^T P^T over pairs of key tiles; P (un-normalised, in [0, 1]) split into fp16 (hi, lo) in registers
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        // (one accumulator per pair: two independent chains of three MFMAs instead of one of six)
+        f32x4 oacc[NP];
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
           const f32x4 pa = s[2 * pp];
           const f32x4 pb = (2 * pp + 1 < T) ? s[2 * pp + 1] : (f32x4){0.f, 0.f, 0.f, 0.f};
-          const auto h0 = __builtin_amdgcn_cvt_pkrtz(pa[0], pa[1]), h1 = __builtin_amdgcn_cvt_pkrtz(pa[2], pa[3]);
-          const auto h2 = __builtin_amdgcn_cvt_pkrtz(pb[0], pb[1]), h3 = __builtin_amdgcn_cvt_pkrtz(pb[2], pb[3]);
-          const auto l0 = __builtin_amdgcn_cvt_pkrtz(pa[0] - (float)h0[0], pa[1] - (float)h0[1]);
-          const auto l1 = __builtin_amdgcn_cvt_pkrtz(pa[2] - (float)h1[0], pa[3] - (float)h1[1]);
-          const auto l2 = __builtin_amdgcn_cvt_pkrtz(pb[0] - (float)h2[0], pb[1] - (float)h2[1]);
-          const auto l3 = __builtin_amdgcn_cvt_pkrtz(pb[2] - (float)h3[0], pb[3] - (float)h3[1]);
           typedef unsigned int att_u4 __attribute__((ext_vector_type(4)));
-          const att_u4 uh = {__builtin_bit_cast(unsigned int, h0), __builtin_bit_cast(unsigned int, h1),
-                             __builtin_bit_cast(unsigned int, h2), __builtin_bit_cast(unsigned int, h3)};
-          const att_u4 ul = {__builtin_bit_cast(unsigned int, l0), __builtin_bit_cast(unsigned int, l1),
-                             __builtin_bit_cast(unsigned int, l2), __builtin_bit_cast(unsigned int, l3)};
+          unsigned int h0, h1, h2 = 0u, h3 = 0u, l0, l1, l2 = 0u, l3 = 0u;
+          att_split_pair_f16(pa[0], pa[1], h0, l0);
+          att_split_pair_f16(pa[2], pa[3], h1, l1);
+          if (G > 0 && 2 * pp + 1 == T - 1) {            // the relay key tile: one live element (s[T - 1] above)
+            att_split_pair_f16(pb[0], 0.f, h2, l2);
+            l2 &= 0xFFFFu;
+          } else if (2 * pp + 1 < T) {
+            att_split_pair_f16(pb[0], pb[1], h2, l2);
+            att_split_pair_f16(pb[2], pb[3], h3, l3);
+          }
+          const att_u4 uh = {h0, h1, h2, h3}, ul = {l0, l1, l2, l3};
           const att_h8 phi = __builtin_bit_cast(att_h8, uh);
           const att_h8 plo = __builtin_bit_cast(att_h8, ul);
           o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi[pp], plo, o, 0, 0, 0);
           o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vlo[pp], phi, o, 0, 0, 0);
           o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vhi[pp], phi, o, 0, 0, 0);
+          oacc[pp] = o;
         }
+        f32x4 o = oacc[0];
+#pragma unroll
+        for (int pp = 1; pp < NP; ++pp) o += oacc[pp];
         o *= inv;
         // the accumulator holds channels 4g .. 4g+3 of query c (relay tile: only the column c == 0 is a row)
         const int orow = is_rt ? (c == 0 ? rt_row : -1) : qm.w;
-        if (orow >= 0) att_store_row4(out_b, (uint32_t)orow, C, h * 16 + 4 * g, o, p.out_split);
+        if (PF) {
+          o_hold[qt] = o;
+          orow_hold[qt] = orow;
+        } else if (orow >= 0) {
+          att_store_row4(out_b, (uint32_t)orow, C, h * 16 + 4 * g, o, p.out_split);
+        }
+        if (HFL_ATT_TRACE && trace_on) {        // the stamp must not float above the tile: tie it to the tile's result
+          const unsigned long long t_ = __builtin_amdgcn_s_memtime() + (o[0] == 1234.5f ? 1 : 0);
+          if (it < 16 && lane == 0 && qt < 5) g_att_trace[it * 8 + 3 + qt] = t_;
+        }
       }
     };
     if (homog)
@@ -1000,6 +1107,8 @@ window_attn_kernel_v5(const WinParams p) {
     else
       body(std::true_type{});
   }
+  if (PF) flush();
+  if (HFL_ATT_TRACE && (p.dbg & 8) && tid == 0 && wg_lin < 4096) g_att_wg[2 * wg_lin + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // expanded RPE table of v4: out (H, TS), TS = (W + W*W + 3) & ~3, W = 2R+1, R = 2^depth - 1 <= pos_bnd:
@@ -1061,6 +1170,7 @@ static inline size_t rpe_form_floats(int depth, int bnd) {      // per head
 static int g_window_variant = 4;
 static int g_window_v4_wgs_per_cu = 1;   // multiples of the resident workgroup count
 static int g_window_dbg = 0;
+static int g_window_pf = 0;            // 1: window_attn_kernel_v5 prefetches the next window into registers
 static int g_window_v2_wgs_per_cu = 16;
 static int g_window_heads_per_wg = 4;
 
@@ -1102,7 +1212,9 @@ static int launch_window(const WinParams& p, hipStream_t s) {
           rows_total * 3 * p.H * 16 * 4 >= (int64_t)1 << 32 || lds5 > 72 * 1024 || hp5 * 64 < LP || p.qkv_bias != nullptr)
         return HFL_EINVAL;
       const int groups5 = p.H / hp5;
-      int resident = v4_waves_per_simd(T, G) * 4 / hp5;
+      constexpr bool pf_fits = T <= 3 || (T == 4 && G == 1);      // <= 256 VGPRs with the second fragment set
+      const int pf = (g_window_pf && pf_fits) ? 1 : 0;
+      int resident = v5_waves_per_simd(T, G, pf) * 4 / hp5;
       const int lds_fit = (int)((size_t)160 * 1024 / (lds5 + 512));
       if (resident > lds_fit) resident = lds_fit;
       if (resident < 1) resident = 1;
@@ -1111,14 +1223,20 @@ static int launch_window(const WinParams& p, hipStream_t s) {
       if (px > p.n_windows) px = p.n_windows;
       dim3 grid5((unsigned)px, (unsigned)groups5);
       hipError_t e;
-#define HFL_V5_LAUNCH(F)                                                                                  \
+#define HFL_V5_LAUNCH(F, P)                                                                               \
   {                                                                                                       \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, F>),                \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, F, P>),             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);                       \
     if (e != hipSuccess) return (int)e;                                                                   \
-    window_attn_kernel_v5<T, G, F><<<grid5, hp5 * 64, lds5, s>>>(p);                                      \
+    window_attn_kernel_v5<T, G, F, P><<<grid5, hp5 * 64, lds5, s>>>(p);                                   \
   }
-      if (form == 0) HFL_V5_LAUNCH(0) else if (form == 1) HFL_V5_LAUNCH(1) else HFL_V5_LAUNCH(2)
+      if (pf) {
+        if constexpr (pf_fits) {
+          if (form == 0) HFL_V5_LAUNCH(0, 1) else if (form == 1) HFL_V5_LAUNCH(1, 1) else HFL_V5_LAUNCH(2, 1)
+        }
+      } else {
+        if (form == 0) HFL_V5_LAUNCH(0, 0) else if (form == 1) HFL_V5_LAUNCH(1, 0) else HFL_V5_LAUNCH(2, 0)
+      }
 #undef HFL_V5_LAUNCH
     } else if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
         (p.table == nullptr || p.rpe2 != nullptr) && rows_total * 3 * p.H * 16 * 4 < (int64_t)1 << 32 &&
@@ -1239,15 +1357,22 @@ extern "C" void hfl_internal_set_cpe_chunk(int rows);
 void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
+int hfl_internal_read_att_trace(unsigned long long* host, int n) {
+  if (n > 16 * 8) n = 16 * 8;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_att_trace), (size_t)n * 8);
+}
+int hfl_internal_read_att_wg(unsigned long long* host, int n) {
+  if (n > 4096 * 2) n = 4096 * 2;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_att_wg), (size_t)n * 8);
+}
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
-  const char* kr = "reset";                      // every probe knob back to its default (tests call it around each case)
-  int i = 0;
-  while (kr[i] != 0 && key[i] == kr[i]) ++i;
-  if (kr[i] == 0 && key[i] == 0) {
+  auto is = [key](const char* name) { return strcmp(key, name) == 0; };
+  if (is("reset")) {                             // every probe knob back to its default (tests call it around each case)
     g_window_variant = 4;
     g_window_v4_wgs_per_cu = 1;
     g_window_dbg = 0;
+    g_window_pf = 0;
     g_window_v2_wgs_per_cu = 16;
     g_window_heads_per_wg = 4;
     hfl_internal_set_window_bwd(2);
@@ -1255,72 +1380,30 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_x3_dbg(0x100);
     hfl_internal_set_cpe_chunk(0);
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
-    return HFL_OK;
-  }
-  const char* km = "mlp_stagger";
-  i = 0;
-  while (km[i] != 0 && key[i] == km[i]) ++i;
-  if (km[i] == 0 && key[i] == 0) {
+  } else if (is("mlp_stagger")) {
     hfl_internal_set_mlp_stagger(value);
-    return HFL_OK;
-  }
-  const char* k = "window_attention";
-  i = 0;
-  while (k[i] != 0 && key[i] == k[i]) ++i;
-  if (k[i] == 0 && key[i] == 0) {
+  } else if (is("window_attention")) {
     g_window_variant = value;
-    return HFL_OK;
-  }
-  const char* kb = "window_bwd";
-  i = 0;
-  while (kb[i] != 0 && key[i] == kb[i]) ++i;
-  if (kb[i] == 0 && key[i] == 0) {
+  } else if (is("window_bwd")) {
     hfl_internal_set_window_bwd(value);
-    return HFL_OK;
-  }
-  const char* kx = "x3_dbg";
-  i = 0;
-  while (kx[i] != 0 && key[i] == kx[i]) ++i;
-  if (kx[i] == 0 && key[i] == 0) {
+  } else if (is("x3_dbg")) {
     hfl_internal_set_x3_dbg(value);
-    return HFL_OK;
-  }
-  const char* k3 = "cpe_chunk_rows";
-  i = 0;
-  while (k3[i] != 0 && key[i] == k3[i]) ++i;
-  if (k3[i] == 0 && key[i] == 0) {
+  } else if (is("cpe_chunk_rows")) {
     hfl_internal_set_cpe_chunk(value);
-    return HFL_OK;
-  }
-  const char* k8 = "window_debug";
-  i = 0;
-  while (k8[i] != 0 && key[i] == k8[i]) ++i;
-  if (k8[i] == 0 && key[i] == 0) {
+  } else if (is("window_debug")) {
     g_window_dbg = value;
-    return HFL_OK;
-  }
-  const char* k7 = "window_v4_wgs_per_cu";
-  i = 0;
-  while (k7[i] != 0 && key[i] == k7[i]) ++i;
-  if (k7[i] == 0 && key[i] == 0) {
+  } else if (is("window_pf")) {
+    g_window_pf = value;
+  } else if (is("window_v4_wgs_per_cu")) {
     g_window_v4_wgs_per_cu = value;
-    return HFL_OK;
-  }
-  const char* k6 = "window_v2_wgs_per_cu";
-  i = 0;
-  while (k6[i] != 0 && key[i] == k6[i]) ++i;
-  if (k6[i] == 0 && key[i] == 0) {
+  } else if (is("window_v2_wgs_per_cu")) {
     g_window_v2_wgs_per_cu = value;
-    return HFL_OK;
-  }
-  const char* k2 = "window_heads_per_wg";
-  i = 0;
-  while (k2[i] != 0 && key[i] == k2[i]) ++i;
-  if (k2[i] == 0 && key[i] == 0) {
+  } else if (is("window_heads_per_wg")) {
     g_window_heads_per_wg = value;
-    return HFL_OK;
+  } else {
+    return HFL_EINVAL;
   }
-  return HFL_EINVAL;
+  return HFL_OK;
 }
 
 /* 1 when hfl_window_attention_fwd_ex accepts the fp16 (hi, lo) qkv operand layout (flag 0x100) for this launch

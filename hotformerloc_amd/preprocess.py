@@ -8,9 +8,11 @@ compacts it; the result feeds `build_batch_octree` without leaving the device.
 
 Parity: normalisation and both masks are bit-exact with the reference (tests/golden/preprocess.npz, produced by the
 reference's own classes).  The cylindrical transform contains `torch.atan2` on the CPU, which the device's `atan2f`
-matches only to 1-2 ulp -- enough to move a point that sits on an octree cell boundary.  `cylindrical='host'`
-(default) therefore runs the transform on the host exactly as the reference does (masked points make one round
-trip); `cylindrical='device'` keeps everything on the GPU and is equal up to those ulps."""
+matches only to 1-3 ulp -- enough to move a point that sits on an octree cell boundary (measured: about 1e-5 of the
+points change their depth-7 cell, tests/test_gpu_preprocess.py; the reference's own float64 chain is not reproducible
+across CPUs to better than 1 ulp either, tests/test_oracle_preprocess.py).  `cylindrical='device'` (default since
+round 3) keeps the whole batch on the GPU under that <= 3 ulp contract; `cylindrical='host'` runs the transform on
+the host exactly as the reference does (the masked points make one round trip) for callers that need its bits."""
 
 from typing import List, Sequence
 
@@ -24,7 +26,7 @@ from .synthetic import cylindrical as _cylindrical_host
 
 def prepare_clouds(clouds: Sequence, coordinates: str = 'cartesian', normalize: bool = True,
                    scale_factor=None, unit_sphere_norm: bool = False, zero_mean: bool = True,
-                   cylindrical: str = 'host', device='cuda') -> List[torch.Tensor]:
+                   cylindrical: str = 'device', device='cuda') -> List[torch.Tensor]:
     """List of raw (n_i, 3) clouds (numpy / torch, any device) -> list of (m_i, 3) float32 CUDA tensors ready for
     `Points(...)` / `build_batch_octree`.  Arguments mirror `TrainingParams.normalize_points / scale_factor /
     unit_sphere_norm / zero_mean` (`misc/utils.py:210-213`) and `ModelParams.coordinates`."""

@@ -39,7 +39,7 @@ def test_prepare_clouds_bit_exact_per_case(golden_dir):
     g = _golden(golden_dir)
     for name, (seed, n, kind, extent, offset, normalize, coords) in CASES.items():
         raw = raw_cloud(seed, n, kind, extent, offset)
-        got = prepare_clouds([raw], coordinates=coords, normalize=normalize)[0]
+        got = prepare_clouds([raw], coordinates=coords, normalize=normalize, cylindrical='host')[0]
         assert got.is_cuda and got.dtype == torch.float32
         got = got.cpu().numpy()
         if coords == 'cartesian':           # normalisation + |x| <= 1 mask: bit-exact against the reference's output
@@ -60,7 +60,7 @@ def test_prepare_clouds_batched_and_feeds_the_octree_build(golden_dir):
     g = _golden(golden_dir)
     names = ['wp_forest', 'wp_ball', 'tiny']                        # all cylindrical + normalised: one batch
     raws = [raw_cloud(*CASES[k][:5]) for k in names]
-    got = prepare_clouds(raws, coordinates='cylindrical', normalize=True)
+    got = prepare_clouds(raws, coordinates='cylindrical', normalize=True, cylindrical='host')
     want = [preprocess_ref.prepare_cloud(torch.from_numpy(r), True, 'cylindrical').numpy() for r in raws]
     for k, t, w in zip(names, got, want):
         assert np.array_equal(t.cpu().numpy(), w), k                       # batched == one by one == oracle here
@@ -90,6 +90,14 @@ def test_device_side_cylindrical_transform_within_ulps(golden_dir):
         total += len(want)
     print('device-side cylindrical: %d of %d points changed depth-7 cell' % (moved, total))
     assert moved <= max(3, total // 1000)
+
+
+def test_default_is_the_device_side_transform(golden_dir):
+    """The default keeps the batch on the device (no per-cloud host round trip): equal to cylindrical='device' bit for bit."""
+    raws = [raw_cloud(*CASES[k][:5]) for k in ('wp_forest', 'wp_ball')]
+    a = prepare_clouds(raws, coordinates='cylindrical', normalize=True)
+    b = prepare_clouds(raws, coordinates='cylindrical', normalize=True, cylindrical='device')
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
 
 
 def test_prepare_clouds_rejects_unsupported_modes():
