@@ -807,11 +807,13 @@ window_attn_kernel_v5(const WinParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int hw = tid >> 6;
-  const int h = blockIdx.y * nhw + hw;
+  const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;                // dispatch order (probes)
+  const int gy = blockIdx.y;
+  const int h = gy * nhw + hw;
   const int c = lane & 15, g = lane >> 4;
 
   if (RPE) {
-    const float4* src = reinterpret_cast<const float4*>(p.rpe2 + (size_t)blockIdx.y * nhw * TS);
+    const float4* src = reinterpret_cast<const float4*>(p.rpe2 + (size_t)gy * nhw * TS);
     float4* dst = reinterpret_cast<float4*>(s_tab);
     for (int i = tid; i < nhw * TS / 4; i += blockDim.x) dst[i] = src[i];
   }
@@ -823,13 +825,22 @@ window_attn_kernel_v5(const WinParams p) {
     reinterpret_cast<uint4*>(s_v + LP * 64)[i] = make_uint4(0u, 0u, 0u, 0u);
   const float mask2 = kMaskValue * 1.4426950408889634f;
   const float rt_add = (g == 0) ? 0.f : kDeadValue;   // the relay key lives in the g == 0 lanes only
-  const uint32_t row_q = (uint32_t)(3 * C) * 4u;       // bytes per qkv row (same as fp32 qkv)
+  // (probe build 3: head-group-major addressing of the SAME byte volume -- [head group][row][Q | K | V][heads of the group] --
+  // to price the operand layout; results are garbage)
+  const uint32_t hgw = (uint32_t)nhw * 64u;             // bytes of one region of one head group
+  const uint32_t row_q = HFL_ATT_TRACE == 3 ? 3u * hgw : (uint32_t)(3 * C) * 4u;       // bytes per qkv row (same as fp32 qkv)
   const char* qkv_b = reinterpret_cast<const char*>(p.qkv);
   char* out_b = reinterpret_cast<char*>(p.out);
-  const uint32_t col_k = (uint32_t)C * 4u + (uint32_t)h * 64u + (uint32_t)g * 16u;        // chunk g of [k_hi | k_lo]
-  const uint32_t col_v = (uint32_t)C * 8u + (uint32_t)h * 64u + (uint32_t)g * 16u;
-  const uint32_t col_qh = (uint32_t)h * 64u + (uint32_t)(g & 1) * 16u;                   // [q_hi | q_hi]
-  const uint32_t col_ql = col_qh + 32u;                                                   // [q_lo | q_lo]
+  const uint32_t rows_all = (uint32_t)(G > 0 ? p.rt_row0 + p.n_windows : p.n_tokens);
+  const uint32_t hg_base = HFL_ATT_TRACE == 3 ? (uint32_t)gy * rows_all * 3u * hgw : 0u;
+  // this lane's 16-B chunk of the head's 64 B in the Q region (K and V: + C * 4, + C * 8)
+  const uint32_t col_l = HFL_ATT_TRACE == 3 ? hg_base + (uint32_t)hw * 64u + (uint32_t)(lane & 3) * 16u
+                                            : (uint32_t)h * 64u + (uint32_t)(lane & 3) * 16u;
+  // LDS block of the wave, 64-B rows: 16-B chunk j of row r sits in slot j ^ ((r >> 2) & 3), so that both the row-per-quad
+  // accesses (lane l: row l >> 2, chunk l & 3) and the operand accesses (lane (c, g): row c, chunk g) are conflict-free
+  const uint32_t reg_k = HFL_ATT_TRACE == 3 ? hgw : (uint32_t)C * 4u;              // Q -> K -> V region stride
+  const int st_quad = (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  const int st_row = c * 64, st_x = (c >> 2) & 3;
   // transposed V reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its 4-key block
   const int tr_off = ((4 * g + (c >> 2)) * 64) + (c & 3) * 8;
 
@@ -839,7 +850,11 @@ window_attn_kernel_v5(const WinParams p) {
 
   const int tstep = p.D;
   // ---- request a window: metadata word + every fragment of this wave's head (index arithmetic only) ----------------
-  auto request = [&](int w, uint2& mt, uint4 (&ka)[T], uint4 (&qh)[T], uint4 (&ql)[T], uint4 (&vr)[T]) {
+  // A quad of lanes reads ONE row's 64 B (lane l: row l >> 2 of the tile, 16-B chunk l & 3): 16 requests per load
+  // instruction instead of the 64 of the MFMA operand mapping (lane (c, g): row c, chunk g -- four rows per quad), and the
+  // query row comes in once instead of as a [hi | hi] and a [lo | lo] load.  The operand mapping is restored through this
+  // wave's LDS block (stage_in below).  Measured with the addresses alone swapped: -13 % on the depth-4 launch.
+  auto request = [&](int w, uint2& mt, uint4 (&kr)[T], uint4 (&qr)[T], uint4 (&vr)[T]) {
     const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
     const int rt_row = (int)p.rt_row0 + w;
     mt = make_uint2(0u, 0xFFFFFFFFu);
@@ -853,18 +868,17 @@ window_attn_kernel_v5(const WinParams p) {
       bool ok;
       if (G > 0 && t == T - 1) {
         row = rt_row;
-        ok = (c == 0);
+        ok = (lane >> 2) == 0;
       } else {
-        row = tok0 + (t * 16 + c) * tstep;
+        row = tok0 + (t * 16 + (lane >> 2)) * tstep;
         ok = row < n_tok;
       }
-      ka[t] = qh[t] = ql[t] = vr[t] = zero4;
+      kr[t] = qr[t] = vr[t] = zero4;
       if (ok) {
-        const char* base = qkv_b + (uint32_t)row * row_q;
-        ka[t] = *reinterpret_cast<const uint4*>(base + col_k);
-        qh[t] = *reinterpret_cast<const uint4*>(base + col_qh);
-        ql[t] = *reinterpret_cast<const uint4*>(base + col_ql);
-        vr[t] = *reinterpret_cast<const uint4*>(base + col_v);
+        const char* base = qkv_b + (uint32_t)row * row_q + col_l;
+        qr[t] = *reinterpret_cast<const uint4*>(base);
+        kr[t] = *reinterpret_cast<const uint4*>(base + reg_k);
+        vr[t] = *reinterpret_cast<const uint4*>(base + 2u * reg_k);
       }
     }
   };
@@ -879,26 +893,25 @@ window_attn_kernel_v5(const WinParams p) {
       if (orow_hold[t] >= 0) att_store_row4(out_b, (uint32_t)orow_hold[t], C, h * 16 + 4 * g, o_hold[t], p.out_split);
   };
   uint2 mt_n = make_uint2(0u, 0xFFFFFFFFu);
-  uint4 ka_n[T], qh_n[T], ql_n[T], vr_n[T];
-  if (PF && (int)blockIdx.x < p.n_windows) request(blockIdx.x, mt_n, ka_n, qh_n, ql_n, vr_n);
+  uint4 kr_n[T], qr_n[T], vr_n[T];
+  if (PF && (int)blockIdx.x < p.n_windows) request(blockIdx.x, mt_n, kr_n, qr_n, vr_n);
 
   const bool trace_on = HFL_ATT_TRACE && (p.dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && hw == 0;
-  const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
   if (HFL_ATT_TRACE && (p.dbg & 8) && tid == 0 && wg_lin < 4096) g_att_wg[2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
   int it = 0;
   for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
     const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
     const int rt_row = (int)p.rt_row0 + w;
     uint2 mt;
-    uint4 ka[T], qh[T], ql[T], vr[T];
+    uint4 kr[T], qr[T], vr[T];
     HFL_ATT_STAMP(0)
     if (HFL_ATT_TRACE && trace_on && it < 16 && lane == 0) g_att_trace[it * 8 + 7] = __builtin_amdgcn_s_memrealtime();     // 100 MHz
     if (PF) {
       mt = mt_n;
 #pragma unroll
-      for (int t = 0; t < T; ++t) { ka[t] = ka_n[t]; qh[t] = qh_n[t]; ql[t] = ql_n[t]; vr[t] = vr_n[t]; }
+      for (int t = 0; t < T; ++t) { kr[t] = kr_n[t]; qr[t] = qr_n[t]; vr[t] = vr_n[t]; }
     } else {
-      request(w, mt, ka, qh, ql, vr);
+      request(w, mt, kr, qr, vr);
     }
     int4* s_qry = s_qry0 + (it & 1) * LP;
     int2* s_key = s_key0 + (it & 1) * LP;
@@ -925,9 +938,23 @@ window_attn_kernel_v5(const WinParams p) {
       }
       s_kbid[j] = bid;
     }
-    // stage this head's V rows exactly as loaded: row (tile, key) = 64 B [16 x hi | 16 x lo], lane (c, g) owns chunk g
+    // row-per-quad registers -> MFMA operand registers through the wave's LDS block (LDS operations of one wave execute in
+    // order, so the block is reused: Q, then K, then the V image that the transposed reads below need)
+    uint4 ka[T], qh[T], ql[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) *reinterpret_cast<uint4*>(s_v + (t * 16 + c) * 64 + g * 16) = vr[t];
+    for (int t = 0; t < T; ++t) *reinterpret_cast<uint4*>(s_v + t * 1024 + st_quad) = qr[t];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      qh[t] = *reinterpret_cast<const uint4*>(s_v + t * 1024 + st_row + (((g & 1) ^ st_x) * 16));         // [q_hi | q_hi]
+      ql[t] = *reinterpret_cast<const uint4*>(s_v + t * 1024 + st_row + (((2 + (g & 1)) ^ st_x) * 16));   // [q_lo | q_lo]
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<uint4*>(s_v + t * 1024 + st_quad) = kr[t];
+#pragma unroll
+    for (int t = 0; t < T; ++t) ka[t] = *reinterpret_cast<const uint4*>(s_v + t * 1024 + st_row + ((g ^ st_x) * 16));
+    // V rows as loaded, unswizzled: row (tile, key) = 64 B [16 x hi | 16 x lo]
+#pragma unroll
+    for (int t = 0; t < T; ++t) *reinterpret_cast<uint4*>(s_v + t * 1024 + lane * 16) = vr[t];
     __syncthreads();
     HFL_ATT_STAMP(1)
     const int bid0 = s_kbid[0], bidl = s_kbid[K - 1];
@@ -967,7 +994,7 @@ window_attn_kernel_v5(const WinParams p) {
       // one counter for loads and stores, and a store issued at the end of a window would make the top of the next one wait
       // for its acknowledgement (measured: ~3.6 k cycles per window)
       flush();
-      if (w + (int)gridDim.x < p.n_windows) request(w + (int)gridDim.x, mt_n, ka_n, qh_n, ql_n, vr_n);
+      if (w + (int)gridDim.x < p.n_windows) request(w + (int)gridDim.x, mt_n, kr_n, qr_n, vr_n);
     }
     HFL_ATT_STAMP(2)
 
@@ -982,6 +1009,14 @@ window_attn_kernel_v5(const WinParams p) {
         const int qxa = qm.x + tabb, qyza = qm.y + (RPE == 2 ? tabb * 0x10001 : tabb);
         const att_h8 bqh = __builtin_bit_cast(att_h8, qh[qt]);
         const att_h8 bql = __builtin_bit_cast(att_h8, ql[qt]);
+        if (HFL_ATT_TRACE >= 2) {      // probe build: the kernel's memory pattern alone (every load consumed, every row stored)
+          const uint4 m = make_uint4(ka[qt].x ^ qh[qt].x ^ ql[qt].x ^ (uint32_t)vhi[qt / 2][0], ka[qt].y ^ qh[qt].y ^ ql[qt].y,
+                                     ka[qt].z ^ qh[qt].z ^ ql[qt].z, ka[qt].w ^ qh[qt].w ^ ql[qt].w);
+          const int orow_m = is_rt ? (c == 0 ? rt_row : -1) : qm.w;
+          if (orow_m >= 0)
+            att_store_row4(out_b, (uint32_t)orow_m, C, h * 16 + 4 * g, __builtin_bit_cast(f32x4, m), p.out_split);
+          continue;
+        }
 
         f32x4 s[T];
 #pragma unroll
@@ -1093,6 +1128,20 @@ window_attn_kernel_v5(const WinParams p) {
         if (PF) {
           o_hold[qt] = o;
           orow_hold[qt] = orow;
+        } else if (p.out_split == 2) {
+          // split2 rows for the proj GEMM: the tile's 16 x [16 hi | 16 lo] bf16 goes through the LDS block (its V image is in
+          // registers by now) and leaves as ONE 16-B store per lane, a quad of lanes per row (two 32-B segments of one line)
+          uint2 hi, lo;
+          x3_split_pair_scalar(o[0], o[1], hi.x, lo.x);
+          x3_split_pair_scalar(o[2], o[3], hi.y, lo.y);
+          *reinterpret_cast<uint2*>(s_v + st_row + (((g >> 1) ^ st_x) * 16) + (g & 1) * 8) = hi;
+          *reinterpret_cast<uint2*>(s_v + st_row + (((2 + (g >> 1)) ^ st_x) * 16) + (g & 1) * 8) = lo;
+          const uint4 v = *reinterpret_cast<const uint4*>(s_v + st_quad);
+          const int rl = lane >> 2, ch = lane & 3;
+          const int orow_l = is_rt ? (rl == 0 ? rt_row : -1) : s_qry[qt * 16 + rl].w;
+          if (orow_l >= 0)
+            *reinterpret_cast<uint4*>(out_b + (size_t)orow_l * (uint32_t)(4 * C) +
+                                      (uint32_t)((h >> 1) * 128 + (h & 1) * 32 + (ch & 1) * 16 + (ch >> 1) * 64)) = v;
         } else if (orow >= 0) {
           att_store_row4(out_b, (uint32_t)orow, C, h * 16 + 4 * g, o, p.out_split);
         }

@@ -76,3 +76,11 @@ hist = np.histogram(st, bins=8)
 print('start histogram:', list(zip(np.round(hist[1][:-1], 1).tolist(), hist[0].tolist())))
 hist = np.histogram(en, bins=8)
 print('end histogram:  ', list(zip(np.round(hist[1][:-1], 1).tolist(), hist[0].tolist())))
+life = (a[:, 1] - a[:, 0]) / 100.0
+n = len(a)
+print('lifetime by (workgroup id % 8) [XCD under round-robin dispatch]:', [round(float(life[i::8].mean()), 1) for i in range(8)],
+      ' spread inside one class: min %.1f max %.1f' % (life[0::8].min(), life[0::8].max()))
+gx = n // 4 if n % 4 == 0 else n
+print('lifetime by head group (blockIdx.y):', [round(float(life[i * gx:(i + 1) * gx].mean()), 1) for i in range(n // gx)])
+cu = life[:gx].reshape(-1, 8)[:, 0]
+print('XCD-0 workgroups of head group 0, in dispatch order:', np.round(cu, 1).tolist())
