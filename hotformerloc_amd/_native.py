@@ -138,8 +138,8 @@ SIGNATURES = {
                                   c_float, c_void_p]),
     'hfl_gemm_bf16_tn': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_gemm_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
-    'hfl_window_rpe_expand_size': (c_int64, [c_int, c_int, c_int]),
-    'hfl_window_rpe_expand': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'hfl_window_rpe_expand_size': (c_int64, [c_int, c_int, c_int, c_int]),
+    'hfl_window_rpe_expand': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),
     'hfl_relay_token_init': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

@@ -977,6 +977,8 @@ window_attn_kernel_v5(const WinParams p) {
       vlo[pp] = __builtin_bit_cast(att_h8, ll);
     }
 
+    // table offsets of this lane's keys stay in registers (24 at K = 48).  (Re-reading them per query tile to fit 128 VGPRs and
+    // a fourth wave per SIMD: depth 5 53 -> 51 us, depth 4 70 -> 78 us with 11 spilled dwords, depth 3 21 -> 29 us: dropped.)
     int kxa[TW][4], kyza[TW][4];
     if (RPE) {
 #pragma unroll
@@ -1205,14 +1207,21 @@ rpe_expand3_kernel(float* __restrict__ out, const float* __restrict__ table, int
 
 // which expanded form a (depth, pos_bnd) pair takes: 1 = x table + y-z table (no clamp needed, depth <= 5), 2 = three
 // clamped 1-D tables (depth <= 7), 0 = none (the three-lookup kernel v2 reads the original table)
-static inline int rpe_form(int depth, int bnd) {
+// which expanded form a (depth, pos_bnd) pair takes, per consumer: the fp32 kernel (v4) knows form 1 only; the fp16 kernel (v5)
+// takes form 1 up to depth 4 and form 2 beyond -- at depth 5 the (2R+1)^2 y-z table is 16 KB per head, which left room for
+// 6 waves per CU only; the three 1-D tables (768 B per head) let 12 stay resident: 61.5 -> 53 us on the depth-5 bench launch
+// in spite of the third lookup (at depth 4, 4 KB per head, form 1 is the faster one: 70 vs 73 us)
+static int g_rpe_form1_max_depth = 4;       // probe knob 'window_rpe_form1_max_depth' (fp16 kernel)
+static inline int rpe_form(int depth, int bnd, int f16) {
   if (depth < 1 || depth > 7) return 0;
-  if (depth <= 5 && ((1 << depth) - 1) <= bnd) return 1;
+  const bool fits = depth <= 5 && ((1 << depth) - 1) <= bnd;
+  if (!f16) return fits ? 1 : 0;
+  if (fits && depth <= g_rpe_form1_max_depth) return 1;
   return 2;
 }
-static inline size_t rpe_form_floats(int depth, int bnd) {      // per head
+static inline size_t rpe_form_floats(int depth, int bnd, int f16) {      // per head
   const int W = 2 * ((1 << depth) - 1) + 1;
-  const int f = rpe_form(depth, bnd);
+  const int f = rpe_form(depth, bnd, f16);
   return f == 1 ? (size_t)((W + W * W + 3) & ~3) : f == 2 ? (size_t)((3 * W + 3) & ~3) : 0;
 }
 
@@ -1247,8 +1256,8 @@ static int launch_window(const WinParams& p, hipStream_t s) {
       // fp16 (hi, lo) operand layout: only the v5 kernel reads it (callers ask hfl_window_attention_f16_ok first).
       // Heads per workgroup: 4, or 2 when the expanded RPE tables of 4 heads do not leave room in LDS (depth 5)
       const int np5 = (T + 1) / 2;
-      const int form = p.table ? rpe_form(p.depth, p.bnd) : 0;
-      const size_t ts5 = p.table ? rpe_form_floats(p.depth, p.bnd) : 0;
+      const int form = p.table ? rpe_form(p.depth, p.bnd, 1) : 0;
+      const size_t ts5 = p.table ? rpe_form_floats(p.depth, p.bnd, 1) : 0;
       int hp5 = hpw;
       size_t lds5 = 0;
       for (;; hp5 >>= 1) {
@@ -1422,6 +1431,7 @@ int hfl_set_variant(const char* key, int value) {
     g_window_v4_wgs_per_cu = 1;
     g_window_dbg = 0;
     g_window_pf = 0;
+    g_rpe_form1_max_depth = 4;
     g_window_v2_wgs_per_cu = 16;
     g_window_heads_per_wg = 4;
     hfl_internal_set_window_bwd(2);
@@ -1441,6 +1451,8 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_cpe_chunk(value);
   } else if (is("window_debug")) {
     g_window_dbg = value;
+  } else if (is("window_rpe_form1_max_depth")) {
+    g_rpe_form1_max_depth = value;
   } else if (is("window_pf")) {
     g_window_pf = value;
   } else if (is("window_v4_wgs_per_cu")) {
@@ -1459,21 +1471,21 @@ int hfl_set_variant(const char* key, int value) {
  * configuration: the v5 kernel needs the expanded RPE table (depth <= 5, no clamp) and <= 72 KiB of LDS */
 int hfl_window_attention_f16_ok(const hfl_window_attn_desc* d, int64_t n_rows_total) {
   if (d == nullptr || d->n_heads <= 0 || d->patch_size % 16 != 0) return 0;
-  if (rpe_form(d->depth, d->pos_bnd) == 0) return 0;
+  if (rpe_form(d->depth, d->pos_bnd, 1) == 0) return 0;
   if (g_window_variant != 4) return 0;
   const int T = d->patch_size / 16 + d->n_relay;
   if (T < 1 || T > 5) return 0;
   int hpw = g_window_heads_per_wg;
   if (hpw < 1 || hpw > 4 || d->n_heads % hpw != 0) hpw = (d->n_heads % 4 == 0) ? 4 : (d->n_heads % 2 == 0) ? 2 : 1;
   const int LP = T * 16;
-  const size_t ts5 = rpe_form_floats(d->depth, d->pos_bnd);
+  const size_t ts5 = rpe_form_floats(d->depth, d->pos_bnd, 1);
   size_t lds5 = 0;
   for (;; hpw >>= 1) {        // as the launcher: 4 heads per workgroup, or 2 when their tables crowd the LDS
     lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts5 * 4 + (size_t)hpw * (2 * ((T + 1) / 2) * 16) * 64;
     if (lds5 <= 72 * 1024 || hpw <= 2 || d->n_heads % (hpw / 2) != 0) break;
   }
   const int W5 = 2 * ((1 << d->depth) - 1) + 1;
-  if (rpe_form(d->depth, d->pos_bnd) == 2 && (size_t)hpw * ts5 * 4 + 12 * (size_t)W5 >= 65536) return 0;
+  if (rpe_form(d->depth, d->pos_bnd, 1) == 2 && (size_t)hpw * ts5 * 4 + 12 * (size_t)W5 >= 65536) return 0;
   if (lds5 > 72 * 1024 || hpw * 64 < LP) return 0;
   if (n_rows_total * 3 * d->n_heads * 16 * 4 >= (int64_t)1 << 32) return 0;
   return 1;
@@ -1526,16 +1538,16 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
   }
 }
 
-int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth) {
+int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth, int f16_operand) {
   if (n_heads <= 0 || pos_bnd < 0) return 0;
-  return (int64_t)n_heads * (int64_t)rpe_form_floats(depth, pos_bnd);
+  return (int64_t)n_heads * (int64_t)rpe_form_floats(depth, pos_bnd, f16_operand ? 1 : 0);
 }
 
-int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth,
+int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth, int f16_operand,
                           hfl_stream_t stream) {
-  const int64_t n = hfl_window_rpe_expand_size(n_heads, pos_bnd, depth);
+  const int64_t n = hfl_window_rpe_expand_size(n_heads, pos_bnd, depth, f16_operand);
   if (n <= 0 || out == nullptr || rpe_table == nullptr) return HFL_EINVAL;
-  if (rpe_form(depth, pos_bnd) == 1)
+  if (rpe_form(depth, pos_bnd, f16_operand ? 1 : 0) == 1)
     rpe_expand_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
         out, rpe_table, n_heads, pos_bnd, (1 << depth) - 1);
   else

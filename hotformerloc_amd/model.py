@@ -681,7 +681,7 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     from ._native import WindowAttnDesc
     table = None if att.rpe is None else att.rpe.rpe_table
     bnd = int(0.8 * att.patch_size * att.dilation ** 0.5)
-    expanded = None if table is None else ops.rpe_expand(table, att.num_heads, bnd, depth)
+    expanded = None if table is None else ops.rpe_expand(table, att.num_heads, bnd, depth, True)
     if table is not None and expanded is None:
         return None
     mlp = block.mlp

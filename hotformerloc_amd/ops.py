@@ -701,15 +701,15 @@ def pad_index(row_off: torch.Tensor, batch: int, nmax: int):
 _RPE2_CACHE = {}        # (id(table), depth) -> (weakref to table, version, expanded table)
 
 
-def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int):
-    """Expanded relative-position table of the two-lookup window kernel (hfl_window_rpe_expand), cached
-    per (table, depth) and rebuilt when the table is modified in place.  None when the depth is not
-    eligible (deeper than 5 or coordinates beyond pos_bnd)."""
+def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int, f16: bool = False):
+    """Expanded relative-position table of the window kernels (hfl_window_rpe_expand) for the fp32-qkv kernel or, with
+    `f16`, for the fp16 (hi, lo) one (the two take different forms at depth 5+), cached per (table, depth, consumer) and
+    rebuilt when the table is modified in place.  None when the consumer has no expanded form for this depth."""
     lib = _native.load()
-    n = lib.hfl_window_rpe_expand_size(n_heads, pos_bnd, depth)
+    n = lib.hfl_window_rpe_expand_size(n_heads, pos_bnd, depth, int(f16))
     if n <= 0:
         return None
-    key = (id(rpe_table), depth)
+    key = (id(rpe_table), depth, bool(f16))
     hit = _RPE2_CACHE.get(key)
     # data_ptr / device: `module.to(...)` swaps `.data` without bumping the version counter
     if (hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version and hit[3] == rpe_table.data_ptr()
@@ -717,7 +717,7 @@ def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int):
         return hit[2]
     out = torch.empty(n, dtype=torch.float32, device=rpe_table.device)
     src = _f32c(rpe_table.detach())
-    check(lib.hfl_window_rpe_expand(out.data_ptr(), src.data_ptr(), n_heads, pos_bnd, depth, _stream()),
+    check(lib.hfl_window_rpe_expand(out.data_ptr(), src.data_ptr(), n_heads, pos_bnd, depth, int(f16), _stream()),
           'hfl_window_rpe_expand')
     if len(_RPE2_CACHE) > 512:
         _RPE2_CACHE.clear()
@@ -752,7 +752,7 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     table_ptr = None
     if rpe_table is not None:
         assert tuple(rpe_table.shape) == (3 * (2 * desc.pos_bnd + 1), n_heads)
-        expanded = rpe_expand(rpe_table, n_heads, desc.pos_bnd, depth)   # keeps the tensor alive below
+        expanded = rpe_expand(rpe_table, n_heads, desc.pos_bnd, depth, qkv_f16)   # keeps the tensor alive below
         if expanded is not None:
             desc.rpe_expanded = expanded.data_ptr()
         rpe_table = _f32c(rpe_table)

@@ -219,12 +219,17 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
                                 const uint32_t* tok_meta, const float* rpe_table,
                                 const hfl_window_attn_desc* desc, int out_split3, hfl_stream_t stream);
 
-/* Expanded relative-position table for the forward kernel: per head the x-axis table restricted to
- * |dx| <= R = 2^depth - 1 followed by the pre-added (dy, dz) table of (2R+1)^2 entries, scaled by
- * log2(e).  Valid when R <= pos_bnd and depth <= 5 (size() returns 0 otherwise: use the plain path).
- * out holds hfl_window_rpe_expand_size() floats; rebuild it whenever rpe_table changes. */
-int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth);
-int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth,
+/* Expanded relative-position table for the forward kernels, scaled by log2(e); which form is built depends on the consumer:
+ *   f16_operand = 0 (fp32 qkv kernel): per head the x-axis table restricted to |dx| <= R = 2^depth - 1 followed by the
+ *     pre-added (dy, dz) table of (2R+1)^2 entries; valid when R <= pos_bnd and depth <= 5 (size() returns 0 otherwise:
+ *     the three-lookup kernel reads rpe_table itself)
+ *   f16_operand = 1 (fp16 (hi, lo) qkv kernel, flag 0x100 of hfl_window_attention_fwd_ex): that form up to depth 4; from
+ *     depth 5 (and whenever R > pos_bnd) three 1-D tables over the full coordinate range with the reference's clamp baked
+ *     in (depth <= 7)
+ * out holds hfl_window_rpe_expand_size() floats; rebuild it whenever rpe_table changes.  A table built for one consumer
+ * must not be handed to the other. */
+int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth, int f16_operand);
+int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int pos_bnd, int depth, int f16_operand,
                           hfl_stream_t stream);
 
 /* Linear on the split operands through hipBLASLt, with the block's epilogue in the same launch:
