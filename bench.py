@@ -350,7 +350,20 @@ def main():
                     step()
                 torch.cuda.synchronize()
             kern_all = t_all.summary()
-            if not args.no_streams:
+            if args.gemm == 'x3':
+                # the default path issues its launches from native code (hfl_block_forward_x3, and ONE window-attention
+                # launch for the two coarse pyramid levels of an iteration): the library records a HIP event pair around
+                # every fp16 window-attention launch, on the launch stream -- the launches of the timed region itself,
+                # first with the step's streams, then the same schedule on one stream ('serial': events bracket the
+                # kernel alone, what rocprofv3 --kernel-trace reports)
+                kern_all[ATTN], _ = native_attention_timing(step, args.steps)
+                if not args.no_streams:
+                    set_pyramid_streams('serial')
+                    step()
+                    rec, iso_sizes = native_attention_timing(step, args.steps)
+                    kern_iso = {ATTN: rec}
+                    set_pyramid_streams(True)
+            elif not args.no_streams:
                 set_pyramid_streams(False)
                 step()
                 torch.cuda.synchronize()
@@ -473,6 +486,35 @@ def bench_clouds(syn, params, args, rank):
     return syn.make_clouds(2, args.batch, args.points, params.coordinates, first_index=rank * args.batch)
 
 
+def native_attention_timing(step, steps):
+    """(launches, ms, algorithmic bytes, flops, moved bytes) and the by-size groups of the fp16 window-attention launches of
+    `steps` product-path steps, from the event pairs the library records around each launch (hfl_internal_attn_timing)."""
+    import ctypes
+    import torch
+    from hotformerloc_amd import _native
+    lib = _native.load()
+    lib.hfl_internal_attn_timing.argtypes = [ctypes.c_int]
+    lib.hfl_internal_attn_timing_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.hfl_internal_attn_timing(1)
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        cap = 1 << 16
+        ms, nb, fl = (ctypes.c_double * cap)(), (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+        n = lib.hfl_internal_attn_timing_read(ms, nb, fl, cap)
+        assert 0 < n <= cap, n
+    finally:
+        lib.hfl_internal_attn_timing(0)
+    groups = {}
+    for i in range(n):
+        c, t = groups.get(int(nb[i]), (0, 0.0))
+        groups[int(nb[i])] = (c + 1, t + ms[i])
+    tot_b = sum(nb[i] for i in range(n))
+    rec = (n, sum(ms[i] for i in range(n)), int(tot_b), int(sum(fl[i] for i in range(n))), int(tot_b))
+    return rec, [(b, c, t) for b, (c, t) in sorted(groups.items(), reverse=True)]
+
+
 def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32, serialised):
     rec = (kern or {}).get(ATTN)
     if not rec:
@@ -514,8 +556,8 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
                        'after the timed region, never inside it; agrees with rocprofv3 --kernel-trace)' % args.steps)
                       if serialised else 'HIP events per launch, re-run after the timed region with the streams of the step'}
     if sizes:
-        # the step's launches by size: one per pyramid depth and block (34 here); the depth-2 / depth-3 launches
-        # hold 2 % / 13 % of the bytes and are latency-bound (a few windows per CU)
+        # the step's launches by size: depth 5 (octf stage), depth 4, and depths 3 + 2 together in one launch (24 per step
+        # here); the coarse levels hold 15 % of the bytes and are latency-bound (a few windows per CU)
         roof['by_launch_size'] = [{'algorithmic_bytes_per_launch': b, 'launches': c,
                                    'avg_launch_us': round(ms_ * 1e3 / c, 2),
                                    'frac': round(b * c / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}

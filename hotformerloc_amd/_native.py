@@ -90,6 +90,7 @@ SIGNATURES = {
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
     'hfl_window_attention_fwd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             ctypes.POINTER(WindowAttnDesc), c_int, c_void_p]),
+    'hfl_window_attention_fwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'hfl_layer_norm_split3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_float, c_void_p]),
     'hfl_add_layer_norm_split3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -116,6 +117,7 @@ SIGNATURES = {
     'hfl_split2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_block_forward_x3_arena': (c_int64, [c_int64, c_int64]),
     'hfl_block_forward_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'hfl_block_attention_x3_multi': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'hfl_relay_block_forward_x3_arena': (c_int64, [c_int64, c_int64]),
     'hfl_relay_block_forward_x3': (c_int, [c_void_p, c_void_p, c_void_p]),
     'hfl_linear_x3_grouped': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),

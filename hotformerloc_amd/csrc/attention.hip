@@ -23,6 +23,7 @@
 #include "x3_math.h"
 
 #include <cstring>
+#include <vector>
 #include <type_traits>
 
 namespace {
@@ -777,19 +778,33 @@ __device__ unsigned long long g_att_wg[4096 * 2];      // probe: s_memrealtime a
     if (it < 16 && lane == 0) g_att_trace[it * 8 + (slot)] = t_;                                 \
   }
 
-// PF = 1: the fragments and the metadata word of the workgroup's NEXT window are requested into a second register set
-// before the softmax of the current one starts (2 waves per SIMD, <= 256 VGPRs): a wave no longer alternates between a
-// load phase and a compute phase, so the memory latency is hidden inside one wave instead of across three.
-constexpr int v5_waves_per_simd(int T, int G, int PF) { return PF ? 2 : v4_waves_per_simd(T, G); }
+// (A variant that requested the NEXT window's fragments into a second register set before the softmax of the current one --
+// 2 waves per SIMD, <= 256 VGPRs, outputs held back so that no store sits in front of the next `s_waitcnt vmcnt(0)` -- was
+// neutral: 65.7 / 81.5 us against 68 / 80.5 us on the depth-5 / depth-4 launches; removed.)
+//
+// ONE launch can serve several attention problems of the same shape (the pyramid levels of an H-OSA iteration: same K, G,
+// heads and table form, different depths and row counts): blockIdx.x ranges are dealt to the problems in proportion to their
+// window counts and each workgroup stays inside its problem.  The depth-2 / depth-3 launches of the bench (2 k / 14 k rows:
+// 14 us and 21 us alone, one or two windows per workgroup, latency-bound) then ride along with the depth-4 one.
+constexpr int kWinMulti = 4;
+struct WinMultiParams {
+  WinParams p[kWinMulti];
+  int first[kWinMulti + 1];      // blockIdx.x range of problem i: [first[i], first[i + 1])
+  int n;
+};
 
-template <int T, int G, int RPE, int PF>
+template <int T, int G, int RPE>
 __global__ void __launch_bounds__(256)
-    __attribute__((amdgpu_waves_per_eu(v5_waves_per_simd(T, G, PF), v5_waves_per_simd(T, G, PF))))
-window_attn_kernel_v5(const WinParams p) {
+    __attribute__((amdgpu_waves_per_eu(v4_waves_per_simd(T, G), v4_waves_per_simd(T, G))))
+window_attn_kernel_v5(const WinMultiParams m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LP = T * 16;
   constexpr int TW = T - G;
   constexpr int NP = (T + 1) / 2;                      // pairs of key tiles (K = 32 per PV MFMA)
+  int prob = 0;
+  while (prob + 1 < m.n && (int)blockIdx.x >= m.first[prob + 1]) ++prob;
+  const WinParams& p = m.p[prob];
+  const int wg_x = (int)blockIdx.x - m.first[prob], wg_nx = m.first[prob + 1] - m.first[prob];
   typedef __attribute__((address_space(3))) const float lds_f32;
   const int H = p.H, K = p.K;
   const int C = H * 16;
@@ -882,37 +897,17 @@ window_attn_kernel_v5(const WinParams p) {
       }
     }
   };
-  // PF: output rows of the window just finished, stored at the start of the next one
-  f32x4 o_hold[T];
-  int orow_hold[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) orow_hold[t] = -1;
-  auto flush = [&]() {
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (orow_hold[t] >= 0) att_store_row4(out_b, (uint32_t)orow_hold[t], C, h * 16 + 4 * g, o_hold[t], p.out_split);
-  };
-  uint2 mt_n = make_uint2(0u, 0xFFFFFFFFu);
-  uint4 kr_n[T], qr_n[T], vr_n[T];
-  if (PF && (int)blockIdx.x < p.n_windows) request(blockIdx.x, mt_n, kr_n, qr_n, vr_n);
-
   const bool trace_on = HFL_ATT_TRACE && (p.dbg & 8) && blockIdx.x == 0 && blockIdx.y == 0 && hw == 0;
   if (HFL_ATT_TRACE && (p.dbg & 8) && tid == 0 && wg_lin < 4096) g_att_wg[2 * wg_lin] = __builtin_amdgcn_s_memrealtime();
   int it = 0;
-  for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x, ++it) {
+  for (int w = wg_x; w < p.n_windows; w += wg_nx, ++it) {
     const int tok0 = (p.D == 1) ? w * K : (w / p.D) * K * p.D + (w % p.D);
     const int rt_row = (int)p.rt_row0 + w;
     uint2 mt;
     uint4 kr[T], qr[T], vr[T];
     HFL_ATT_STAMP(0)
     if (HFL_ATT_TRACE && trace_on && it < 16 && lane == 0) g_att_trace[it * 8 + 7] = __builtin_amdgcn_s_memrealtime();     // 100 MHz
-    if (PF) {
-      mt = mt_n;
-#pragma unroll
-      for (int t = 0; t < T; ++t) { kr[t] = kr_n[t]; qr[t] = qr_n[t]; vr[t] = vr_n[t]; }
-    } else {
-      request(w, mt, kr, qr, vr);
-    }
+    request(w, mt, kr, qr, vr);
     int4* s_qry = s_qry0 + (it & 1) * LP;
     int2* s_key = s_key0 + (it & 1) * LP;
     int* s_kbid = s_kbid0 + (it & 1) * LP;
@@ -991,13 +986,6 @@ window_attn_kernel_v5(const WinParams p) {
         }
     }
 
-    if (PF) {
-      // the previous window's output rows leave NOW, a whole softmax phase before the next `s_waitcnt vmcnt(0)`: gfx950 has
-      // one counter for loads and stores, and a store issued at the end of a window would make the top of the next one wait
-      // for its acknowledgement (measured: ~3.6 k cycles per window)
-      flush();
-      if (w + (int)gridDim.x < p.n_windows) request(w + (int)gridDim.x, mt_n, kr_n, qr_n, vr_n);
-    }
     HFL_ATT_STAMP(2)
 
     auto body = [&](auto masked_tag) {
@@ -1127,10 +1115,7 @@ window_attn_kernel_v5(const WinParams p) {
         o *= inv;
         // the accumulator holds channels 4g .. 4g+3 of query c (relay tile: only the column c == 0 is a row)
         const int orow = is_rt ? (c == 0 ? rt_row : -1) : qm.w;
-        if (PF) {
-          o_hold[qt] = o;
-          orow_hold[qt] = orow;
-        } else if (p.out_split == 2) {
+        if (p.out_split == 2) {
           // split2 rows for the proj GEMM: the tile's 16 x [16 hi | 16 lo] bf16 goes through the LDS block (its V image is in
           // registers by now) and leaves as ONE 16-B store per lane, a quad of lanes per row (two 32-B segments of one line)
           uint2 hi, lo;
@@ -1158,7 +1143,6 @@ window_attn_kernel_v5(const WinParams p) {
     else
       body(std::true_type{});
   }
-  if (PF) flush();
   if (HFL_ATT_TRACE && (p.dbg & 8) && tid == 0 && wg_lin < 4096) g_att_wg[2 * wg_lin + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -1228,9 +1212,111 @@ static inline size_t rpe_form_floats(int depth, int bnd, int f16) {      // per 
 static int g_window_variant = 4;
 static int g_window_v4_wgs_per_cu = 1;   // multiples of the resident workgroup count
 static int g_window_dbg = 0;
-static int g_window_pf = 0;            // 1: window_attn_kernel_v5 prefetches the next window into registers
 static int g_window_v2_wgs_per_cu = 16;
 static int g_window_heads_per_wg = 4;
+
+// fp16 (hi, lo) operand layout: only the v5 kernel reads it (callers ask hfl_window_attention_f16_ok first).  `n` problems of
+// one shape in ONE launch (see WinMultiParams); HFL_EINVAL when they cannot share a launch (the caller then launches them
+// one by one).  Heads per workgroup: 4, or 2 when the expanded RPE tables of 4 heads do not leave room in LDS.
+// per-launch HIP events around the v5 launches (bench.py's roofline leg times the launches the product path really issues --
+// including those inside hfl_block_forward_x3 / hfl_block_attention_x3_multi, which no Python-side timer sees)
+struct AttnTimingRec {
+  hipEvent_t e0, e1;
+  double bytes, flops;
+};
+static int g_attn_timing = 0;
+static std::vector<AttnTimingRec> g_attn_recs;
+
+template <int T, int G>
+static int launch_window_v5(const WinParams* ps, int n, hipStream_t s) {
+  constexpr int LP = T * 16;
+  constexpr int np5 = (T + 1) / 2;
+  if (n < 1 || n > kWinMulti) return HFL_EINVAL;
+  int form0 = 0, hp0 = 0;
+  size_t lds_max = 0;
+  int64_t windows = 0;
+  for (int i = 0; i < n; ++i) {
+    const WinParams& p = ps[i];
+    int hpw = g_window_heads_per_wg;             // heads (= waves) per workgroup, at most 4
+    if (hpw < 1 || hpw > 4 || p.H % hpw != 0) hpw = (p.H % 4 == 0) ? 4 : (p.H % 2 == 0) ? 2 : 1;
+    const int64_t rows_total = G > 0 ? p.rt_row0 + p.n_windows : p.n_tokens;
+    const int form = p.table ? rpe_form(p.depth, p.bnd, 1) : 0;
+    const size_t ts5 = p.table ? rpe_form_floats(p.depth, p.bnd, 1) : 0;
+    int hp5 = hpw;
+    size_t lds5 = 0;
+    for (;; hp5 >>= 1) {
+      lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hp5 * ts5 * 4 + (size_t)hp5 * (2 * np5 * 16) * 64;
+      if (lds5 <= 72 * 1024 || hp5 <= 2 || p.H % (hp5 / 2) != 0) break;
+    }
+    const int W5 = 2 * ((1 << (p.depth > 0 && p.depth <= 7 ? p.depth : 0)) - 1) + 1;
+    if (!p.qkv_f16 || p.depth < 1 || p.depth > 7 || (p.table != nullptr && (p.rpe2 == nullptr || form == 0)) ||
+        (p.table == nullptr && p.depth > 10) || (form == 2 && (size_t)hp5 * ts5 * 4 + 12 * (size_t)W5 >= 65536) ||
+        rows_total * 3 * p.H * 16 * 4 >= (int64_t)1 << 32 || lds5 > 72 * 1024 || hp5 * 64 < LP || p.qkv_bias != nullptr ||
+        p.n_windows < 1)
+      return HFL_EINVAL;
+    if (i == 0) {
+      form0 = form;
+      hp0 = hp5;
+    } else if (form != form0 || hp5 != hp0 || p.H != ps[0].H || p.K != ps[0].K) {
+      return HFL_EINVAL;
+    }
+    if (lds5 > lds_max) lds_max = lds5;
+    windows += p.n_windows;
+  }
+  const int groups5 = ps[0].H / hp0;
+  // persistent grid: exactly the workgroups that are resident at once (waves-per-SIMD target of the kernel, LDS), times
+  // g_window_v4_wgs_per_cu, dealt to the problems in proportion to their windows (at least one each)
+  int resident = v4_waves_per_simd(T, G) * 4 / hp0;
+  const int lds_fit = (int)((size_t)160 * 1024 / (lds_max + 512));
+  if (resident > lds_fit) resident = lds_fit;
+  if (resident < 1) resident = 1;
+  int64_t px = (int64_t)hfl_num_cus() * resident * g_window_v4_wgs_per_cu / groups5;
+  if (px < n) px = n;
+  WinMultiParams m;
+  m.n = n;
+  m.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    int64_t share = windows <= px ? ps[i].n_windows : (ps[i].n_windows * px + windows - 1) / windows;
+    if (share < 1) share = 1;
+    if (share > ps[i].n_windows) share = ps[i].n_windows;
+    m.p[i] = ps[i];
+    m.first[i + 1] = m.first[i] + (int)share;
+  }
+  for (int i = n; i < kWinMulti; ++i) {
+    m.p[i] = ps[0];
+    m.first[i + 1] = m.first[n];
+  }
+  dim3 grid5((unsigned)m.first[n], (unsigned)groups5);
+  hipError_t e;
+#define HFL_V5_LAUNCH(F)                                                                                  \
+  {                                                                                                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, F>),                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);                    \
+    if (e != hipSuccess) return (int)e;                                                                   \
+    window_attn_kernel_v5<T, G, F><<<grid5, hp0 * 64, lds_max, s>>>(m);                                   \
+  }
+  AttnTimingRec rec{};
+  if (g_attn_timing) {
+    // algorithmic bytes: q, k, v read + out written = 16 B per (row, channel); 4 L^2 C FLOP per window
+    for (int i = 0; i < n; ++i) {
+      const double rows = (double)(G > 0 ? ps[i].rt_row0 + ps[i].n_windows : ps[i].n_tokens);
+      const double real_windows = (double)((ps[i].n_tokens + ps[i].K - 1) / ps[i].K);
+      rec.bytes += rows * ps[i].H * 16 * 16.0;
+      rec.flops += 4.0 * (ps[i].K + G) * (ps[i].K + G) * ps[i].H * 16 * real_windows;
+    }
+    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return HFL_EINVAL;
+    e = hipEventRecord(rec.e0, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (form0 == 0) HFL_V5_LAUNCH(0) else if (form0 == 1) HFL_V5_LAUNCH(1) else HFL_V5_LAUNCH(2)
+#undef HFL_V5_LAUNCH
+  if (g_attn_timing) {
+    e = hipEventRecord(rec.e1, s);
+    if (e != hipSuccess) return (int)e;
+    g_attn_recs.push_back(rec);
+  }
+  HFL_RETURN_LAST_ERROR();
+}
 
 template <int T, int G>
 static int launch_window(const WinParams& p, hipStream_t s) {
@@ -1253,49 +1339,7 @@ static int launch_window(const WinParams& p, hipStream_t s) {
     const size_t ts4 = p.table ? (size_t)((W4 + W4 * W4 + 3) & ~3) : 0;
     const size_t lds4 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hpw * ts4 * 4;
     if (p.qkv_f16) {
-      // fp16 (hi, lo) operand layout: only the v5 kernel reads it (callers ask hfl_window_attention_f16_ok first).
-      // Heads per workgroup: 4, or 2 when the expanded RPE tables of 4 heads do not leave room in LDS (depth 5)
-      const int np5 = (T + 1) / 2;
-      const int form = p.table ? rpe_form(p.depth, p.bnd, 1) : 0;
-      const size_t ts5 = p.table ? rpe_form_floats(p.depth, p.bnd, 1) : 0;
-      int hp5 = hpw;
-      size_t lds5 = 0;
-      for (;; hp5 >>= 1) {
-        lds5 = (size_t)2 * LP * (16 + 8 + 4) + (size_t)hp5 * ts5 * 4 + (size_t)hp5 * (2 * np5 * 16) * 64;
-        if (lds5 <= 72 * 1024 || hp5 <= 2 || p.H % (hp5 / 2) != 0) break;
-      }
-      const int W5 = 2 * ((1 << (p.depth > 0 && p.depth <= 7 ? p.depth : 0)) - 1) + 1;
-      if (p.depth < 1 || p.depth > 7 || (p.table != nullptr && (p.rpe2 == nullptr || form == 0)) ||
-          (p.table == nullptr && p.depth > 10) || (form == 2 && (size_t)hp5 * ts5 * 4 + 12 * (size_t)W5 >= 65536) ||
-          rows_total * 3 * p.H * 16 * 4 >= (int64_t)1 << 32 || lds5 > 72 * 1024 || hp5 * 64 < LP || p.qkv_bias != nullptr)
-        return HFL_EINVAL;
-      const int groups5 = p.H / hp5;
-      constexpr bool pf_fits = T <= 3 || (T == 4 && G == 1);      // <= 256 VGPRs with the second fragment set
-      const int pf = (g_window_pf && pf_fits) ? 1 : 0;
-      int resident = v5_waves_per_simd(T, G, pf) * 4 / hp5;
-      const int lds_fit = (int)((size_t)160 * 1024 / (lds5 + 512));
-      if (resident > lds_fit) resident = lds_fit;
-      if (resident < 1) resident = 1;
-      int px = hfl_num_cus() * resident * g_window_v4_wgs_per_cu / groups5;
-      if (px < 1) px = 1;
-      if (px > p.n_windows) px = p.n_windows;
-      dim3 grid5((unsigned)px, (unsigned)groups5);
-      hipError_t e;
-#define HFL_V5_LAUNCH(F, P)                                                                               \
-  {                                                                                                       \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, F, P>),             \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);                       \
-    if (e != hipSuccess) return (int)e;                                                                   \
-    window_attn_kernel_v5<T, G, F, P><<<grid5, hp5 * 64, lds5, s>>>(p);                                   \
-  }
-      if (pf) {
-        if constexpr (pf_fits) {
-          if (form == 0) HFL_V5_LAUNCH(0, 1) else if (form == 1) HFL_V5_LAUNCH(1, 1) else HFL_V5_LAUNCH(2, 1)
-        }
-      } else {
-        if (form == 0) HFL_V5_LAUNCH(0, 0) else if (form == 1) HFL_V5_LAUNCH(1, 0) else HFL_V5_LAUNCH(2, 0)
-      }
-#undef HFL_V5_LAUNCH
+      return launch_window_v5<T, G>(&p, 1, s);
     } else if (g_window_variant == 4 && !p.clamp && p.depth >= 1 && p.depth <= 5 &&
         (p.table == nullptr || p.rpe2 != nullptr) && rows_total * 3 * p.H * 16 * 4 < (int64_t)1 << 32 &&
         lds4 <= 72 * 1024 && hpw * 64 >= LP) {
@@ -1415,6 +1459,31 @@ extern "C" void hfl_internal_set_cpe_chunk(int rows);
 void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
+// bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
+int hfl_internal_attn_timing(int on) {
+  for (auto& r : g_attn_recs) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_attn_recs.clear();
+  g_attn_timing = on ? 1 : 0;
+  return HFL_OK;
+}
+// ... and read it: per recorded launch the duration (ms), algorithmic bytes and FLOP; returns the number of launches recorded
+int hfl_internal_attn_timing_read(double* ms, double* bytes, double* flops, int cap) {
+  int n = 0;
+  for (auto& r : g_attn_recs) {
+    if (n >= cap) break;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;
+    ms[n] = t;
+    bytes[n] = r.bytes;
+    flops[n] = r.flops;
+    ++n;
+  }
+  return (int)g_attn_recs.size();
+}
 int hfl_internal_read_att_trace(unsigned long long* host, int n) {
   if (n > 16 * 8) n = 16 * 8;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_att_trace), (size_t)n * 8);
@@ -1430,7 +1499,7 @@ int hfl_set_variant(const char* key, int value) {
     g_window_variant = 4;
     g_window_v4_wgs_per_cu = 1;
     g_window_dbg = 0;
-    g_window_pf = 0;
+    hfl_internal_attn_timing(0);
     g_rpe_form1_max_depth = 4;
     g_window_v2_wgs_per_cu = 16;
     g_window_heads_per_wg = 4;
@@ -1453,8 +1522,6 @@ int hfl_set_variant(const char* key, int value) {
     g_window_dbg = value;
   } else if (is("window_rpe_form1_max_depth")) {
     g_rpe_form1_max_depth = value;
-  } else if (is("window_pf")) {
-    g_window_pf = value;
   } else if (is("window_v4_wgs_per_cu")) {
     g_window_v4_wgs_per_cu = value;
   } else if (is("window_v2_wgs_per_cu")) {
@@ -1497,16 +1564,21 @@ int hfl_window_attention_fwd(float* out, const float* qkv, const uint32_t* tok_m
   return hfl_window_attention_fwd_ex(out, qkv, nullptr, tok_meta, rpe_table, d, 0, stream);
 }
 
-int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
-                                const uint32_t* tok_meta, const float* rpe_table,
-                                const hfl_window_attn_desc* d, int out_split3, hfl_stream_t stream) {
+}  // extern "C"
+
+// argument checks + kernel parameters of one attention problem; HFL_OK with *empty = true when there is nothing to do
+static int win_params(WinParams& p, bool* empty, void* out, const float* qkv, const float* qkv_bias, const uint32_t* tok_meta,
+                      const float* rpe_table, const hfl_window_attn_desc* d, int out_split3) {
+  *empty = false;
   if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
   if ((qkv_bias != nullptr || out_split3) && g_window_variant < 2) return HFL_EINVAL;
   if ((out_split3 & 3) == 3 || (out_split3 & ~0x103)) return HFL_EINVAL;
   if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
   if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
-  if (d->n_windows == 0) return HFL_OK;
-  WinParams p;
+  if (d->n_windows == 0) {
+    *empty = true;
+    return HFL_OK;
+  }
   p.out = static_cast<float*>(out); p.qkv = qkv; p.meta = tok_meta; p.table = rpe_table;
   p.qkv_bias = qkv_bias; p.out_split = out_split3 & 3;
   p.qkv_f16 = (out_split3 >> 8) & 1;
@@ -1518,6 +1590,67 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
   p.batch = d->batch_size; p.scale = d->scale;
   // coordinates at octree depth `depth` are < 2^depth; 0 (unknown) keeps the clamp
   p.clamp = (d->depth <= 0 || d->depth > 10 || ((1 << d->depth) - 1) > d->pos_bnd) ? 1 : 0;
+  return HFL_OK;
+}
+
+extern "C" {
+
+// n attention problems (fp16 (hi, lo) qkv operands) in ONE launch when they have one shape, else one launch each
+int hfl_window_attention_fwd_multi(int n, void* const* out, const float* const* qkv, const uint32_t* const* tok_meta,
+                                   const float* const* rpe_table, const hfl_window_attn_desc* const* desc, int out_split3,
+                                   hfl_stream_t stream) {
+  if (n < 1 || n > kWinMulti || out == nullptr || qkv == nullptr || tok_meta == nullptr || rpe_table == nullptr ||
+      desc == nullptr || !(out_split3 & 0x100))
+    return HFL_EINVAL;
+  WinParams ps[kWinMulti];
+  int live = 0;
+  bool same = true;
+  for (int i = 0; i < n; ++i) {
+    bool empty = false;
+    const int rc = win_params(ps[live], &empty, out[i], qkv[i], nullptr, tok_meta[i], rpe_table[i], desc[i], out_split3);
+    if (rc != HFL_OK) return rc;
+    if (empty) continue;
+    if (desc[i]->n_relay != desc[0]->n_relay || desc[i]->patch_size != desc[0]->patch_size) same = false;
+    ++live;
+  }
+  if (live == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = HFL_EINVAL;
+  if (same && live > 1) {
+    const int T = ps[0].K / 16 + desc[0]->n_relay;
+    if (desc[0]->n_relay == 0) {
+      switch (T) {
+        case 1: rc = launch_window_v5<1, 0>(ps, live, s); break;
+        case 2: rc = launch_window_v5<2, 0>(ps, live, s); break;
+        case 3: rc = launch_window_v5<3, 0>(ps, live, s); break;
+        case 4: rc = launch_window_v5<4, 0>(ps, live, s); break;
+        default: break;
+      }
+    } else {
+      switch (T) {
+        case 2: rc = launch_window_v5<2, 1>(ps, live, s); break;
+        case 3: rc = launch_window_v5<3, 1>(ps, live, s); break;
+        case 4: rc = launch_window_v5<4, 1>(ps, live, s); break;
+        case 5: rc = launch_window_v5<5, 1>(ps, live, s); break;
+        default: break;
+      }
+    }
+    if (rc != HFL_EINVAL) return rc;
+  }
+  for (int i = 0; i < n; ++i) {          // not one shape (or a single problem): one launch each
+    rc = hfl_window_attention_fwd_ex(out[i], qkv[i], nullptr, tok_meta[i], rpe_table[i], desc[i], out_split3, stream);
+    if (rc != HFL_OK) return rc;
+  }
+  return HFL_OK;
+}
+
+int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
+                                const uint32_t* tok_meta, const float* rpe_table,
+                                const hfl_window_attn_desc* d, int out_split3, hfl_stream_t stream) {
+  WinParams p;
+  bool empty = false;
+  const int rc0 = win_params(p, &empty, out, qkv, qkv_bias, tok_meta, rpe_table, d, out_split3);
+  if (rc0 != HFL_OK || empty) return rc0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int T = d->patch_size / 16 + d->n_relay;
   if (d->n_relay == 0) {

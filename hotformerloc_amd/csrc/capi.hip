@@ -29,9 +29,9 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
   int rc;
   const int phase = io->phase;
-  if (phase < 0 || phase > 2) return HFL_EINVAL;
+  if (phase < 0 || phase > 4) return HFL_EINVAL;
   // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention)
-  if (phase != 2 && nt > 0) {
+  if (phase <= 1 && nt > 0) {
     rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
     if (rc != HFL_OK) return rc;
     if (phase == 1) {           // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
@@ -42,16 +42,17 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
     }
   }
   if (phase == 1) return HFL_OK;
-  // ---- phase 2 (or the whole block)
-  if (rows > nt) {
+  // ---- phase 2 (or the whole block) = phase 3 (the relay rows up to their qkv) + the window attention + phase 4 (the rest);
+  // 3 and 4 exist so that the attention of several blocks can go out as one launch in between (hfl_block_attention_x3_multi)
+  if (phase != 4 && rows > nt) {
     const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
     hipError_t e = hipMemcpyAsync(x0 + nt * C, src, (size_t)(rows - nt) * C * 4, hipMemcpyDeviceToDevice,
                                   static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return (int)e;
   }
-  {
-    // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phase 2)
-    const int64_t r0 = phase == 2 ? nt : 0, nr = rows - r0;
+  if (phase != 4) {
+    // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phases 2, 3)
+    const int64_t r0 = phase != 0 ? nt : 0, nr = rows - r0;
     if (nr > 0) {
       rc = hfl_layer_norm_split2(a2 + r0 * 2 * C, x0 + r0 * C, w->norm1_gamma, w->norm1_beta, nr, C, w->eps, stream);
       if (rc != HFL_OK) return rc;
@@ -60,8 +61,11 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
       if (rc != HFL_OK) return rc;
     }
   }
-  rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
-  if (rc != HFL_OK) return rc;
+  if (phase == 3) return HFL_OK;
+  if (phase != 4) {
+    rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
+    if (rc != HFL_OK) return rc;
+  }
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
@@ -75,6 +79,29 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
 }
 
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) { return n_rows * channels * 4 * 12; }
+
+// The window attention of n blocks (between their phases 3 and 4) as ONE launch when the blocks have one attention shape
+// (the pyramid levels of an H-OSA iteration), else one launch each: operands are found in the blocks' arenas.
+int hfl_block_attention_x3_multi(int n, const hfl_block_weights* const* w, const hfl_block_io* const* io,
+                                 const hfl_window_attn_desc* const* desc, hfl_stream_t stream) {
+  if (n < 1 || n > 4 || w == nullptr || io == nullptr || desc == nullptr) return HFL_EINVAL;
+  void* out[4];
+  const float* qkv[4];
+  const uint32_t* meta[4];
+  const float* table[4];
+  for (int i = 0; i < n; ++i) {
+    if (w[i] == nullptr || io[i] == nullptr || desc[i] == nullptr) return HFL_EINVAL;
+    const int64_t C = w[i]->channels, rows = io[i]->n_rows;
+    if (C <= 0 || C % 128 != 0 || rows < io[i]->n_tokens) return HFL_EINVAL;
+    unsigned char* a = static_cast<unsigned char*>(io[i]->arena);
+    const size_t unit = (size_t)rows * C * 4;
+    qkv[i] = reinterpret_cast<const float*>(a + 2 * unit);
+    out[i] = a + 5 * unit;
+    meta[i] = io[i]->tok_meta;
+    table[i] = w[i]->rpe_table;
+  }
+  return hfl_window_attention_fwd_multi(n, out, qkv, meta, table, desc, 2 | 0x100, stream);
+}
 
 // The relay-token transformer block as one call (see include/hotformerloc_hip.h): the same launches, in the same order, as
 // model.RelayTokenTransformerBlock issues through the Python wrappers.

@@ -97,6 +97,7 @@ _GROUPED_TAPS = os.environ.get('HFL_GROUPED_TAPS', '1') != '0'     # live-tap co
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
+_MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
 
 
 def set_train_split(enabled: bool):
@@ -117,9 +118,15 @@ def set_attention_f16(enabled: bool):
     _ATTN_F16 = bool(enabled)
 
 
-def set_pyramid_streams(enabled: bool):
-    """Run the pyramid depths of one H-OSA iteration on separate HIP streams (inference path)."""
-    global _PYRAMID_STREAMS
+_SERIAL_STREAMS = False
+
+
+def set_pyramid_streams(enabled):
+    """Run the pyramid depths of one H-OSA iteration on separate HIP streams (inference path).  'serial': the launches of
+    that schedule, in its order, all on the current stream (bench.py's roofline leg: a kernel's events then bracket the
+    kernel alone)."""
+    global _PYRAMID_STREAMS, _SERIAL_STREAMS
+    _SERIAL_STREAMS = enabled == 'serial'
     _PYRAMID_STREAMS = bool(enabled)
 
 _W3_CACHE = {}          # id(weight) -> (weakref to weight, version, W3)
@@ -1057,10 +1064,10 @@ class HOTFormerStage(nn.Module):
                 # part on its own stream first, RTSA runs beside it on a stream of its own, the rest of the block follows
                 # once both are done -- the ~120 us chain of eight tiny RTSA launches leaves the critical path.
                 main = torch.cuda.current_stream()
-                side = self._side_streams(data.device)
-                rs = self._rtsa_stream(data.device)
-                sts = [main if (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) else side[j - 1]
-                       for j, d in enumerate(depths)]
+                side = [main] * (len(depths) - 1) if _SERIAL_STREAMS else self._side_streams(data.device)
+                rs = main if _SERIAL_STREAMS else self._rtsa_stream(data.device)
+                small = [not (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) for j, d in enumerate(depths)]
+                sts = [side[j - 1] if small[j] else main for j in range(len(depths))]
                 # issue order = critical path first (the host runs only just ahead of the GPU here): the finest level's
                 # token phase, RTSA, then the small levels
                 order = sorted(range(len(depths)), key=lambda j: -bufs[depths[j]].shape[0])
@@ -1085,15 +1092,44 @@ class HOTFormerStage(nn.Module):
                     phase1(j)
                 fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
                 old = (dict(bufs), dict(rts))        # buffers other streams still read stay alive until the join
+                # The levels on SIDE streams (the small ones: 2 k and 14 k rows in the bench) send their window attention out as
+                # ONE launch: their windows are one or two per workgroup, latency-bound launches of 14 and 21 us alone.  The
+                # join is between those side streams only.  (Measured alternatives: all three levels in one launch joined
+                # on the main stream -3.5 % of the step; the small levels back to back on one side stream -3 %.)
+                group = [j for j in order if small[j] and calls[depths[j]] is not None] if _MERGED_ATTN else []
+                if len(group) < 2:
+                    group = []
+                outs = {}
+
+                def relay_in(j):
+                    return self.down_projections[j][i](fresh[depths[j]]) if proj else fresh[depths[j]]
+
                 for j in order:
                     d = depths[j]
                     sts[j].wait_event(ev_rt)
                     with torch.cuda.stream(sts[j]):
-                        blk = self.hosa_blocks[j][i]
-                        rin = self.down_projections[j][i](fresh[d]) if proj else fresh[d]
-                        out = blk._tail(calls[d].run(2, rin), plan, d) if calls[d] is not None else blk(bufs[d], plan, d, rin)
-                        bufs[d] = out
-                        rts[d] = self.up_projections[j][i](out[nts[j]:]) if proj else out[nts[j]:]
+                        if j in group:
+                            calls[d].run(3, relay_in(j))                      # relay rows in, their LN1 / qkv
+                        elif calls[d] is not None:
+                            outs[j] = self.hosa_blocks[j][i]._tail(calls[d].run(2, relay_in(j)), plan, d)
+                        else:
+                            outs[j] = self.hosa_blocks[j][i](bufs[d], plan, d, relay_in(j))
+                if group:
+                    lead = sts[group[0]]
+                    for j in group[1:]:
+                        lead.wait_event(sts[j].record_event())
+                    with torch.cuda.stream(lead):
+                        ops.block_attention_multi([calls[depths[j]] for j in group])
+                        ev_att = lead.record_event()
+                    for j in group:
+                        if sts[j] is not lead:
+                            sts[j].wait_event(ev_att)
+                        with torch.cuda.stream(sts[j]):
+                            outs[j] = self.hosa_blocks[j][i]._tail(calls[depths[j]].run(4), plan, depths[j])      # proj + MLP
+                for j in order:
+                    with torch.cuda.stream(sts[j]):
+                        bufs[depths[j]] = outs[j]
+                        rts[depths[j]] = self.up_projections[j][i](outs[j][nts[j]:]) if proj else outs[j][nts[j]:]
                 for j in range(len(depths)):
                     if sts[j] is not main:
                         main.wait_stream(sts[j])

@@ -513,7 +513,9 @@ def block_forward_x3(weights, keep_alive, x_in, relay, neigh, tok_meta, n_tokens
 class BlockCall:
     """The same block in two phases (hfl_block_io.phase): `run(1)` issues what reads token rows only (CPE, their LN1 and
     qkv projection) -- the caller may do that while the relay-token self-attention of the iteration is still running on
-    another stream -- `run(2, relay)` the rest, on whatever stream is current at that call; `run(0, relay)` = both."""
+    another stream -- `run(2, relay)` the rest, on whatever stream is current at that call; `run(0, relay)` = both.
+    `run(3, relay)` / `block_attention_multi([...])` / `run(4)` split phase 2 around the window attention, so that the
+    attention of several blocks goes out as one launch."""
 
     def __init__(self, weights, keep_alive, x_in, neigh, tok_meta, n_tokens: int, desc: WindowAttnDesc):
         _dev(x_in, neigh, tok_meta)
@@ -535,6 +537,18 @@ class BlockCall:
         check(self.lib.hfl_block_forward_x3(ctypes.byref(self.weights), ctypes.byref(self.io), ctypes.byref(self.desc),
                                             _stream()), 'hfl_block_forward_x3')
         return self.out
+
+
+def block_attention_multi(calls):
+    """The window attention of several blocks that have run phases 1 and 3 (`BlockCall.run(1)`, `.run(3, relay)`), as one
+    launch when their attention shapes agree (hfl_block_attention_x3_multi); `.run(4)` of each block follows."""
+    n = len(calls)
+    assert 1 <= n <= 4
+    lib = _native.load()
+    ws = _native.ptr_array([ctypes.addressof(c.weights) for c in calls])
+    ios = _native.ptr_array([ctypes.addressof(c.io) for c in calls])
+    ds = _native.ptr_array([ctypes.addressof(c.desc) for c in calls])
+    check(lib.hfl_block_attention_x3_multi(n, ws, ios, ds, _stream()), 'hfl_block_attention_x3_multi')
 
 
 def relay_block_forward_x3(weights, keep_alive, rt, seq_rows, seq_off, batch: int, max_seq_len: int):

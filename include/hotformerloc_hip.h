@@ -218,6 +218,12 @@ int hfl_window_attention_f16_ok(const hfl_window_attn_desc* desc, int64_t n_rows
 int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bias,
                                 const uint32_t* tok_meta, const float* rpe_table,
                                 const hfl_window_attn_desc* desc, int out_split3, hfl_stream_t stream);
+/* n (<= 4) independent attention problems on fp16 (hi, lo) qkv operands (out_split3 carries 0x100) as ONE launch when they
+ * have one shape (patch_size, n_relay, n_heads, table form), else one launch each: arrays of the arguments of
+ * hfl_window_attention_fwd_ex (no qkv_bias).  Small problems ride along with a large one instead of paying a launch each. */
+int hfl_window_attention_fwd_multi(int n, void* const* out, const float* const* qkv, const uint32_t* const* tok_meta,
+                                   const float* const* rpe_table, const hfl_window_attn_desc* const* desc, int out_split3,
+                                   hfl_stream_t stream);
 
 /* Expanded relative-position table for the forward kernels, scaled by log2(e); which form is built depends on the consumer:
  *   f16_operand = 0 (fp32 qkv kernel): per head the x-axis table restricted to |dx| <= R = 2^depth - 1 followed by the
@@ -466,11 +472,19 @@ typedef struct hfl_block_io {
                                                           CPE, LN1 and the qkv projection of the TOKEN rows (may run while the
                                                           relay-token self-attention of the iteration is still in flight);
                                                           2: the rest -- relay rows in, their LN1 / qkv, window attention, proj,
-                                                          MLP.  Phases 1 and 2 of a block share `arena`. */
+                                                          MLP.  3 + 4 split phase 2 around the attention: 3 = relay rows in and
+                                                          their LN1 / qkv, 4 = proj and MLP; between them the caller runs the
+                                                          attention of this and other blocks with hfl_block_attention_x3_multi.
+                                                          All phases of a block share `arena`. */
 } hfl_block_io;
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels);
 int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, const hfl_window_attn_desc* desc,
                          hfl_stream_t stream);
+/* The window attention of n (<= 4) blocks that have finished phases 1 and 3, in ONE launch when they share an attention shape
+ * (patch size, relay tokens, heads, table form: the pyramid levels of an H-OSA iteration,
+ * models/hotformerloc_backbone.py:466-473), else one launch each; then run each block's phase 4. */
+int hfl_block_attention_x3_multi(int n, const hfl_block_weights* const* w, const hfl_block_io* const* io,
+                                 const hfl_window_attn_desc* const* desc, hfl_stream_t stream);
 
 /* The relay-token transformer block (RTSA, models/hotformerloc_backbone.py:239-302) of the inference path as ONE call: LN1 ->
  * split2, qkv GEMM, ragged relay attention (hfl_relay_attention_fwd), split2, proj GEMM + residual, LN2 -> split2, fc1 GEMM +

@@ -389,3 +389,31 @@ def test_early_phase_schedule_equals_the_sequential_one():
                 assert torch.equal(out[early], y)                   # and run to run
             out[early] = y
         assert torch.equal(out[True], out[False]), prop
+
+
+@pytest.mark.gpu
+def test_merged_window_attention_launch_equals_one_launch_per_level():
+    """The window attention of an H-OSA iteration's three pyramid levels as ONE launch (hfl_block_attention_x3_multi between
+    block phases 3 and 4) against one launch per level: the same windows through the same kernel, bitwise equal descriptors;
+    also on a batch small enough that the coarsest level has fewer windows than its share of the grid."""
+    from hotformerloc_amd import model as M
+    params, depth = load_config('wild-places')
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'stress')
+    model = model.cuda().eval()
+    for n_clouds, pts in ((4, 2500), (1, 700), (9, 4096)):
+        octree = build_batch_octree(syn.make_clouds(17, n_clouds, pts, params.coordinates), depth, 2, 'cuda')
+        out = {}
+        for merged in (True, False, True):
+            M._MERGED_ATTN = merged
+            try:
+                with torch.no_grad():
+                    y = model({'octree': octree})['global']
+                torch.cuda.synchronize()
+            finally:
+                M._MERGED_ATTN = True
+            if merged in out:
+                assert torch.equal(out[merged], y)
+            out[merged] = y
+        assert torch.isfinite(out[True]).all()
+        assert torch.equal(out[True], out[False]), (n_clouds, pts)
