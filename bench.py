@@ -73,6 +73,9 @@ def parse():
     ap.add_argument('--resident-plan', action='store_true',
                     help='headline step keeps the window plan / tap tables cached on the octree (round-2 behaviour)')
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
+    ap.add_argument('--serial-streams', action='store_true',
+                    help="the step's own launch schedule on ONE stream (what the roofline leg times: a kernel trace of this "
+                         'run shows every kernel alone; profiles/*_serial_*)')
     ap.add_argument('--attn-variant', type=int, default=0, help='A/B: window attention kernel variant (0 = default)')
     ap.add_argument('--train', action='store_true', help='time forward+backward (BASELINE config 3) instead of forward')
     ap.add_argument('--multistaged', action='store_true',
@@ -186,7 +189,7 @@ def main():
     from hotformerloc_amd import synthetic as syn
     from hotformerloc_amd.model import set_gemm_mode, set_pyramid_streams
     set_gemm_mode(args.gemm)
-    set_pyramid_streams(not args.no_streams)
+    set_pyramid_streams('serial' if args.serial_streams else not args.no_streams)
     if args.no_train_x3:
         from hotformerloc_amd.model import set_train_x3
         set_train_x3(False)

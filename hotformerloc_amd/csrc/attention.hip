@@ -2012,12 +2012,10 @@ __device__ __forceinline__ uint32_t bwd_bf16_rne(float v) {
   return u >> 16;
 }
 // four floats -> packed bf16 hi (2 dwords) and lo (2 dwords)
+// (v_cvt_pk_bf16_f32: round to nearest even as bwd_bf16_rne, 6 instructions per pair instead of ~14)
 __device__ __forceinline__ void bwd_split4(const float a, const float b, const float c, const float d, uint2& hi, uint2& lo) {
-  const uint32_t h0 = bwd_bf16_rne(a), h1 = bwd_bf16_rne(b), h2 = bwd_bf16_rne(c), h3 = bwd_bf16_rne(d);
-  const uint32_t l0 = bwd_bf16_rne(a - __uint_as_float(h0 << 16)), l1 = bwd_bf16_rne(b - __uint_as_float(h1 << 16));
-  const uint32_t l2 = bwd_bf16_rne(c - __uint_as_float(h2 << 16)), l3 = bwd_bf16_rne(d - __uint_as_float(h3 << 16));
-  hi = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-  lo = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  x3_split_pair_scalar(a, b, hi.x, lo.x);
+  x3_split_pair_scalar(c, d, hi.y, lo.y);
 }
 __device__ __forceinline__ bwd_b8 bwd_cat(const uint2 a, const uint2 b) {
   const uint4 q = make_uint4(a.x, a.y, b.x, b.y);
@@ -2106,32 +2104,34 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
   };
 
   for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
-    __syncthreads();
-    for (int j = tid; j < LP; j += blockDim.x) {
-      int bid = -1, row = -1, x = 0, y = 0, z = 0;
+    // Rows are index arithmetic (token of window slot j = tok0 + j * D, relay row = rt_row0 + w), so NOTHING below waits for
+    // the metadata round trip: the metadata words, the Q / K / dO rows and the V fragments are requested together.
+    auto row_of = [&](int j) -> int {
       if (j < K) {
-        const int64_t t = (p.D == 1) ? (int64_t)w * K + j
-                                     : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
-        if (t < p.n_tokens) {
-          const uint32_t xyz = p.meta[2 * t];
-          x = (int)(xyz & 1023u); y = (int)((xyz >> 10) & 1023u); z = (int)(xyz >> 20);
-          bid = (int)p.meta[2 * t + 1];
-          row = (int)t;
-        }
-      } else if (G > 0 && j == K) {
-        const int64_t t0 = (int64_t)w * K;
-        bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
-        row = (int)(p.rt_row0 + w);
+        const int64_t t = (p.D == 1) ? (int64_t)w * K + j : ((int64_t)(w / p.D) * K + j) * p.D + (w % p.D);
+        return t < p.n_tokens ? (int)t : -1;
       }
-      s_key[j] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), bid);
-      s_qry[j] = make_int4(4 * x, 4 * y, 4 * z, row >= 0 ? bid : -2);
-      s_row[j] = row;
+      return (G > 0 && j == K) ? (int)(p.rt_row0 + w) : -1;
+    };
+    static_assert(LP <= 128, "one metadata slot per thread");
+    uint32_t m_xyz = 0u;
+    int m_bid = -1, m_row = -1;
+    if (tid < LP) {
+      m_row = row_of(tid);
+      if (tid < K) {
+        if (m_row >= 0) {
+          m_xyz = p.meta[2 * (int64_t)m_row];
+          m_bid = (int)p.meta[2 * (int64_t)m_row + 1];
+        }
+      } else if (G > 0 && tid == K) {
+        const int64_t t0 = (int64_t)w * K;
+        m_bid = t0 < p.n_tokens ? (int)p.meta[2 * t0 + 1] : p.batch;
+      }
     }
-    __syncthreads();
-    // ---- stage Q, K, dO of this head as bf16 (hi, lo) rows -----------------------------------------------------------
+    // ---- stage Q, K, dO of this head as bf16 (hi, lo) rows (this wave's own images: no barrier involved) -------------
     for (int i = lane; i < LP * 4; i += 64) {
       const int j = i >> 2, f = i & 3;
-      const int row = s_row[j];
+      const int row = row_of(j);
       float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), k4 = q4, d4 = q4;
       if (row >= 0) {
         const float* base = p.qkv + (int64_t)row * 3 * C + h * 16 + 4 * f;
@@ -2154,7 +2154,7 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
     bwd_b8 av[T];
 #pragma unroll
     for (int kt = 0; kt < T; ++kt) {
-      const int row = s_row[kt * 16 + c];
+      const int row = row_of(kt * 16 + c);
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
       if (row >= 0) {
         const float* base = p.qkv + (int64_t)row * 3 * C + 2 * C + h * 16 + 8 * (g & 1);
@@ -2166,6 +2166,14 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
       bwd_split4(b.x, b.y, b.z, b.w, h1, l1);
       av[kt] = (g < 2) ? bwd_cat(h0, h1) : bwd_cat(l0, l1);
     }
+    __syncthreads();                 // every wave is done with the previous window's metadata
+    if (tid < LP) {
+      const int x = (int)(m_xyz & 1023u), y = (int)((m_xyz >> 10) & 1023u), z = (int)(m_xyz >> 20);
+      s_key[tid] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), m_bid);
+      s_qry[tid] = make_int4(4 * x, 4 * y, 4 * z, m_row >= 0 ? m_bid : -2);
+      s_row[tid] = m_row;
+    }
+    __syncthreads();
     __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before it reads them
     __builtin_amdgcn_wave_barrier();
 
@@ -2216,8 +2224,7 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
           }
           s[kt] = acc;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = att_rows_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < T; ++kt)
@@ -2227,8 +2234,7 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
             s[kt][r] = e;
             sum += e;
           }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = att_rows_sum(sum);
         const float inv = 1.0f / sum;
         float dsum = 0.f;
 #pragma unroll
@@ -2238,8 +2244,7 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
             s[kt][r] *= inv;                        // P
             dsum += s[kt][r] * dp[kt][r];
           }
-        dsum += __shfl_xor(dsum, 16, 64);
-        dsum += __shfl_xor(dsum, 32, 64);
+        dsum = att_rows_sum(dsum);
         f32x4 dsv[T];
         float dmax = 0.f;
 #pragma unroll
@@ -2254,7 +2259,8 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
         }
         if (q_rpe) {
 #pragma unroll
-          for (int o = 1; o < 64; o <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+          for (int o = 1; o < 16; o <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+          dmax = att_rows_max(dmax);
           int bexp = (int)((__float_as_uint(dmax) >> 23) & 0xffu);          // dmax in [2^(bexp-127), 2^(bexp-126))
           if (bexp >= 30) {                                                  // (smaller: the tile's gradient is zero in f32)
             if (bexp > 250) bexp = 250;

@@ -97,6 +97,7 @@ _GROUPED_TAPS = os.environ.get('HFL_GROUPED_TAPS', '1') != '0'     # live-tap co
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
+_DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
 _MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
 
 
@@ -269,6 +270,30 @@ def _require_layernorm(conv_norm: str):
         raise NotImplementedError("conv_norm=%r: every shipped config uses 'layernorm'" % conv_norm)
 
 
+def arm_drop_paths(model: nn.Module, batch_size: int, device, dtype=torch.float32):
+    """Draw the per-cloud stochastic-depth factors of every active `OctreeDropPath` of `model` for one forward in three
+    launches (rand, floor, div over an (instances x 2, B) matrix) and hand each instance its two rows.  Same distribution as
+    the reference's per-call draws (models/layers/octformer_layers.py:213-289: independent Bernoulli(keep) per call and
+    cloud); the draws themselves cannot match the reference's RNG stream either way."""
+    cache = model.__dict__.get('_drop_path_cache')
+    if cache is None:
+        cache = model.__dict__['_drop_path_cache'] = {'mods': [m for m in model.modules() if isinstance(m, OctreeDropPath)]}
+    mods = [m for m in cache['mods'] if m.drop_prob > 0.0]
+    sig = (tuple((m.drop_prob, m.scale_by_keep) for m in mods), str(device), dtype)
+    if cache.get('sig') != sig:
+        keep = [1.0 - m.drop_prob for m in mods for _ in range(2)]
+        div = [(1.0 - m.drop_prob) if (m.scale_by_keep and m.drop_prob < 1.0) else 1.0 for m in mods for _ in range(2)]
+        cache['sig'] = sig
+        cache['keep'] = torch.tensor(keep, dtype=dtype).reshape(-1, 1).to(device)
+        cache['div'] = torch.tensor(div, dtype=dtype).reshape(-1, 1).to(device)
+    if not mods:
+        return
+    f = torch.floor(torch.rand(2 * len(mods), batch_size, dtype=dtype, device=device) + cache['keep']) / cache['div']
+    for i, m in enumerate(mods):
+        m._factors = f[2 * i:2 * i + 2]
+        m._calls = 0
+
+
 class OctreeDropPath(nn.Module):
     """Per-cloud stochastic depth (models/layers/octformer_layers.py:213-289): in training every
     cloud keeps (scaled by 1/keep) or drops a residual branch; identity in eval.  `bid` gives the
@@ -279,24 +304,36 @@ class OctreeDropPath(nn.Module):
         self.drop_prob = float(drop_prob)
         self.scale_by_keep = scale_by_keep
 
+    # Every block calls its drop path twice per forward (attention branch, MLP branch).  Inside a model forward the draws of
+    # ALL instances are made at once (`arm_drop_paths`: one rand + floor + div for the whole network instead of four tiny
+    # launches per call, ~570 launches per CS-Wild-Places training step); `_factors` holds this instance's two rows (2, B).
+    # A recomputation under gradient checkpointing calls the same two branches again and so reads the same rows.
+    _factors = None
+    _calls = 0
+
+    def _draw(self, batch_size: int, dtype, device):
+        """(B,) per-cloud factor of one call: 0 or 1 / keep."""
+        f = self._factors
+        if f is not None and f.shape[1] == batch_size and f.device == device and f.dtype == dtype:
+            r = f[self._calls % f.shape[0]]
+            self._calls += 1
+            return r
+        keep = 1.0 - self.drop_prob
+        rnd = torch.floor(torch.rand(batch_size, dtype=dtype, device=device) + keep)
+        if keep > 0.0 and self.scale_by_keep:
+            rnd = rnd / keep
+        return rnd
+
     def forward(self, data, bid, batch_size: int):
         if self.drop_prob <= 0.0 or not self.training:
             return data
-        keep = 1.0 - self.drop_prob
-        rnd = torch.floor(torch.rand(batch_size, 1, dtype=data.dtype, device=data.device) + keep)
-        if keep > 0.0 and self.scale_by_keep:
-            rnd = rnd / keep
-        return data * rnd[bid]
+        return data * self._draw(batch_size, data.dtype, data.device)[bid].unsqueeze(1)
 
     def row_scale(self, bid, batch_size: int, like):
         """The same draw as forward() as a per-row factor (rows,) for the fused residual branches; None when inactive."""
         if self.drop_prob <= 0.0 or not self.training:
             return None
-        keep = 1.0 - self.drop_prob
-        rnd = torch.floor(torch.rand(batch_size, 1, dtype=like.dtype, device=like.device) + keep)
-        if keep > 0.0 and self.scale_by_keep:
-            rnd = rnd / keep
-        return rnd[bid].reshape(-1).contiguous()
+        return self._draw(batch_size, like.dtype, like.device)[bid].reshape(-1).contiguous()
 
     def extra_repr(self):
         return 'drop_prob={:.4f}'.format(self.drop_prob)
@@ -1524,6 +1561,8 @@ class HOTFormerLoc(nn.Module):
                                'call to_device(batch, "cuda") first -- there is no CPU path')
         octree.construct_all_neigh()                     # no-op when misc/torch_utils.to_device did it
         data = octree.get_input_feature(self.input_features, nempty=True)
+        if self.training and _DROP_POOL:
+            arm_drop_paths(self, int(octree.batch_size), data.device, data.dtype)
         local, relay, plan = self.backbone(data, octree, octree.depth)
         if self.pooling.pooled_feats == 'local':
             x = local
