@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libhotformerloc_hip.so'
 ARCH = 'gfx950'
-SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'gemm_x3.hip', 'mlp_fused.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
+SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'gemm_x3.hip', 'mlp_fused.hip', 'qkv_fused.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 # hipBLASLt for hfl_gemm_bf16 (the ROCm copy that matches the headers; rpath so the loader finds it)
@@ -27,7 +27,8 @@ LINK_FLAGS = ['-L' + os.path.join(ROCM, 'lib'), '-lhipblaslt', '-Wl,-rpath,' + o
 EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
                # mlp_fused.hip: element-wise math runs BETWEEN MFMAs there; packed f32 VALU (what SLP vectorisation of adjacent
                # scalar ops produces) stalls the matrix pipe, plain VALU does not
-               'mlp_fused.hip': ['-fno-slp-vectorize']}
+               'mlp_fused.hip': ['-fno-slp-vectorize'],
+               'qkv_fused.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc() -> str:
@@ -49,7 +50,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(LIBDIR, 'obj')
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, 'hfl_common.h'), os.path.join(CSRC, 'x3_math.h'),
+    headers = [os.path.join(CSRC, 'hfl_common.h'), os.path.join(CSRC, 'x3_math.h'), os.path.join(CSRC, 'stage_stream.h'),
                os.path.join(HERE, '..', 'include', 'hotformerloc_hip.h')]
     jobs = []
     for src in SOURCES:

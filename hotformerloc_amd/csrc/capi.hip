@@ -35,9 +35,13 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
     rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
     if (rc != HFL_OK) return rc;
     if (phase == 1) {           // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
-      rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, nt, C, w->eps, stream);
-      if (rc != HFL_OK) return rc;
-      rc = hfl_linear_x3_qkv(qkv, a2, w->qkv_w, w->qkv_b, nt, (int)C, (int)(3 * C), w->q_scale, stream);
+      if (w->qkv_pack != nullptr) {
+        rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
+      } else {
+        rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, nt, C, w->eps, stream);
+        if (rc != HFL_OK) return rc;
+        rc = hfl_linear_x3_qkv(qkv, a2, w->qkv_w, w->qkv_b, nt, (int)C, (int)(3 * C), w->q_scale, stream);
+      }
       if (rc != HFL_OK) return rc;
     }
   }

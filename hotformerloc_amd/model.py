@@ -189,6 +189,34 @@ def _mlp_pack(mlp: 'MLP', rows: int):
     return hit[3]
 
 
+# LN1 -> qkv of the token rows as ONE launch (csrc/qkv_fused.hip).  Worth it where the launch's workgroup passes are well
+# filled: C = 128 from 24 576 rows on (118 096 rows: 71 vs 96 us for LayerNorm + qkv GEMM), C = 256 only when the last round of
+# 32 768 rows is at least half full (65 536 rows: 103 vs 114-122 us, but 66 775 rows -- 2.04 rounds, three passes -- 153 vs 127)
+_QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
+
+
+def _qkv_pack(att: 'OctreeAttention', rows: int):
+    """Weight image of the fused LN1 -> qkv launch for this block, or None when the launch does not apply / does not pay."""
+    lin = att.qkv
+    c = lin.in_features
+    if not (_QKV_FUSED and rows >= _MLP_FUSED_MIN_ROWS and c in (128, 256) and lin.out_features == 3 * c and lin.bias is not None):
+        return None
+    if c == 256:
+        fill = (rows % 32768) / 32768.0
+        if 0.0 < fill < 0.5:
+            return None
+    w = lin.weight
+    key = ('qkvpack', id(w))
+    hit = _W3_CACHE.get(key)
+    stamp = (w._version, w.data_ptr())
+    if hit is None or hit[0]() is not w or hit[1] != stamp:
+        if hit is None or hit[0]() is not w:
+            weakref.finalize(w, _W3_CACHE.pop, key, None)
+        hit = (weakref.ref(w), stamp, ops.qkv_fused_pack(w))
+        _W3_CACHE[key] = hit
+    return hit[2]
+
+
 def _block_tail_x3(x, attn_out2, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
     """proj (+bias +residual) -> LN2 -> fc1 (+bias, GELU, re-split) -> fc2 (+bias +residual): the proj launch of the
     hand-written GEMM, then the MLP branch as one fused launch (hidden activation in registers) or, for small row counts,
@@ -625,11 +653,24 @@ class OctreeAttention(nn.Module):
     def forward_split(self, x, norm1: nn.LayerNorm, plan: WindowPlan, depth: int):
         """LN1 -> qkv -> attention, split-precision path; returns the bf16 operand of `proj`."""
         if _GEMM_MODE == 'x3':         # qkv bias folded into the GEMM epilogue, attention writes split2 rows
+            f16 = _ATTN_F16 and ops.window_attention_f16_ok(x.shape[0], self.patch_size, self.dilation,
+                                                            self.rt_per_window, self.num_heads, depth)
+            qs = 16 ** -0.5 * 1.4426950408889634
+            nt = plan.n_tokens[depth]
+            qpack = _qkv_pack(self, nt) if (f16 and x.dtype == torch.float32 and x.is_contiguous()) else None
+            if qpack is not None:
+                # as hfl_block_forward_x3 does it: LN1 -> qkv of the token rows in one launch, the relay rows through
+                # LayerNorm + the qkv GEMM
+                qkv = torch.empty((x.shape[0], 3 * x.shape[1]), dtype=torch.float32, device=x.device)
+                ops.ln_qkv_fused(x[:nt], norm1.weight, norm1.bias, norm1.eps, qpack, self.qkv.bias, qs, out=qkv[:nt])
+                if x.shape[0] > nt:
+                    ops.linear_x3_qkv(ops.layer_norm_split2(x[nt:], norm1.weight, norm1.bias, norm1.eps), _w2(self.qkv),
+                                      self.qkv.bias, qs, out=qkv[nt:])
+                return self.core(qkv, plan, depth, out_split=2, qkv_f16=True)
             a2 = ops.layer_norm_split2(x, norm1.weight, norm1.bias, norm1.eps)
-            if _ATTN_F16 and ops.window_attention_f16_ok(x.shape[0], self.patch_size, self.dilation,
-                                                         self.rt_per_window, self.num_heads, depth):
+            if f16:
                 # the projection writes q, k, v as fp16 (hi, lo) MFMA operands (q pre-scaled): fp16-MFMA window kernel
-                qkv = ops.linear_x3_qkv(a2, _w2(self.qkv), self.qkv.bias, 16 ** -0.5 * 1.4426950408889634)
+                qkv = ops.linear_x3_qkv(a2, _w2(self.qkv), self.qkv.bias, qs)
                 return self.core(qkv, plan, depth, out_split=2, qkv_f16=True)
             qkv = ops.linear_x3(a2, _w2(self.qkv), bias=self.qkv.bias)
             return self.core(qkv, plan, depth, out_split=2)
@@ -729,6 +770,8 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     if table is not None and expanded is None:
         return None
     mlp = block.mlp
+    qpack = _qkv_pack(att, nt)
+    w.qkv_pack = None if qpack is None else qpack.data_ptr()
     pack = _mlp_pack(mlp, rows)
     if pack is not None:
         w.mlp_pack, w.fc1_w, w.fc2_w = pack.data_ptr(), None, None
@@ -740,7 +783,7 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
                           dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
                           batch_size=plan.B, scale=16 ** -0.5, depth=depth,
                           rpe_expanded=None if expanded is None else expanded.data_ptr())
-    return ops.BlockCall(w, (keep, expanded, pack), x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
+    return ops.BlockCall(w, (keep, expanded, pack, qpack), x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
 
 
 def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):

@@ -585,7 +585,7 @@ def wgrad_x3(dy2: torch.Tensor, x2: torch.Tensor, with_bias: bool = False):
     return dw, db
 
 
-def linear_x3_qkv(x2: torch.Tensor, w2: torch.Tensor, bias, q_scale: float) -> torch.Tensor:
+def linear_x3_qkv(x2: torch.Tensor, w2: torch.Tensor, bias, q_scale: float, out=None) -> torch.Tensor:
     """qkv projection into the fp16 (hi, lo) operand layout of the v5 window-attention kernel (hfl_linear_x3_qkv):
     returns an opaque (rows, 3C) float32-sized buffer for `window_attention(..., qkv_f16=True)`."""
     _dev(x2, w2, bias)
@@ -593,11 +593,45 @@ def linear_x3_qkv(x2: torch.Tensor, w2: torch.Tensor, bias, q_scale: float) -> t
     m, k2 = x2.shape
     n = w2.shape[0]
     assert w2.shape[1] == k2 and n % 3 == 0
-    out = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+    else:
+        assert tuple(out.shape) == (m, n) and out.dtype == torch.float32 and out.is_contiguous()
     with _timed('hfl_linear_x3', m * (k2 // 2) * 4 + m * n * 4, 2 * m * (k2 // 2) * n):
         check(_native.load().hfl_linear_x3_qkv(out.data_ptr(), x2.data_ptr(), w2.data_ptr(),
                                                None if bias is None else _f32c(bias).data_ptr(), m, k2 // 2, n,
                                                float(q_scale), _stream()), 'hfl_linear_x3_qkv')
+    return out
+
+
+def qkv_fused_pack(w_qkv: torch.Tensor) -> torch.Tensor:
+    """Weight image of `ln_qkv_fused` from the fp32 qkv weight (3C, C) (hfl_qkv_fused_pack).  Once per parameter."""
+    _dev(w_qkv)
+    w = _f32c(w_qkv.detach())
+    c = w.shape[1]
+    assert tuple(w.shape) == (3 * c, c)
+    lib = _native.load()
+    n = int(lib.hfl_qkv_fused_pack_bytes(c))
+    if n <= 0:
+        raise _native.NativeLibraryError('hfl_qkv_fused_pack: unsupported channel count %d' % c)
+    pack = torch.empty(n, dtype=torch.uint8, device=w.device)
+    check(lib.hfl_qkv_fused_pack(pack.data_ptr(), w.data_ptr(), c, _stream()), 'hfl_qkv_fused_pack')
+    return pack
+
+
+def ln_qkv_fused(x, gamma, beta, eps: float, pack, bias, q_scale: float, out=None):
+    """LayerNorm + qkv projection into the fp16 (hi, lo) operand layout of the window kernel in ONE launch
+    (hfl_ln_qkv_fused = layer_norm_split2 + linear_x3_qkv): an opaque (rows, 3C) float32-sized buffer."""
+    _dev(x, gamma, beta, pack, bias)
+    x = _f32c(x)
+    m, c = x.shape
+    if out is None:
+        out = torch.empty((m, 3 * c), dtype=torch.float32, device=x.device)
+    # algorithmic bytes: read x, write the operand rows; 2 M C 3C flop
+    with _timed('hfl_ln_qkv_fused', m * c * 16, 6 * m * c * c):
+        check(_native.load().hfl_ln_qkv_fused(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                              float(eps), pack.data_ptr(), _f32c(bias).data_ptr(), float(q_scale), m, c,
+                                              _stream()), 'hfl_ln_qkv_fused')
     return out
 
 

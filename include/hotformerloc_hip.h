@@ -415,6 +415,16 @@ int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channel
 int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* b1, const float* b2, int64_t n_rows, int channels, hfl_stream_t stream);
 
+/* 9d. LayerNorm -> qkv projection as ONE launch, written as the fp16 (hi, lo) operand rows of the window kernel
+ *     (= hfl_layer_norm_split2 + hfl_linear_x3_qkv: norm1 -> attention.qkv, models/octformer_backbone.py:70,
+ *     models/hotformerloc_backbone.py:213-216; csrc/qkv_fused.hip).  C = 128 or 256.  `pack` = hfl_qkv_fused_pack_bytes(C)
+ *     bytes laid out once per parameter by hfl_qkv_fused_pack from the f32 weight (3C, C); bias (3C); qkv_out (n_rows, 3C)
+ *     4 B per element; q_scale (softmax scale x log2 e) is folded into the queries. */
+int64_t hfl_qkv_fused_pack_bytes(int channels);
+int hfl_qkv_fused_pack(void* pack, const float* w_qkv, int channels, hfl_stream_t stream);
+int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                     const float* bias, float q_scale, int64_t n_rows, int channels, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 10. Backward kernels (training path; autograd glue in hotformerloc_amd/autograd.py).
  *     The reference gets these from PyTorch autograd over its materialised formulation and from
@@ -459,6 +469,9 @@ typedef struct hfl_block_weights {
   const void* mlp_pack;                                /* hfl_mlp_fused_pack image of (fc1, fc2) or NULL: when set, LN2 -> fc1 ->
                                                           GELU -> fc2 -> residual run as ONE launch (hfl_ln_mlp_fused) and fc1_w /
                                                           fc2_w are not read */
+  const void* qkv_pack;                                /* hfl_qkv_fused_pack image of qkv_w or NULL: when set, phase 1 runs LN1 -> qkv
+                                                          of the token rows as ONE launch (hfl_ln_qkv_fused); qkv_w is still
+                                                          read for the relay rows */
 } hfl_block_weights;
 typedef struct hfl_block_io {
   const float* x_in;

@@ -934,3 +934,31 @@ def test_ln_mlp_fused_layout_exact_on_small_integers():
     ref = _mlp_ref(x, torch.ones(C), torch.zeros(C), 0.0, w1, b1, w2, b2)
     # GELU of integers is not an integer: compare to fp64 at the (hi, lo) bf16 resolution of the hidden activation
     assert (got.double() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,c', [(1, 128), (17, 128), (5000, 128), (70000, 128), (33, 256), (4099, 256), (40000, 256)])
+def test_ln_qkv_fused_matches_fp64_and_the_two_launch_form(rows, c):
+    """hfl_ln_qkv_fused (LayerNorm -> qkv projection -> fp16 (hi, lo) attention operand rows in one launch) against fp64
+    LayerNorm + Linear, and against hfl_layer_norm_split2 + hfl_linear_x3_qkv, whose arithmetic it shares (same split
+    operands, same fp16 split of the result): ragged row counts, several workgroup passes, both channel widths."""
+    g = torch.Generator(device='cuda').manual_seed(rows + c)
+    x = torch.randn(rows, c, device='cuda', generator=g) * 1.7 + 0.4
+    gamma = torch.rand(c, device='cuda', generator=g) + 0.5
+    beta = torch.randn(c, device='cuda', generator=g) * 0.1
+    w = torch.randn(3 * c, c, device='cuda', generator=g) * 0.06
+    b = torch.randn(3 * c, device='cuda', generator=g) * 0.1
+    qs = 16 ** -0.5 * 1.4426950408889634
+
+    def decode(buf):           # per head 64 B = [16 x hi | 16 x lo] fp16
+        h = buf.view(torch.float16).reshape(rows, 3, c // 16, 2, 16).float()
+        return (h[:, :, :, 0] + h[:, :, :, 1]).reshape(rows, 3 * c)
+
+    fused = decode(ops.ln_qkv_fused(x, gamma, beta, 1e-5, ops.qkv_fused_pack(w), b, qs))
+    two = decode(ops.linear_x3_qkv(ops.layer_norm_split2(x, gamma, beta, 1e-5), ops.split2_weight(w), b, qs))
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.double(), (c,), gamma.double(), beta.double(), 1e-5),
+                                     w.double(), b.double())
+    ref[:, :c] *= qs
+    assert torch.isfinite(fused).all()
+    assert ((fused.double() - ref).norm() / ref.norm()).item() < 1e-5
+    assert (fused - two).abs().max().item() < 1e-4 * ref.abs().max().item()
