@@ -819,6 +819,43 @@ def window_attention(qkv, tok_meta, rpe_table, n_tokens: int, n_windows: int, pa
     return out
 
 
+def window_attention_multi(problems, out_split: int = 2):
+    """Several window-attention problems on fp16 (hi, lo) qkv operands as ONE launch when their shapes agree
+    (hfl_window_attention_fwd_multi), else one launch each.  `problems`: list of dicts with the arguments of
+    `window_attention` (qkv, tok_meta, rpe_table, n_tokens, n_windows, patch_size, dilation, n_relay, n_heads, batch_size,
+    rt_row0, depth).  Returns the list of outputs (split2 bf16 rows for out_split 2, fp32 rows for 0)."""
+    assert 1 <= len(problems) <= 4 and out_split in (0, 2)
+    lib = _native.load()
+    outs, descs, keep = [], [], []
+    for pr in problems:
+        qkv = _f32c(pr['qkv'])
+        _dev(qkv, pr['tok_meta'], pr['rpe_table'])
+        rows, c = qkv.shape[0], pr['n_heads'] * 16
+        assert qkv.shape[1] == 3 * c
+        out = (torch.zeros((rows, 2 * c), dtype=torch.bfloat16, device=qkv.device) if out_split == 2
+               else torch.zeros((rows, c), dtype=torch.float32, device=qkv.device))
+        bnd = int(0.8 * pr['patch_size'] * pr['dilation'] ** 0.5)
+        desc = WindowAttnDesc(n_tokens=pr['n_tokens'], rt_row0=pr.get('rt_row0', 0), n_windows=pr['n_windows'],
+                              patch_size=pr['patch_size'], dilation=pr['dilation'], n_relay=pr['n_relay'],
+                              n_heads=pr['n_heads'], pos_bnd=bnd, batch_size=pr['batch_size'], scale=16 ** -0.5,
+                              depth=pr['depth'])
+        table = pr['rpe_table']
+        if table is not None:
+            expanded = rpe_expand(table, pr['n_heads'], bnd, pr['depth'], True)
+            desc.rpe_expanded = None if expanded is None else expanded.data_ptr()
+            table = _f32c(table)
+            keep.append((expanded, table))
+        outs.append(out)
+        descs.append(desc)
+        keep.append(qkv)
+        pr['_ptrs'] = (out.data_ptr(), qkv.data_ptr(), pr['tok_meta'].data_ptr(), None if table is None else table.data_ptr())
+    arr = lambda i: _native.ptr_array([pr['_ptrs'][i] for pr in problems])
+    check(lib.hfl_window_attention_fwd_multi(len(problems), arr(0), arr(1), arr(2), arr(3),
+                                             _native.ptr_array([ctypes.addressof(d) for d in descs]),
+                                             out_split | 0x100, _stream()), 'hfl_window_attention_fwd_multi')
+    return outs
+
+
 def relay_attention(qkv, seq_rows, seq_off, batch: int, n_heads: int, max_seq_len: int):
     """Ragged per-cloud attention over relay-token rows; rows in no sequence -> 0."""
     _dev(qkv, seq_rows, seq_off)

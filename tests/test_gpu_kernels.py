@@ -962,3 +962,47 @@ def test_ln_qkv_fused_matches_fp64_and_the_two_launch_form(rows, c):
     assert torch.isfinite(fused).all()
     assert ((fused.double() - ref).norm() / ref.norm()).item() < 1e-5
     assert (fused - two).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_window_attention_multi_launch_equals_single_launches():
+    """hfl_window_attention_fwd_multi: the three pyramid levels of a Wild-Places batch (same K, relay token, heads; different
+    depths, row counts and expanded tables) in ONE launch against one launch each -- the same windows through the same kernel,
+    bitwise equal; a problem with another shape in the list falls back to single launches and is equal as well."""
+    sizes = [4096, 30, 2500, 4096]
+    clouds = [syn.unit_ball_cloud(700 + i, n) for i, n in enumerate(sizes)]
+    params, ref, dev, oplan, plan = _plans(clouds, 'wild-places', 7)
+    K = params.patch_size
+    g = torch.Generator(device='cuda').manual_seed(9)
+    probs = []
+    for depth in (4, 3, 2):
+        H, C = 16, 256
+        nt, W = plan.n_tokens[depth], plan.n_windows[depth]
+        x = torch.randn(nt + W, C, device='cuda', generator=g)
+        w = torch.randn(3 * C, C, device='cuda', generator=g) * 0.06
+        b = torch.randn(3 * C, device='cuda', generator=g) * 0.1
+        qkv = ops.linear_x3_qkv(ops.split2(x), ops.split2_weight(w), b, 0.25 * 1.4426950408889634)
+        table = torch.randn(3 * (2 * int(0.8 * K) + 1), H, device='cuda', generator=g) * 0.3
+        probs.append(dict(qkv=qkv, tok_meta=plan.meta[depth], rpe_table=table, n_tokens=nt, n_windows=W, patch_size=K,
+                          dilation=1, n_relay=1, n_heads=H, batch_size=len(sizes), rt_row0=nt, depth=depth))
+    single = [ops.window_attention(p['qkv'], p['tok_meta'], p['rpe_table'], p['n_tokens'], p['n_windows'], K, 1, 1, 16,
+                                   len(sizes), rt_row0=p['n_tokens'], depth=p['depth'], out_split=2, qkv_f16=True)
+              for p in probs]
+    multi = ops.window_attention_multi([dict(p) for p in probs])
+    for p, a, m in zip(probs, single, multi):
+        used = p['n_tokens'] + (-(-p['n_tokens'] // K))          # token rows + relay rows of windows that hold tokens
+        assert torch.equal(a[:used].view(torch.int16), m[:used].view(torch.int16)), p['depth']
+    # depth 5 without relay token (another shape): the call must still give every problem its own result
+    d5 = 5
+    nt5, W5 = plan.n_tokens[d5], plan.n_windows[d5]
+    x5 = torch.randn(nt5, 128, device='cuda', generator=g)
+    qkv5 = ops.linear_x3_qkv(ops.split2(x5), ops.split2_weight(torch.randn(384, 128, device='cuda', generator=g) * 0.08),
+                             torch.zeros(384, device='cuda'), 0.25 * 1.4426950408889634)
+    t5 = torch.randn(3 * (2 * int(0.8 * K) + 1), 8, device='cuda', generator=g) * 0.3
+    p5 = dict(qkv=qkv5, tok_meta=plan.meta[d5], rpe_table=t5, n_tokens=nt5, n_windows=W5, patch_size=K, dilation=1, n_relay=0,
+              n_heads=8, batch_size=len(sizes), rt_row0=0, depth=d5)
+    want5 = ops.window_attention(qkv5, plan.meta[d5], t5, nt5, W5, K, 1, 0, 8, len(sizes), depth=d5, out_split=2, qkv_f16=True)
+    mixed = ops.window_attention_multi([dict(probs[0]), dict(p5)])
+    assert torch.equal(mixed[1][:nt5].view(torch.int16), want5[:nt5].view(torch.int16))
+    used0 = probs[0]['n_tokens'] + (-(-probs[0]['n_tokens'] // K))
+    assert torch.equal(mixed[0][:used0].view(torch.int16), single[0][:used0].view(torch.int16))
