@@ -555,8 +555,10 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
                      'frac_issued_of_peak_used': round(useful_tf * (3.5 if f16 else 1.0) /
                                                        (MFMA_F16_PEAK_TFLOPS if f16 else mfma_peak_f32), 4),
                      'useful_over_f32_peak': round(useful_tf / MFMA_F32_PEAK_TFLOPS, 4)},
-            'timing': ('HIP events per launch over %d steps, pyramid streams serialised (re-run right '
-                       'after the timed region, never inside it; agrees with rocprofv3 --kernel-trace)' % args.steps)
+            'timing': ('HIP event pair around every launch (recorded by the library on the launch stream for the fp16 kernel, '
+                       'by ops.KernelTimer for the fp32 one) over %d steps re-run right after the timed region, never inside '
+                       'it, with the step\'s launch schedule on ONE stream; the kernel trace of that schedule is '
+                       'profiles/*_serial_kernel_stats.csv (bench.py --serial-streams)' % args.steps)
                       if serialised else 'HIP events per launch, re-run after the timed region with the streams of the step'}
     if sizes:
         # the step's launches by size: depth 5 (octf stage), depth 4, and depths 3 + 2 together in one launch (24 per step
