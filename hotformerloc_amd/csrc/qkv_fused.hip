@@ -106,8 +106,9 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
   };
   // stage protocol of csrc/mlp_fused.hip: at acquire(n) stage n has landed for every wave and the slot of stage n - 2 is
   // free; its refill with stage n + 2 goes out piece by piece between the MFMA steps of stage n.  The epilogue's stores
-  // sit on the same counter behind those pieces: waiting for "all but the last DPW operations" therefore waits for a little
-  // more than stage n (never less).
+  // sit on the same counter: loads return in order among themselves, so "at most DPW operations outstanding" can only be the
+  // youngest DPW loads and / or stores -- stage n has landed whatever the stores do (they may complete out of order with the
+  // loads: a count of DPW + stores would NOT be safe).  The price: outstanding stores eat into the look-ahead of the ring.
   int dma_n = 0;
   uint32_t dma_slot = 0;
   auto acquire = [&](int n) -> const unsigned char* {
