@@ -1,6 +1,6 @@
 """Phase timeline of ONE wave of the fp16 window-attention kernel (window_debug bit 3: s_memtime stamps at the top of the window
 loop, after the barrier, after the fragment setup / prefetch issue and after every query tile), depth-4 bench shape.
-HFL_KNOBS=window_pf=1 selects the prefetching variant.  Needs a library built with the stamps compiled in:
+HFL_KNOBS=key=value,... sets probe knobs (hfl_set_variant).  Needs a library built with the stamps compiled in:
 `HFL_EXTRA_HIPCC_FLAGS=-DHFL_ATT_TRACE=1 python -m hotformerloc_amd.build` (touch csrc/attention.hip first)."""
 import ctypes
 import os

@@ -15,7 +15,7 @@ if os.environ.get('HFL_LIB'):
 from hotformerloc_amd import build_batch_octree, load_config, ops, synthetic as syn  # noqa: E402
 from hotformerloc_amd.plan import WindowPlan  # noqa: E402
 
-for kv in os.environ.get('HFL_KNOBS', '').split(','):          # e.g. HFL_KNOBS=window_pf=1,window_v4_wgs_per_cu=2
+for kv in os.environ.get('HFL_KNOBS', '').split(','):          # e.g. HFL_KNOBS=window_rpe_form1_max_depth=5,window_v4_wgs_per_cu=2
     if '=' in kv:
         _native.load().hfl_set_variant(kv.split('=')[0].encode(), int(kv.split('=')[1]))
 depths = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else [5, 4, 3, 2]
