@@ -94,28 +94,35 @@ class OverlappedGradReducer:
         final in the backward); a bucket is flattened and all-reduced asynchronously on a side stream as soon as every used
         parameter in it has its final gradient (`register_post_accumulate_grad_hook`), while the backward continues;
       * buckets are launched strictly IN ORDER on every rank, whatever the timing, so the sequence of collectives is the
-        same everywhere by construction; what is still missing at `finish()` goes out then, in the same order;
+        same everywhere by construction; what is still missing at `finish()` goes out then, in the same order -- also on a
+        rank that never called `arm()` in this step (no local minibatch): it sends every bucket from `finish()`;
       * which parameters are "used" (receive a gradient on some rank) is not knowable before a backward: the first step of a
         reducer runs the non-overlapped `allreduce_gradients` and records the all-reduced has-gradient flags; later steps
-        assume that set, contribute zeros for a used parameter that has no gradient on this rank, keep `grad = None` for
-        the others, and re-check the flags at `finish()` (one small all-reduce): if the set changed, the stragglers are
-        reduced on the spot and the set is updated.
-    Only the LAST backward of a step may launch (`arm()` before it): earlier minibatches only accumulate."""
+        assume that set, contribute zeros for a used parameter that has no gradient on this rank, and all-reduce the REAL
+        has-gradient flags of ALL parameters at `finish()` (one small collective): a used parameter that got no gradient
+        on any rank this step goes back to `grad = None` (AdamW then skips it, as the reference's step does), a parameter
+        outside the set that did get one is reduced on the spot and joins the set.
+    Only the LAST backward of a step may launch (`arm()` before it): earlier minibatches only accumulate.
+    `force`: run the collectives at world size 1 too (single-GPU RCCL test)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, force: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.bucket_bytes = bucket_bytes
+        self.force = force
         self.used = None                       # per parameter: receives a gradient on some rank (learnt on the first step)
         self.buckets: List[List[int]] = []
         self.armed = False
         self._handles = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(self.params)]
         self._stream = None
+        self._works = []
         self.launched_during_backward = 0      # diagnostics of the last step
 
     # -- bookkeeping -------------------------------------------------------------------------
     def _active(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.force or dist.get_world_size(self.group) > 1
 
     def _build_buckets(self):
         self.buckets, cur, size = [], [], 0
@@ -137,15 +144,30 @@ class OverlappedGradReducer:
                 self._launch_ready()
         return hook
 
+    def _begin(self):
+        self._ready = [False] * len(self.params)
+        self._had_grad = [False] * len(self.params)     # real (not zero-filled) gradient on THIS rank
+        self._next = 0
+        self._works = []
+        self.launched_during_backward = 0
+
     def arm(self):
         """Call right before the LAST backward of the step: from here on a parameter's gradient is final when its hook fires."""
         if not self._active() or self.used is None:
             return
+        self._begin()
         self.armed = True
-        self._ready = [False] * len(self.params)
-        self._next = 0
+
+    def reset(self):
+        """Drop the state of a step that did not reach `finish()` (exception in the backward).  Collectives already in
+        flight are waited for so that their buffers may be freed; the gradients of that step are not meaningful."""
+        self.armed = False
+        for work, _flat, _grads in self._works:
+            try:
+                work.wait()
+            except Exception:                          # pragma: no cover
+                pass
         self._works = []
-        self.launched_during_backward = 0
 
     # -- launching ---------------------------------------------------------------------------
     def _launch_ready(self):
@@ -162,6 +184,8 @@ class OverlappedGradReducer:
             p = self.params[i]
             if p.grad is None:                 # used elsewhere, untouched here: zeros
                 p.grad = torch.zeros_like(p)
+            else:
+                self._had_grad[i] = True
             grads.append(p.grad)
         if dev.type == 'cuda':
             if self._stream is None:
@@ -181,40 +205,52 @@ class OverlappedGradReducer:
             self.armed = False
             return
         if self.used is None:                  # first step: learn the set with the non-overlapped reduction
-            has = allreduce_gradients(self.params, self.group, self.bucket_bytes, return_flags=True)
+            has = allreduce_gradients(self.params, self.group, self.bucket_bytes, force=self.force, return_flags=True)
             self.used = has
             self._build_buckets()
             return
-        if not self.armed:                     # arm() was not called: plain reduction
-            allreduce_gradients(self.params, self.group, self.bucket_bytes)
-            return
+        if not self.armed:                     # arm() was not called on this rank: the SAME bucket sequence, all from here
+            self._begin()
         self.armed = False
         while self._next < len(self.buckets):
             self._launch(self._next)
             self._next += 1
         dev = self.params[0].device
+        cuda = dev.type == 'cuda'
+        # The copy-back must be ordered after the collective ON THE STREAM IT RUNS ON: for the RCCL process group
+        # `work.wait()` only makes the *current* stream wait for the collective's own stream (it does not block the
+        # host), so it has to be called with the side stream current -- the stream `flat` was produced on and the
+        # copy-back is enqueued on.  (gloo's wait() blocks the host; the same code is right there too.)
         for work, flat, grads in self._works:
-            work.wait()
-            ctx = torch.cuda.stream(self._stream) if dev.type == 'cuda' else _null()
+            ctx = torch.cuda.stream(self._stream) if cuda else _null()
             with ctx:
+                work.wait()
                 off = 0
                 for g in grads:
                     g.copy_(flat[off:off + g.numel()].view_as(g))
                     off += g.numel()
-        if dev.type == 'cuda':
+                if cuda:
+                    for g in grads:            # the gradients are consumed on the main stream afterwards
+                        g.record_stream(self._stream)
+        if cuda:
             torch.cuda.current_stream(dev).wait_stream(self._stream)
         self._works = []
-        # parameters outside the assumed set that DID get a gradient somewhere this step (the set changed): reduce them now
-        extra = [i for i, u in enumerate(self.used) if not u]
-        if extra:
-            has = torch.tensor([0.0 if self.params[i].grad is None else 1.0 for i in extra], dtype=torch.float32, device=dev)
-            dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.group)
-            late = [i for i, h in zip(extra, (has > 0).tolist()) if h]
-            if late:
-                allreduce_gradients([self.params[i] for i in late], self.group, self.bucket_bytes)
-                for i in late:
-                    self.used[i] = True
-                self._build_buckets()
+        # the REAL has-gradient flags of every parameter, summed over the ranks (one small collective)
+        has = torch.tensor([1.0 if (self._had_grad[i] if u else self.params[i].grad is not None) else 0.0
+                            for i, u in enumerate(self.used)], dtype=torch.float32, device=dev)
+        dist.all_reduce(has, op=dist.ReduceOp.SUM, group=self.group)
+        anywhere = (has > 0).tolist()
+        late = []
+        for i, (u, a) in enumerate(zip(self.used, anywhere)):
+            if u and not a:
+                self.params[i].grad = None     # used before, no gradient on ANY rank this step: as the reference leaves it
+            elif a and not u:
+                late.append(i)
+        if late:                               # the set grew: reduce the newcomers now (same list on every rank)
+            allreduce_gradients([self.params[i] for i in late], self.group, self.bucket_bytes, force=self.force)
+            for i in late:
+                self.used[i] = True
+            self._build_buckets()
 
     def close(self):
         for h in self._handles:
@@ -269,12 +305,17 @@ def multistaged_training_step(model: torch.nn.Module, minibatches: List[dict], p
     else:
         model.zero_grad(set_to_none=True)
     i = 0
-    for k, mb in enumerate(minibatches):
-        y = model(mb)['global']
-        if reducer is not None and k == len(minibatches) - 1:
-            reducer.arm()                                  # gradients are final from here on: buckets may leave
-        y.backward(gradient=grad_local[i:i + y.shape[0]])
-        i += y.shape[0]
+    try:
+        for k, mb in enumerate(minibatches):
+            y = model(mb)['global']
+            if reducer is not None and k == len(minibatches) - 1:
+                reducer.arm()                              # gradients are final from here on: buckets may leave
+            y.backward(gradient=grad_local[i:i + y.shape[0]])
+            i += y.shape[0]
+    except BaseException:
+        if reducer is not None:
+            reducer.reset()                                # no stale armed state / in-flight work for the next step
+        raise
     if reducer is not None:
         reducer.finish()
     else:

@@ -205,9 +205,11 @@ def _overlap_worker(rank, world, port, n_total, result_dir):
         model.use_sometimes = rank == 0
         reducer = OverlappedGradReducer(model.parameters(), bucket_bytes=64)     # tiny buckets: several per step
         out = []
-        for step in range(3):
+        for step in range(4):
             if step == 2:
                 model.use_sometimes = rank == world - 1          # the set of touched parameters moves to another rank
+            if step == 3:
+                model.use_sometimes = False                      # ... and then no rank touches it
             stats = multistaged_training_step(model, minibatches, pos, neg, _toy_listwise_loss, n_total=n_total,
                                               reducer=reducer)
             out.append({'grads': [None if p.grad is None else p.grad.clone() for p in model.parameters()],
@@ -224,17 +226,19 @@ def test_overlapped_gradient_reduction_matches_single_process(tmp_path, world, n
     """OverlappedGradReducer behind the multi-staged step (gloo; world 4 with UNEVEN shards 3,3,2,2): step 0 learns which
     parameters receive gradients (plain reduction), steps 1-2 reduce bucket by bucket from the gradient hooks of the last
     backward -- same sums as one process back-propagating the whole batch, identical on every rank, `grad = None` kept for a
-    parameter no rank uses, zeros contributed for one only some ranks use."""
+    parameter no rank uses, zeros contributed for one only some ranks use, and `grad = None` again in a step where a
+    parameter of the learnt set receives no gradient on any rank (step 3; the reference's step leaves it None and AdamW skips it)."""
     mp.spawn(_overlap_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, 'ov_%d.pt' % r)) for r in range(world)]
     x, pos, neg = _toy_data(n_total)
-    for step in range(3):
+    for step in range(4):
         # single-process gradients: `sometimes` is added on the rows of the rank that uses it
         ref = _ToyEncoderWithUnused()
         user = 0 if step < 2 else world - 1
         lo, hi = shard_bounds(n_total, user, world)
         y = ref.b(torch.tanh(ref.a(x)))
-        y = torch.cat([y[:lo], y[lo:hi] + ref.sometimes, y[hi:]], 0)
+        if step < 3:
+            y = torch.cat([y[:lo], y[lo:hi] + ref.sometimes, y[hi:]], 0)
         loss, _ = _toy_listwise_loss(torch.nn.functional.normalize(y, dim=1), pos, neg)
         loss.backward()
         want = [p.grad for p in ref.parameters()]
@@ -242,14 +246,57 @@ def test_overlapped_gradient_reduction_matches_single_process(tmp_path, world, n
             got = res[r][step]
             assert abs(got['loss'] - loss.item()) < 1e-6
             for g, w, (name, _) in zip(got['grads'], want, ref.named_parameters()):
-                if name == 'never_used':
-                    assert g is None
+                if name == 'never_used' or (name == 'sometimes' and step == 3):
+                    assert g is None, (step, r, name)
                 else:
                     assert g is not None and torch.allclose(g, w, atol=1e-6), (step, r, name)
             for g, g0 in zip(got['grads'], res[0][step]['grads']):
                 assert (g is None and g0 is None) or torch.equal(g, g0)
         if step >= 1:                                   # overlapped steps really launched buckets from the hooks
             assert res[0][step]['buckets'] >= 2 and res[0][step]['during_backward'] >= 1
+
+
+def _unarmed_worker(rank, world, port, result_dir):
+    from hotformerloc_amd.training import OverlappedGradReducer
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        x, _, _ = _toy_data(8)
+        lo, hi = shard_bounds(8, rank, world)
+        model = _ToyEncoder()
+        reducer = OverlappedGradReducer(model.parameters(), bucket_bytes=64)
+        out = []
+        for step in range(3):
+            model.zero_grad(set_to_none=True)
+            y = model({'x': x[lo:hi]})['global'].sum()
+            if step >= 1 and rank == 0:
+                reducer.arm()                          # rank 1 never arms: it must still issue the same bucket sequence
+            y.backward()
+            reducer.finish()
+            out.append([p.grad.clone() for p in model.parameters()])
+        if rank == 0:                                  # an exception in the backward: no stale state in the next step
+            reducer.arm()
+            reducer.reset()
+            assert not reducer.armed and reducer._works == []
+        reducer.close()
+        torch.save(out, os.path.join(result_dir, 'ua_%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_reducer_same_collectives_when_a_rank_never_arms(tmp_path):
+    """A rank that does not call arm() in a step (no local minibatch) sends every bucket from finish(), in the same order
+    as the ranks that launched from their hooks: no mismatched collectives, same sums."""
+    mp.spawn(_unarmed_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'ua_0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'ua_1.pt'))
+    x, _, _ = _toy_data(8)
+    ref = _ToyEncoder()
+    ref({'x': x})['global'].sum().backward()
+    for step in range(3):
+        for g0, g1, p in zip(r0[step], r1[step], ref.parameters()):
+            assert torch.equal(g0, g1) and torch.allclose(g0, p.grad, atol=1e-6)
 
 
 def test_bench_rank_slices_concatenate_to_the_global_batch():

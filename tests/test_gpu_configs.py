@@ -167,3 +167,39 @@ def test_rccl_multistaged_step_equals_no_group_step(rccl_world1):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(a.abs().max().item(), 1e-30)), k
         else:
             assert torch.equal(a, b), (k, (a - b).abs().max().item())
+
+
+def test_rccl_overlapped_reducer_equals_plain_reduction(rccl_world1):
+    """`OverlappedGradReducer` on the RCCL path (world size 1, forced): at world size 1 the all-reduced gradient is the
+    local one, so after `finish()` every `p.grad` must equal the gradient of the same backward without a reducer -- bit for
+    bit, and consumed on the main stream right away.  Buckets leave from the hooks while the backward is still queued
+    on the main stream, and the copy-back runs on the reducer's side stream: a copy-back that is not ordered behind the
+    collective's own stream (ProcessGroupNCCL's `work.wait()` only orders the *current* stream) shows up here as stale
+    or partial gradients.  Large parameters and many steps so that the collective is really in flight."""
+    from hotformerloc_amd.training import OverlappedGradReducer
+    torch.manual_seed(0)
+    layers = []
+    for _ in range(12):
+        layers += [torch.nn.Linear(1024, 1024), torch.nn.GELU()]
+    net = torch.nn.Sequential(*layers).cuda()
+    x = torch.randn(4096, 1024, device='cuda')
+    reducer = OverlappedGradReducer(net.parameters(), group=rccl_world1, bucket_bytes=8 << 20, force=True)
+    try:
+        for step in range(6):
+            scale = float(step + 1)
+            net.zero_grad(set_to_none=True)
+            (net(x).square().mean() * scale).backward()
+            want = [p.grad.clone() for p in net.parameters()]
+            net.zero_grad(set_to_none=True)
+            y = net(x).square().mean() * scale
+            reducer.arm()
+            y.backward()
+            reducer.finish()
+            got = [p.grad + 0 for p in net.parameters()]          # consumed on the main stream, no host sync in between
+            torch.cuda.synchronize()
+            for g, w in zip(got, want):
+                assert torch.equal(g, w), (step, (g - w).abs().max().item())
+            if step >= 1:
+                assert len(reducer.buckets) >= 4 and reducer.launched_during_backward >= 1
+    finally:
+        reducer.close()
