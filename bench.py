@@ -86,6 +86,14 @@ def parse():
     ap.add_argument('--no-collective', action='store_true', help='A/B: skip the descriptor all-gather (N > 1 diagnostics)')
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no other legs)')
     ap.add_argument('--no-train-leg', action='store_true', help='skip the config-3 child process')
+    ap.add_argument('--no-oxford-leg', action='store_true', help="skip the config-5 per-rank workload's child process")
+    ap.add_argument('--no-pinned-leg', action='store_true', help='skip the host-contention child process')
+    ap.add_argument('--dry-launch', action='store_true',
+                    help='--gpus N without a launcher: print the child command this process would start, and exit')
+    ap.add_argument('--pin-cores', type=int, default=0,
+                    help='restrict this process to the first N logical CPUs before anything else runs (what one of 8 ranks '
+                         'sharing a host gets) and report host issue time per step in `host_issue`')
+    ap.add_argument('--master-port', type=int, default=None, help='self-launch: rendezvous port (default: a free one)')
     ap.add_argument('--train-leg-steps', type=int, default=5)
     ap.add_argument('--train-leg-warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -153,25 +161,62 @@ def parity_record(got, want):
 def train_leg(args):
     """BASELINE config 3 (CS-Wild-Places cfg, B = 64, 4096..32768 points per cloud, forward + backward) timed by this same
     script in a CHILD process (its own hipBLASLt schedule, its own allocator), same warm-up / step / barrier protocol."""
-    cmd = [sys.executable, os.path.abspath(__file__), '--config', 'cs-wild-places', '--train', '--no-extras',
-           '--no-cpu-baseline', '--steps', str(args.train_leg_steps), '--warmup', str(args.train_leg_warmup)]
+    saved = os.environ.pop('TENSILE_STREAMK_DATA_PARALLEL', None)
+    try:
+        return child_leg(['--config', 'cs-wild-places', '--train', '--steps', str(args.train_leg_steps), '--warmup',
+                          str(args.train_leg_warmup)],
+                         'child process: python bench.py --config cs-wild-places --train (BASELINE config 3)',
+                         keys=('peak_memory_GiB',))
+    finally:
+        if saved is not None:
+            os.environ['TENSILE_STREAMK_DATA_PARALLEL'] = saved
+
+
+def child_leg(extra, what, timeout=900, keys=()):
+    """One more workload timed by this same script in a CHILD process (same warm-up / step / barrier protocol)."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--no-extras', '--no-cpu-baseline'] + extra
     env = dict(os.environ)
-    env.pop('TENSILE_STREAMK_DATA_PARALLEL', None)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     t0 = time.perf_counter()
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     except subprocess.TimeoutExpired:
         return {'error': 'timeout'}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     if r.returncode != 0 or not lines:
         return {'error': 'rc %d' % r.returncode, 'stderr_tail': r.stderr[-400:]}
     j = json.loads(lines[-1])
-    return {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'],
-            'warmup': j['warmup'], 'workload': j['config']['workload'], 'dtype': j['dtype'],
-            'peak_memory_GiB': j.get('peak_memory_GiB'), 'wall_s': round(time.perf_counter() - t0, 1),
-            'what': 'child process: python bench.py --config cs-wild-places --train (BASELINE config 3)'}
+    out = {'value': j['value'], 'unit': j['unit'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'],
+           'warmup': j['warmup'], 'workload': j['config']['workload'], 'dtype': j['dtype'],
+           'wall_s': round(time.perf_counter() - t0, 1), 'what': what}
+    for k in keys:
+        if k in j:
+            out[k] = j[k]
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N fresh ranks with torch.distributed.run as a CHILD
+    process and relay rank 0's JSON line and the children's exit code.  This parent never touches the GPU (no HIP call, no
+    torch import) and never exec()s; the under-torchrun path below is what the children run."""
+    import socket
+    port = args.master_port
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != '--dry-launch']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    if args.dry_launch:
+        print(json.dumps({'launch': cmd}), flush=True)
+        return 0
+    log('no RANK in the environment: launching %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run(cmd, env=env)                       # stdout / stderr inherited: rank 0's line goes straight out
+    return r.returncode
 
 
 _T0 = time.perf_counter()
@@ -181,8 +226,29 @@ def log(*a):
     print('[bench %.1fs]' % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
 
 
+def rank_report(dist, elapsed, steps, device):
+    """Per-rank ms/step (all-gathered, in rank order) and the MAX over ranks of the timed region's seconds."""
+    import torch
+    world = dist.get_world_size()
+    tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    allt = [torch.zeros_like(tt) for _ in range(world)]
+    dist.all_gather(allt, tt)
+    per_rank = [round(float(x.item()) / steps * 1e3, 3) for x in allt]
+    t = tt.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return per_rank, float(t.item())
+
+
 def main():
     args = parse()
+    if args.pin_cores > 0 and hasattr(os, 'sched_setaffinity'):
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:args.pin_cores]))
+        os.environ['OMP_NUM_THREADS'] = str(args.pin_cores)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_launch:
+        print(json.dumps({'launch': None, 'note': 'nothing to launch: --gpus 1, or already under a launcher'}), flush=True)
+        return
     import torch
     import torch.distributed as dist
     from hotformerloc_amd import build_batch_octree, load_config, model_factory, ops
@@ -201,9 +267,12 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d'
-                         % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    n_dev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    if n_dev < world or local_rank >= n_dev:
+        raise SystemExit('bench.py rank %d: need %d GPUs on this node (one rank per GPU), found %d'
+                         % (rank, world, n_dev))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or 'RANK' in os.environ        # under torchrun the RCCL path runs even at N=1
@@ -293,6 +362,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             y = fn()
+        t_issued = time.perf_counter() - t0           # the host has queued everything; the GPU may still be running
         if use_dist:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
@@ -300,6 +370,7 @@ def main():
         assert torch.isfinite(y).all()
         if tag is not None:
             last[tag] = y.detach().float().cpu().numpy()
+            last[tag + '_issue_s'] = t_issued
         return dt
 
     def leg(dt):
@@ -382,10 +453,7 @@ def main():
     per_rank = None
     allgather_ms = None
     if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        allt = [torch.zeros_like(tt) for _ in range(world)]
-        dist.all_gather(allt, tt)
-        per_rank = [round(float(x.item()) / args.steps * 1e3, 3) for x in allt]
+        per_rank, elapsed_max = rank_report(dist, elapsed, args.steps, dev)
         if collective:
             y = torch.zeros((args.batch, params.output_dim), device=dev)
             for _ in range(3):
@@ -397,10 +465,8 @@ def main():
                 all_gather_descriptors(y, args.batch * world, force=True)
             torch.cuda.synchronize()
             allgather_ms = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = elapsed_max
 
     if rank == 0:
         total_clouds = args.batch * world * args.steps
@@ -459,10 +525,35 @@ def main():
             line['kernels'] = others
         if args.train:
             line['peak_memory_GiB'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+        # host side of the timed region: seconds until the last launch of the K steps was queued (no synchronisation
+        # inside the region), next to the region's wall time.  issue ~ wall means the host is the bound.
+        line['host_issue'] = {'ms_per_step_issue': round(last['value_issue_s'] / args.steps * 1e3, 3),
+                              'ms_per_step_wall': line['ms_per_step'],
+                              'logical_cpus_allowed': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None,
+                              'logical_cpus_host': os.cpu_count()}
         if extras and not args.no_train_leg and args.config == 'wild-places':
             log('config-3 training leg (child process) ...')
             line['train_cs'] = train_leg(args)
             log('train leg:', line['train_cs'])
+        if extras and not args.no_oxford_leg and args.config == 'wild-places':
+            log('config-5 per-rank workload (Oxford cfg, B = 64, depth 9; child process) ...')
+            line['oxford'] = child_leg(['--config', 'oxford', '--batch', '64', '--steps', str(args.steps), '--warmup',
+                                        str(args.warmup)],
+                                       'child process: python bench.py --config oxford --batch 64 (BASELINE config 5: the '
+                                       'per-rank workload of batch 512 on 8 GPUs; reference cfg config/config_oxford.txt:21)',
+                                       keys=('host_issue',))
+            log('oxford leg:', line['oxford'])
+        if extras and not args.no_pinned_leg and args.config == 'wild-places':
+            # eight ranks share one host at N = 8: the headline workload again with this process restricted to 1/8 of
+            # the host's logical CPUs (8 concurrent issuing processes cannot be run on a 1-GPU box)
+            pin = max(1, (os.cpu_count() or 8) // 8)
+            log('host-contention leg (pinned to %d logical CPUs; child process) ...' % pin)
+            line['pinned_host'] = child_leg(['--pin-cores', str(pin), '--steps', str(args.steps), '--warmup', str(args.warmup),
+                                             '--gemm', args.gemm],
+                                            'child process: the headline step with the process pinned to %d of the host\'s %d '
+                                            'logical CPUs (1/8: the share of one of 8 ranks)' % (pin, os.cpu_count() or 0),
+                                            keys=('host_issue',))
+            log('pinned leg:', line['pinned_host'])
         if world == 1 and not args.no_cpu_baseline and not args.train:
             line['cpu_baseline'], want = cpu_baseline(params, depth, args)
             line['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)

@@ -23,6 +23,7 @@
 #include "x3_math.h"
 
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include <type_traits>
 
@@ -1226,6 +1227,12 @@ struct AttnTimingRec {
 };
 static int g_attn_timing = 0;
 static std::vector<AttnTimingRec> g_attn_recs;
+static std::mutex g_attn_mu;                     // launches may come from autograd / side-stream host threads
+static void attn_rec_drop(AttnTimingRec& r) {
+  if (r.e0) (void)hipEventDestroy(r.e0);
+  if (r.e1) (void)hipEventDestroy(r.e1);
+  r.e0 = r.e1 = nullptr;
+}
 
 template <int T, int G>
 static int launch_window_v5(const WinParams* ps, int n, hipStream_t s) {
@@ -1304,17 +1311,39 @@ static int launch_window_v5(const WinParams* ps, int n, hipStream_t s) {
       rec.bytes += rows * ps[i].H * 16 * 16.0;
       rec.flops += 4.0 * (ps[i].K + G) * (ps[i].K + G) * ps[i].H * 16 * real_windows;
     }
-    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return HFL_EINVAL;
+    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) {
+      attn_rec_drop(rec);
+      return HFL_EINVAL;
+    }
     e = hipEventRecord(rec.e0, s);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) {
+      attn_rec_drop(rec);
+      return (int)e;
+    }
+  }
+  const bool timed = rec.e0 != nullptr;
+#define HFL_V5_FAIL_IF(cond)    \
+  if (cond) {                   \
+    if (timed) attn_rec_drop(rec); \
+    return (int)e;              \
+  }
+#undef HFL_V5_LAUNCH
+#define HFL_V5_LAUNCH(F)                                                                                  \
+  {                                                                                                       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel_v5<T, G, F>),                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);                    \
+    HFL_V5_FAIL_IF(e != hipSuccess)                                                                       \
+    window_attn_kernel_v5<T, G, F><<<grid5, hp0 * 64, lds_max, s>>>(m);                                   \
   }
   if (form0 == 0) HFL_V5_LAUNCH(0) else if (form0 == 1) HFL_V5_LAUNCH(1) else HFL_V5_LAUNCH(2)
 #undef HFL_V5_LAUNCH
-  if (g_attn_timing) {
+  if (timed) {
     e = hipEventRecord(rec.e1, s);
-    if (e != hipSuccess) return (int)e;
+    HFL_V5_FAIL_IF(e != hipSuccess)
+    std::lock_guard<std::mutex> lk(g_attn_mu);
     g_attn_recs.push_back(rec);
   }
+#undef HFL_V5_FAIL_IF
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -1461,16 +1490,15 @@ void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
 int hfl_internal_attn_timing(int on) {
-  for (auto& r : g_attn_recs) {
-    (void)hipEventDestroy(r.e0);
-    (void)hipEventDestroy(r.e1);
-  }
+  std::lock_guard<std::mutex> lk(g_attn_mu);
+  for (auto& r : g_attn_recs) attn_rec_drop(r);
   g_attn_recs.clear();
   g_attn_timing = on ? 1 : 0;
   return HFL_OK;
 }
 // ... and read it: per recorded launch the duration (ms), algorithmic bytes and FLOP; returns the number of launches recorded
 int hfl_internal_attn_timing_read(double* ms, double* bytes, double* flops, int cap) {
+  std::lock_guard<std::mutex> lk(g_attn_mu);
   int n = 0;
   for (auto& r : g_attn_recs) {
     if (n >= cap) break;

@@ -293,6 +293,32 @@ def _use_checkpoint(stage) -> bool:
     return bool(stage.grad_checkpoint) and stage.training and torch.is_grad_enabled()
 
 
+def _checkpoint_block(blk, *args):
+    """`checkpoint(blk, *args, use_reentrant=False)` with the block's stochastic-depth factors captured in the closure: the
+    recomputation in the backward must see the draws of ITS forward, also when another forward has re-armed the model in
+    between (forward A, forward B, backward A).  The reference's checkpoint gets this from the preserved RNG state
+    (octformer_backbone.py:415-416); here the draws are tensors handed out by `arm_drop_paths`."""
+    mods = blk.__dict__.get('_drop_path_mods')
+    if mods is None:
+        mods = blk.__dict__['_drop_path_mods'] = [m for m in blk.modules() if isinstance(m, OctreeDropPath)]
+    snap = [(m, m._factors) for m in mods]
+
+    def run(*a):
+        for m, f in snap:
+            m._factors, m._calls = f, 0
+        return blk(*a)
+    return checkpoint(run, *args, use_reentrant=False)
+
+
+def disarm_drop_paths(model: nn.Module):
+    """End of a model forward: the pooled draws belong to that forward only.  A submodule called on its own afterwards
+    (backbone alone, tests) draws fresh factors instead of silently reusing the last forward's."""
+    cache = model.__dict__.get('_drop_path_cache')
+    if cache is not None:
+        for m in cache['mods']:
+            m._factors = None
+
+
 def _require_layernorm(conv_norm: str):
     if conv_norm.lower() != 'layernorm':
         raise NotImplementedError("conv_norm=%r: every shipped config uses 'layernorm'" % conv_norm)
@@ -845,7 +871,7 @@ class OctFormerStage(nn.Module):
         ckpt = _use_checkpoint(self)
         for blk in self.blocks:
             # activation checkpointing per block, non-reentrant, as octformer_backbone.py:415-416
-            x = checkpoint(blk, x, plan, depth, use_reentrant=False) if ckpt else blk(x, plan, depth)
+            x = _checkpoint_block(blk, x, plan, depth) if ckpt else blk(x, plan, depth)
         return x
 
 
@@ -1102,7 +1128,7 @@ class HOTFormerStage(nn.Module):
         for i in range(self.num_blocks):
             for j, d in enumerate(depths):
                 blk = self.hosa_blocks[j][i]
-                feats[d] = checkpoint(blk, feats[d], plan, d, use_reentrant=False) if ckpt else blk(feats[d], plan, d)
+                feats[d] = _checkpoint_block(blk, feats[d], plan, d) if ckpt else blk(feats[d], plan, d)
         return feats, {d: None for d in depths}
 
     def forward(self, data, plan: WindowPlan, depth: int):
@@ -1132,7 +1158,7 @@ class HOTFormerStage(nn.Module):
             """down-projection -> H-OSA block -> up-projection of one level (610-630); returns (buffer, relay rows for RTSA)"""
             blk = self.hosa_blocks[j][i]
             rin = self.down_projections[j][i](fresh_d) if proj else fresh_d
-            out = checkpoint(blk, buf, plan, d, rin, use_reentrant=False) if ckpt else blk(buf, plan, d, rin)
+            out = _checkpoint_block(blk, buf, plan, d, rin) if ckpt else blk(buf, plan, d, rin)
             nt = plan.n_tokens[d]
             return out, (self.up_projections[j][i](out[nt:]) if proj else out[nt:])
 
@@ -1217,7 +1243,7 @@ class HOTFormerStage(nn.Module):
                 continue
             rt_all = torch.cat([rts[d] for d in depths], 0)
             if ckpt:                                                    # 596-601
-                rt_all = checkpoint(self.rtsa_blocks[i], rt_all, plan, use_reentrant=False)
+                rt_all = _checkpoint_block(self.rtsa_blocks[i], rt_all, plan)
             else:
                 rt_all = self.rtsa_blocks[i](rt_all, plan)
             fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
@@ -1604,9 +1630,14 @@ class HOTFormerLoc(nn.Module):
                                'call to_device(batch, "cuda") first -- there is no CPU path')
         octree.construct_all_neigh()                     # no-op when misc/torch_utils.to_device did it
         data = octree.get_input_feature(self.input_features, nempty=True)
-        if self.training and _DROP_POOL:
+        armed = self.training and _DROP_POOL
+        if armed:
             arm_drop_paths(self, int(octree.batch_size), data.device, data.dtype)
-        local, relay, plan = self.backbone(data, octree, octree.depth)
+        try:
+            local, relay, plan = self.backbone(data, octree, octree.depth)
+        finally:
+            if armed:
+                disarm_drop_paths(self)
         if self.pooling.pooled_feats == 'local':
             x = local
         elif self.pooling.pooled_feats == 'relaytokens':

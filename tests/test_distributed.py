@@ -319,3 +319,79 @@ def test_bench_rank_slices_concatenate_to_the_global_batch():
         assert len(flat) == len(whole) == 6
         for a, b in zip(flat, whole):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- bench.py launcher + per-rank reporting (round 4)
+_BENCH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+
+
+def _bench_env():
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` with no RANK in the environment starts its own ranks: the child command is the driver's
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    ...`), the user's flags are passed through, and --gpus 1 launches nothing."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, _BENCH, '--gpus', '4', '--steps', '3', '--warmup', '1', '--dry-launch'],
+                       capture_output=True, text=True, env=_bench_env(), timeout=120)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])['launch']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert int(cmd[cmd.index('--master-port') + 1]) > 0
+    tail = cmd[cmd.index(_BENCH) + 1:]
+    assert tail == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    r = subprocess.run([sys.executable, _BENCH, '--dry-launch'], capture_output=True, text=True, env=_bench_env(), timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])['launch'] is None
+
+
+def test_bench_self_launch_reports_missing_gpus_from_the_children():
+    """On a box with fewer GPUs than ranks the CHILDREN say so ("need N GPUs") and the parent relays their non-zero exit
+    code -- no usage error from the parent, no hang."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('this box has the GPUs')
+    r = subprocess.run([sys.executable, _BENCH, '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=_bench_env(), timeout=600)
+    assert r.returncode != 0
+    assert 'need 2 GPUs on this node' in r.stderr, r.stderr[-800:]
+
+
+def _rank_report_worker(rank, world, port, result_dir):
+    import importlib.util
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location('bench_mod', _BENCH)
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        from hotformerloc_amd.distributed import all_gather_descriptors
+        # stub step: this rank's "descriptors" + the bench's collective, then the bench's own reporting code
+        local = torch.full((3, 4), float(rank))
+        g = all_gather_descriptors(local, 3 * world, force=True)
+        per_rank, worst = bench.rank_report(dist, 0.010 * (rank + 1), 5, torch.device('cpu'))
+        torch.save({'per_rank': per_rank, 'worst': worst, 'gathered': g}, os.path.join(result_dir, 'rr_%d.pt' % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_rank_report_is_max_over_ranks(tmp_path):
+    """bench.py's N > 1 reporting (per-rank ms/step in rank order, MAX over ranks as the timed region) under gloo, world 2,
+    with a stub step that runs the bench's descriptor all-gather."""
+    mp.spawn(_rank_report_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(os.path.join(tmp_path, 'rr_%d.pt' % r))
+        assert got['per_rank'] == [2.0, 4.0]
+        assert abs(got['worst'] - 0.020) < 1e-12
+        assert torch.equal(got['gathered'], torch.tensor([0.0, 0, 0, 1, 1, 1])[:, None].expand(6, 4))
