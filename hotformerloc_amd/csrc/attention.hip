@@ -1488,6 +1488,8 @@ extern "C" void hfl_internal_set_cpe_chunk(int rows);
 void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
+void hfl_internal_set_mlp_ring_pf(int v);
+void hfl_internal_set_qkv_ring_pf(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
 int hfl_internal_attn_timing(int on) {
   std::lock_guard<std::mutex> lk(g_attn_mu);
@@ -1536,6 +1538,11 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_x3_dbg(0x100);
     hfl_internal_set_cpe_chunk(0);
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
+    hfl_internal_set_mlp_ring_pf(3);
+    hfl_internal_set_qkv_ring_pf(3);
+  } else if (is("ring_pf")) {
+    hfl_internal_set_mlp_ring_pf(value);
+    hfl_internal_set_qkv_ring_pf(value);
   } else if (is("mlp_stagger")) {
     hfl_internal_set_mlp_stagger(value);
   } else if (is("window_attention")) {

@@ -57,10 +57,12 @@ struct MlpFusedParams {
 
 static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
 static int g_mlp_stagger_groups = 8;
+static int g_mlp_ring_pf = 3;      // probe knob 'ring_pf': stages of the weight stream in flight ahead of the consumed one (2 | 3)
 
-template <int C, int NT>
+template <int C, int NT, int PF>
 __global__ void __launch_bounds__(512, 2)
 ln_mlp_fused_kernel(const MlpFusedParams p) {
+  static_assert(PF == 2 || PF == 3, "stages in flight ahead of the one being consumed");
   constexpr int KS = C / 32;               // k-steps of GEMM1
   constexpr int FT = C / 16;               // 16-feature tiles of the output
   constexpr int NCH = C / 8;               // chunks of 32 hidden features (hidden = 4 C)
@@ -115,11 +117,13 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   int dma_n = 0;                            // stage whose pieces the current stage body issues (NST: none)
   uint32_t dma_slot = 0;
   auto acquire = [&](int n) -> const unsigned char* {
-    if (n + 1 < NST) HFL_WAIT_VM(DPW);
+    // stages issued after stage n so far: n + 1 .. n + PF - 1 (those that exist); this wave's pieces of them may stay in flight
+    if (n + PF - 1 < NST) HFL_WAIT_VM((PF - 1) * DPW);
+    else if (n + 1 < NST) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
     else HFL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
-    dma_n = n + 2;
-    dma_slot = (seq + 2) % NSLOT;
+    dma_n = n + PF;
+    dma_slot = (seq + PF) % NSLOT;
     const unsigned char* st = smem + (seq % NSLOT) * STAGE_B;
     ++seq;
     return st;
@@ -205,6 +209,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     __builtin_amdgcn_s_barrier();
     issue(0, seq % NSLOT);
     issue(1, (seq + 1) % NSLOT);
+    if (PF == 3) issue(2, (seq + 2) % NSLOT);
 
     f32x4 oacc[FT][NT];
 #pragma unroll
@@ -423,6 +428,8 @@ static int grid_guess(int n_tiles) {
 
 extern "C" {
 
+void hfl_internal_set_mlp_ring_pf(int v) { g_mlp_ring_pf = v == 2 ? 2 : 3; }
+
 void hfl_internal_set_mlp_stagger(int v) {
   g_mlp_stagger = v & 0xFF;
   g_mlp_stagger_groups = (v >> 8) > 0 ? (v >> 8) : 2;
@@ -461,14 +468,18 @@ int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float
   const int grid = p.n_tiles < cus ? p.n_tiles : cus;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
-#define HFL_MLP_LAUNCH(CC, NT)                                                                                  \
+#define HFL_MLP_LAUNCH(CC, NT, PF)                                                                              \
   {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT>),              \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT, PF>),          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     if (e != hipSuccess) return (int)e;                                                                         \
-    ln_mlp_fused_kernel<CC, NT><<<grid, 512, lds, s>>>(p);                                                      \
+    ln_mlp_fused_kernel<CC, NT, PF><<<grid, 512, lds, s>>>(p);                                                  \
   }
-  if (channels == 256) HFL_MLP_LAUNCH(256, 1) else HFL_MLP_LAUNCH(128, 2)
+  if (g_mlp_ring_pf == 3) {
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3) else HFL_MLP_LAUNCH(128, 2, 3)
+  } else {
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2) else HFL_MLP_LAUNCH(128, 2, 2)
+  }
 #undef HFL_MLP_LAUNCH
   HFL_RETURN_LAST_ERROR();
 }

@@ -56,9 +56,10 @@ constexpr int qkv_staging_blocks(int C, int NT, int W) {
   return nb;
 }
 
-template <int C, int NT, int W>
+template <int C, int NT, int W, int PF>
 __global__ void __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(W / 4, W / 4)))
 ln_qkv_fused_kernel(const QkvFusedParams p) {
+  static_assert(PF == 2 || PF == 3, "stages in flight ahead of the one being consumed (csrc/mlp_fused.hip)");
   constexpr int KS = C / 32;               // k-steps
   constexpr int NST = 3 * C / 32;          // stages per pass: 32 output features each
   constexpr int SPR = C / 32;              // stages per region (Q, K, V)
@@ -112,11 +113,12 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
   int dma_n = 0;
   uint32_t dma_slot = 0;
   auto acquire = [&](int n) -> const unsigned char* {
-    if (n + 1 < NST) HFL_WAIT_VM(DPW);
+    if (n + PF - 1 < NST) HFL_WAIT_VM((PF - 1) * DPW);
+    else if (n + 1 < NST) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
     else HFL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
-    dma_n = n + 2;
-    dma_slot = (seq + 2) % NSLOT;
+    dma_n = n + PF;
+    dma_slot = (seq + PF) % NSLOT;
     const unsigned char* st = smem + (seq % NSLOT) * STAGE_B;
     ++seq;
     return st;
@@ -197,6 +199,7 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
     __builtin_amdgcn_s_barrier();
     issue(0, seq % NSLOT);
     issue(1, (seq + 1) % NSLOT);
+    if (PF == 3) issue(2, (seq + 2) % NSLOT);
 
     // The epilogue of the PREVIOUS stage rides between the k-steps of the current one; the fragment waits of the k-loop
     // (`s_waitcnt lgkmcnt(0)` after every k-step and at the start of a half) are what its own LDS round trips wait on, so it
@@ -370,7 +373,11 @@ qkv_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w, i
 
 }  // namespace
 
+static int g_qkv_ring_pf = 3;
+
 extern "C" {
+
+void hfl_internal_set_qkv_ring_pf(int v) { g_qkv_ring_pf = v == 2 ? 2 : 3; }
 
 int64_t hfl_qkv_fused_pack_bytes(int channels) {
   if (channels != 128 && channels != 256) return 0;
@@ -405,14 +412,18 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   p.stagger_groups = 8;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 20 + (size_t)waves * qkv_staging_blocks(channels, nt, waves) * 2048;
-#define HFL_QKV_LAUNCH(CC, NT, WW)                                                                              \
+#define HFL_QKV_LAUNCH(CC, NT, WW, PF)                                                                          \
   {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_qkv_fused_kernel<CC, NT, WW>),          \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_qkv_fused_kernel<CC, NT, WW, PF>),      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     if (e != hipSuccess) return (int)e;                                                                         \
-    ln_qkv_fused_kernel<CC, NT, WW><<<grid, WW * 64, lds, s>>>(p);                                              \
+    ln_qkv_fused_kernel<CC, NT, WW, PF><<<grid, WW * 64, lds, s>>>(p);                                          \
   }
-  if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8) else HFL_QKV_LAUNCH(128, 2, 8)
+  if (g_qkv_ring_pf == 3) {
+    if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 3) else HFL_QKV_LAUNCH(128, 2, 8, 3)
+  } else {
+    if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 2) else HFL_QKV_LAUNCH(128, 2, 8, 2)
+  }
 #undef HFL_QKV_LAUNCH
   HFL_RETURN_LAST_ERROR();
 }
