@@ -155,6 +155,9 @@ SIGNATURES = {
     'hfl_mlp_fused_pack': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'hfl_ln_mlp_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                          c_void_p]),
+    'hfl_ln_mlp_fused_workspace': (c_int64, [c_int64, c_int]),
+    'hfl_ln_mlp_fused_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                            c_void_p, c_int64, c_void_p]),
     'hfl_qkv_fused_pack_bytes': (c_int64, [c_int]),
     'hfl_qkv_fused_pack': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'hfl_ln_qkv_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int64, c_int,

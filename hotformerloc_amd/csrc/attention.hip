@@ -1490,6 +1490,8 @@ void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
 void hfl_internal_set_mlp_ring_pf(int v);
 void hfl_internal_set_qkv_ring_pf(int v);
+void hfl_internal_set_mlp_tail_split(int v);
+void hfl_internal_set_qkv_tail_split(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
 int hfl_internal_attn_timing(int on) {
   std::lock_guard<std::mutex> lk(g_attn_mu);
@@ -1540,6 +1542,11 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
     hfl_internal_set_mlp_ring_pf(3);
     hfl_internal_set_qkv_ring_pf(3);
+    hfl_internal_set_mlp_tail_split(1);
+    hfl_internal_set_qkv_tail_split(1);
+  } else if (is("tail_split")) {
+    hfl_internal_set_mlp_tail_split(value);
+    hfl_internal_set_qkv_tail_split(value);
   } else if (is("ring_pf")) {
     hfl_internal_set_mlp_ring_pf(value);
     hfl_internal_set_qkv_ring_pf(value);

@@ -73,8 +73,10 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
-    return hfl_ln_mlp_fused(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
-                            stream);
+    // (the arena's h2 | g2 region, 5 units, is free on this path: workspace of the left-over rows' partial sums, at most
+    // 32768 rows x C x 4 B -- hfl_ln_mlp_fused_ws falls back to whole passes when it does not fit)
+    return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
+                               h2, (int64_t)(5 * unit), stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);

@@ -53,6 +53,15 @@ struct MlpFusedParams {
   int n_tiles;                // ceil(M / 16)
   int stagger;                // workgroup g starts (g % stagger_groups) * stagger naps of ~4000 cycles late (0: all together)
   int stagger_groups;
+  // Tail split (tail_sets > 0): every workgroup walks `full_passes` whole passes; the tiles left over (fewer than one pass
+  // per workgroup) are cut into `tail_sets` sets of up to one pass, and each set is computed by `tail_parts` workgroups that
+  // share the hidden dimension: part k runs chunks [k, k + 1) * NCH / tail_parts and writes its fc2 partial sums to
+  // part[k] (rows of the tail region x C, f32); mlp_tail_reduce_kernel adds them in fixed order (+ bias + residual).
+  int full_passes;
+  int tail_tile0;             // first tile of the tail region
+  int tail_sets;
+  int tail_parts;
+  float* part;                // (tail_parts, tail rows, C)
 };
 
 static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
@@ -84,9 +93,25 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
 
   // ---- this workgroup's share of the 16-row tiles
   const int G = gridDim.x, g = blockIdx.x;
-  const int base = p.n_tiles / G, extra = p.n_tiles % G;
-  int tile0 = g * base + (g < extra ? g : extra);
-  const int tile_end = tile0 + base + (g < extra ? 1 : 0);
+  int tile0, tile_end;
+  // tail work of this workgroup: set `tset` (tiles [tail_lo, tail_hi)), hidden chunks [tc0, tc0 + tnch)
+  int tail_lo = 0, tail_hi = 0, tc0 = 0, tnch = 0, tpart = 0;
+  if (p.tail_sets > 0) {
+    tile0 = g * p.full_passes * TPP;
+    tile_end = tile0 + p.full_passes * TPP;
+    if (g < p.tail_sets * p.tail_parts) {
+      const int tset = g % p.tail_sets;
+      tpart = g / p.tail_sets;
+      tail_lo = p.tail_tile0 + tset * TPP;
+      tail_hi = tail_lo + TPP < p.n_tiles ? tail_lo + TPP : p.n_tiles;
+      tnch = NCH / p.tail_parts;
+      tc0 = tpart * tnch;
+    }
+  } else {
+    const int base = p.n_tiles / G, extra = p.n_tiles % G;
+    tile0 = g * base + (g < extra ? g : extra);
+    tile_end = tile0 + base + (g < extra ? 1 : 0);
+  }
 
   // small vectors live in LDS for the whole kernel: read per use with ds_read (a global load per use would be a dependent
   // L2 round trip each -- the register file has no room to hold them)
@@ -101,8 +126,17 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   // ---- stage stream: stage n of a pass lives at pack + n * STAGE_B; wave w copies bytes [w, w+1) * DPW KiB of it
   const uint32_t lane_off = (uint32_t)lane * 16u;
   uint32_t seq = 0;                         // stages acquired so far (all passes): slot = seq % NSLOT
+  // A pass over the hidden chunks [c0, c0 + nch) (all of them except in the tail) consumes the stages A_c0, A_c0+1, B_c0, ...,
+  // A_last, B_last-1, B_last: in the pack's stage order (A0, A1, B0, A2, B1, ...) that is index 2 c0 - 1 (0 for c0 = 0), then
+  // 2 c0 + 1 ... 2 (c0 + nch) - 2 contiguously, then 2 (c0 + nch) (2 NCH - 1 for the last chunk of all).
+  int c0 = 0, nst = NST;                    // current pass: first chunk, stages
+  auto sidx = [&](int n) -> int {
+    if (n == 0) return c0 == 0 ? 0 : 2 * c0 - 1;
+    if (n == nst - 1) return 2 * c0 + nst == NST ? NST - 1 : 2 * c0 + nst;
+    return 2 * c0 + n;
+  };
   auto issue = [&](int n, uint32_t slot) {
-    const unsigned char* s = p.pack + (int64_t)n * STAGE_B + wave * (DPW * 1024);      // wave-uniform
+    const unsigned char* s = p.pack + (int64_t)sidx(n) * STAGE_B + wave * (DPW * 1024);      // wave-uniform
     unsigned char* d = smem + slot * STAGE_B + wave * (DPW * 1024);
 #pragma unroll
     for (int i = 0; i < DPW; ++i)
@@ -118,8 +152,8 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   uint32_t dma_slot = 0;
   auto acquire = [&](int n) -> const unsigned char* {
     // stages issued after stage n so far: n + 1 .. n + PF - 1 (those that exist); this wave's pieces of them may stay in flight
-    if (n + PF - 1 < NST) HFL_WAIT_VM((PF - 1) * DPW);
-    else if (n + 1 < NST) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
+    if (n + PF - 1 < nst) HFL_WAIT_VM((PF - 1) * DPW);
+    else if (n + 1 < nst) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
     else HFL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     dma_n = n + PF;
@@ -129,10 +163,10 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     return st;
   };
   auto dma_piece = [&](int i) {
-    if (dma_n < NST)
+    if (dma_n < nst)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(p.pack + (int64_t)dma_n * STAGE_B + wave * (DPW * 1024) + i * 1024 +
-                                                          lane_off),
+          (const __attribute__((address_space(1))) void*)(p.pack + (int64_t)sidx(dma_n) * STAGE_B + wave * (DPW * 1024) +
+                                                          i * 1024 + lane_off),
           (__attribute__((address_space(3))) void*)(smem + dma_slot * STAGE_B + wave * (DPW * 1024) + i * 1024), 16, 0, 0);
   };
   constexpr int PPH = DPW / 2;              // pieces per half stage
@@ -149,7 +183,17 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     const int naps = (int)(blockIdx.x % (unsigned)p.stagger_groups) * p.stagger;
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(63);          // ~4000 cycles each
   }
-  while (tile0 < tile_end) {
+  bool tail = false;
+  for (;;) {
+    if (tile0 >= tile_end) {
+      if (tail || tnch == 0) break;
+      tail = true;                          // the last pass: this workgroup's part of a tail set
+      tile0 = tail_lo;
+      tile_end = tail_hi;
+      c0 = tc0;
+      nst = 2 * tnch;
+    }
+    const int nch = nst / 2;                // hidden chunks of this pass (even)
     const int ntile = tile_end - tile0 < TPP ? tile_end - tile0 : TPP;    // tiles of this pass
     // ---- LayerNorm of this wave's rows -> B-operand fragments (lane: row fr of the tile, channels 32 ks + 8 fq + j)
     bf16x8 xh[NT][KS], xl[NT][KS];
@@ -209,7 +253,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     __builtin_amdgcn_s_barrier();
     issue(0, seq % NSLOT);
     issue(1, (seq + 1) % NSLOT);
-    if (PF == 3) issue(2, (seq + 2) % NSLOT);
+    if (PF == 3 && nst > 2) issue(2, (seq + 2) % NSLOT);
 
     f32x4 oacc[FT][NT];
 #pragma unroll
@@ -224,7 +268,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     auto gelu_pair = [&](int pidx, f32x4 (&hp)[2][NT], int chunk) {
       const int t = pidx >> 2, d = pidx & 3;
       const int i = d >> 1, r0 = 2 * (d & 1);
-      const float2 b = *reinterpret_cast<const float2*>(b1s + chunk * 32 + i * 16 + fq * 4 + r0);
+      const float2 b = *reinterpret_cast<const float2*>(b1s + (c0 + chunk) * 32 + i * 16 + fq * 4 + r0);
       // SCALAR f32 math on purpose (and -fno-slp-vectorize for this file): beside MFMAs a v_pk_*_f32 costs ~12 extra
       // cycles of the matrix pipe each (MI355X_MICROARCH.md, cycle constants), a plain VALU op hides in the MFMA's shadow
       const float g0 = x3_gelu(hp[i][t][r0] + b.x), g1 = x3_gelu(hp[i][t][r0 + 1] + b.y);
@@ -339,21 +383,34 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
       if (more) st = acquire(n++);
     };
     stage1(hA, hB, 0, false);                                             // A0
-    for (int j = 1; j < NCH; j += 2) {           // NCH is even: j odd here, j + 1 even
+#pragma unroll 1
+    for (int j = 1; j < nch; j += 2) {           // nch is even: j odd here, j + 1 even
       stage1(hB, hA, j - 1, true);                                        // A_j + gelu(j - 1)
       stage2(true);                                                       // B_{j-1}
-      if (j + 1 < NCH) {
+      if (j + 1 < nch) {
         stage1(hA, hB, j, true);                                          // A_{j+1} + gelu(j)
         stage2(true);                                                     // B_j
       }
     }
-    if (active) gelu_only(hB, NCH - 1);          // NCH - 1 is odd: its accumulators are hB
-    stage2(false);                                                        // B_{NCH-1}
+    if (active) gelu_only(hB, nch - 1);          // nch - 1 is odd: its accumulators are hB
+    stage2(false);                                                        // B_{nch-1}
 
     // ---- epilogue: out = acc + b2 + x (lane: row fr of the tile, features 16 i + 4 fq .. + 3)
     // (tell the compiler's wait-count pass what the inline-asm wait of the last stage did: nothing is in flight any more,
     // so the residual loads below get ordinary counted waits)
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+    if (tail) {                                  // partial sums of this part's chunks, no bias, no residual
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!have[t] || row[t] >= p.M) continue;
+        const int64_t tail_rows = p.M - (int64_t)p.tail_tile0 * 16;
+        float* orow = p.part + ((int64_t)tpart * tail_rows + (row[t] - (int64_t)p.tail_tile0 * 16)) * C + fq * 4;
+#pragma unroll
+        for (int i = 0; i < FT; ++i) *reinterpret_cast<f32x4*>(orow + i * 16) = oacc[i][t];
+      }
+      tile0 += ntile;
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (!have[t] || row[t] >= p.M) continue;
@@ -369,6 +426,25 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
       }
     }
     tile0 += ntile;
+  }
+}
+
+// out[r] = x[r] + b2 + sum_k part[k][r] over the tail rows, k in fixed order (bitwise reproducible); one float4 per lane
+__global__ void __launch_bounds__(256)
+mlp_tail_reduce_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ b2,
+                       const float* __restrict__ part, int64_t row0, int64_t tail_rows, int C, int parts) {
+  const int64_t n4 = tail_rows * C / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)((i * 4) % C);
+    float4 a = reinterpret_cast<const float4*>(x + row0 * C)[i];
+    const float4 b = *reinterpret_cast<const float4*>(b2 + col);
+    float4 sum = reinterpret_cast<const float4*>(part)[i];
+    for (int k = 1; k < parts; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(part + (int64_t)k * tail_rows * C)[i];
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    a.x = sum.x + b.x + a.x; a.y = sum.y + b.y + a.y; a.z = sum.z + b.z + a.z; a.w = sum.w + b.w + a.w;
+    reinterpret_cast<float4*>(out + row0 * C)[i] = a;
   }
 }
 
@@ -448,8 +524,51 @@ int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channel
   HFL_RETURN_LAST_ERROR();
 }
 
+// Tail plan of a launch over n_rows: {full passes per workgroup, first tail tile, sets, parts}; parts == 0: no tail split
+// (the rows are whole passes, or fewer than one round, or the split is switched off).
+struct MlpTailPlan {
+  int full, tile0, sets, parts;
+};
+static int g_mlp_tail_split = 1;   // probe knob 'mlp_tail_split'
+static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels) {
+  MlpTailPlan t{0, 0, 0, 0};
+  const int64_t n_tiles = hfl_cdiv(n_rows, 16);
+  const int cus = hfl_num_cus();
+  const int tpp = channels == 256 ? 8 : 16, nch = channels / 8;
+  if (!g_mlp_tail_split || n_tiles <= (int64_t)cus * tpp) return t;          // at most one round: nothing to balance
+  const int64_t full = n_tiles / ((int64_t)cus * tpp);
+  const int64_t rem = n_tiles - full * cus * tpp;
+  if (rem == 0) return t;
+  const int sets = (int)hfl_cdiv(rem, tpp);
+  int parts = 1;
+  while (parts * 2 <= cus / sets && nch / (parts * 2) >= 2) parts *= 2;      // parts | NCH, at least 2 chunks (an even count) each
+  if (parts < 2) return t;                                                   // a tail of more than half a round: plain passes
+  t.full = (int)full; t.tile0 = (int)(full * cus * tpp); t.sets = sets; t.parts = parts;
+  return t;
+}
+
+extern "C" void hfl_internal_set_mlp_tail_split(int v) { g_mlp_tail_split = v ? 1 : 0; }
+
+/* Workspace of hfl_ln_mlp_fused_ws for this shape (0: none needed). */
+extern "C" int64_t hfl_ln_mlp_fused_workspace(int64_t n_rows, int channels) {
+  if (n_rows <= 0 || (channels != 128 && channels != 256)) return 0;
+  const MlpTailPlan t = mlp_tail_plan(n_rows, channels);
+  if (t.parts == 0) return 0;
+  return (int64_t)t.parts * (n_rows - (int64_t)t.tile0 * 16) * channels * 4;
+}
+
+extern "C" int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                        const float* b1, const float* b2, int64_t n_rows, int channels, void* workspace,
+                        int64_t workspace_bytes, hfl_stream_t stream);
+
 int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* b1, const float* b2, int64_t n_rows, int channels, hfl_stream_t stream) {
+  return hfl_ln_mlp_fused_ws(out, x, gamma, beta, eps, pack, b1, b2, n_rows, channels, nullptr, 0, stream);
+}
+
+int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                        const float* b1, const float* b2, int64_t n_rows, int channels, void* workspace,
+                        int64_t workspace_bytes, hfl_stream_t stream) {
   if (out == nullptr || x == nullptr || gamma == nullptr || beta == nullptr || pack == nullptr || b1 == nullptr ||
       b2 == nullptr || n_rows < 0)
     return HFL_EINVAL;
@@ -466,6 +585,14 @@ int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float
   p.stagger_groups = g_mlp_stagger_groups;
   const int cus = hfl_num_cus();
   const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+  p.full_passes = 0; p.tail_tile0 = 0; p.tail_sets = 0; p.tail_parts = 0; p.part = nullptr;
+  MlpTailPlan tp = mlp_tail_plan(n_rows, channels);
+  if (tp.parts > 0 && workspace != nullptr && workspace_bytes >= hfl_ln_mlp_fused_workspace(n_rows, channels)) {
+    p.full_passes = tp.full; p.tail_tile0 = tp.tile0; p.tail_sets = tp.sets; p.tail_parts = tp.parts;
+    p.part = static_cast<float*>(workspace);
+  } else {
+    tp.parts = 0;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
 #define HFL_MLP_LAUNCH(CC, NT, PF)                                                                              \
@@ -481,6 +608,11 @@ int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float
     if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2) else HFL_MLP_LAUNCH(128, 2, 2)
   }
 #undef HFL_MLP_LAUNCH
+  if (tp.parts > 0) {
+    const int64_t row0 = (int64_t)tp.tile0 * 16, tail_rows = n_rows - row0;
+    const int64_t n4 = tail_rows * channels / 4;
+    mlp_tail_reduce_kernel<<<(unsigned)hfl_cdiv(n4, 256), 256, 0, s>>>(out, x, b2, p.part, row0, tail_rows, channels, tp.parts);
+  }
   HFL_RETURN_LAST_ERROR();
 }
 

@@ -39,6 +39,13 @@ struct QkvFusedParams {
   int n_tiles;                // ceil(M / 16)
   int stagger;
   int stagger_groups;
+  // Tail split (csrc/mlp_fused.hip): `full_passes` whole passes per workgroup; the tiles left over are cut into `tail_sets`
+  // sets of up to one pass, each computed by `tail_parts` workgroups that share the OUTPUT features: part k runs the stages
+  // [k, k + 1) * NST / tail_parts (32 features each) of its set -- no reduction, the parts write disjoint columns.
+  int full_passes;
+  int tail_tile0;
+  int tail_sets;
+  int tail_parts;
 };
 
 // LDS accesses of the epilogue as inline asm: while an LDS-DMA is in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every
@@ -84,9 +91,24 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
   unsigned char* stg = stg_all + wave * (NB * 2048);
 
   const int G = gridDim.x, g = blockIdx.x;
-  const int base = p.n_tiles / G, extra = p.n_tiles % G;
-  int tile0 = g * base + (g < extra ? g : extra);
-  const int tile_end = tile0 + base + (g < extra ? 1 : 0);
+  int tile0, tile_end;
+  int tail_lo = 0, tail_hi = 0, ts0 = 0, tnst = 0;       // tail work: tiles [tail_lo, tail_hi), stages [ts0, ts0 + tnst)
+  if (p.tail_sets > 0) {
+    tile0 = g * p.full_passes * TPP;
+    tile_end = tile0 + p.full_passes * TPP;
+    if (g < p.tail_sets * p.tail_parts) {
+      const int tset = g % p.tail_sets;
+      tail_lo = p.tail_tile0 + tset * TPP;
+      tail_hi = tail_lo + TPP < p.n_tiles ? tail_lo + TPP : p.n_tiles;
+      tnst = NST / p.tail_parts;
+      ts0 = (g / p.tail_sets) * tnst;
+    }
+  } else {
+    const int base = p.n_tiles / G, extra = p.n_tiles % G;
+    tile0 = g * base + (g < extra ? g : extra);
+    tile_end = tile0 + base + (g < extra ? 1 : 0);
+  }
+  int s0 = 0, nst = NST;                    // current pass: first stage of the pack, stages (even)
 
   for (int i = tid; i < 3 * C / 4; i += W * 64) reinterpret_cast<float4*>(bs)[i] = reinterpret_cast<const float4*>(p.bias)[i];
   for (int i = tid; i < C / 4; i += W * 64) {
@@ -98,7 +120,7 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
   const uint32_t lane_off = (uint32_t)lane * 16u;
   uint32_t seq = 0;                         // stages acquired so far (all passes): slot = seq % NSLOT
   auto issue = [&](int n, uint32_t slot) {
-    const unsigned char* s = p.pack + (int64_t)n * STAGE_B + wave * (DPW * 1024);
+    const unsigned char* s = p.pack + (int64_t)(s0 + n) * STAGE_B + wave * (DPW * 1024);
     unsigned char* d = smem + slot * STAGE_B + wave * (DPW * 1024);
 #pragma unroll
     for (int i = 0; i < DPW; ++i)
@@ -113,8 +135,8 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
   int dma_n = 0;
   uint32_t dma_slot = 0;
   auto acquire = [&](int n) -> const unsigned char* {
-    if (n + PF - 1 < NST) HFL_WAIT_VM((PF - 1) * DPW);
-    else if (n + 1 < NST) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
+    if (n + PF - 1 < nst) HFL_WAIT_VM((PF - 1) * DPW);
+    else if (n + 1 < nst) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
     else HFL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     dma_n = n + PF;
@@ -124,10 +146,10 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
     return st;
   };
   auto dma_piece = [&](int i) {
-    if (dma_n < NST)
+    if (dma_n < nst)
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(p.pack + (int64_t)dma_n * STAGE_B + wave * (DPW * 1024) + i * 1024 +
-                                                          lane_off),
+          (const __attribute__((address_space(1))) void*)(p.pack + (int64_t)(s0 + dma_n) * STAGE_B + wave * (DPW * 1024) +
+                                                          i * 1024 + lane_off),
           (__attribute__((address_space(3))) void*)(smem + dma_slot * STAGE_B + wave * (DPW * 1024) + i * 1024), 16, 0, 0);
   };
   // A fragment of a 16-row block of a stage: row = block * 16 + fr, hi chunk fq, lo chunk 4 + fq (slot t of row r at t ^ ((r >> 1) & 7))
@@ -142,7 +164,16 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
     const int naps = (int)(blockIdx.x % (unsigned)p.stagger_groups) * p.stagger;
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(63);
   }
-  while (tile0 < tile_end) {
+  bool tail = false;
+  for (;;) {
+    if (tile0 >= tile_end) {
+      if (tail || tnst == 0) break;
+      tail = true;                          // the last pass: this workgroup's columns of a tail set
+      tile0 = tail_lo;
+      tile_end = tail_hi;
+      s0 = ts0;
+      nst = tnst;
+    }
     const int ntile = tile_end - tile0 < TPP ? tile_end - tile0 : TPP;
     // ---- LayerNorm of this wave's rows -> B-operand fragments (lane: row fr of the tile, channels 32 ks + 8 fq + j)
     bf16x8 xh[NT][KS], xl[NT][KS];
@@ -199,7 +230,7 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
     __builtin_amdgcn_s_barrier();
     issue(0, seq % NSLOT);
     issue(1, (seq + 1) % NSLOT);
-    if (PF == 3) issue(2, (seq + 2) % NSLOT);
+    if (PF == 3 && nst > 2) issue(2, (seq + 2) % NSLOT);
 
     // The epilogue of the PREVIOUS stage rides between the k-steps of the current one; the fragment waits of the k-loop
     // (`s_waitcnt lgkmcnt(0)` after every k-step and at the start of a half) are what its own LDS round trips wait on, so it
@@ -322,22 +353,22 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
     };
     f32x4 hA[2][NT], hB[2][NT];                 // accumulators of two consecutive stages
     const unsigned char* st = acquire(0);
-    auto stage = [&](f32x4 (&h)[2][NT], f32x4 (&hp)[2][NT], int n) {
+    auto stage = [&](f32x4 (&h)[2][NT], f32x4 (&hp)[2][NT], int n) {       // n: stage of this pass; s0 + n: of the pack
       if (active) {
-        gemm_half(st, std::integral_constant<int, 0>{}, h, hp, n - 1, n > 0);
-        gemm_half(st, std::integral_constant<int, 1>{}, h, hp, n - 1, n > 0);
+        gemm_half(st, std::integral_constant<int, 0>{}, h, hp, s0 + n - 1, n > 0);
+        gemm_half(st, std::integral_constant<int, 1>{}, h, hp, s0 + n - 1, n > 0);
       } else {
         idle_pieces();
       }
-      if (n + 1 < NST) st = acquire(n + 1);
+      if (n + 1 < nst) st = acquire(n + 1);
     };
     static_assert(NST % 2 == 0, "stages come in pairs");
 #pragma unroll 1
-    for (int n = 0; n < NST; n += 2) {
+    for (int n = 0; n < nst; n += 2) {
       stage(hA, hB, n);
       stage(hB, hA, n + 1);
     }
-    if (active) epilogue(hB, NST - 1);
+    if (active) epilogue(hB, s0 + nst - 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);          // tell the compiler's wait-count pass: nothing in flight (vmcnt(0) was waited)
     tile0 += ntile;
   }
@@ -374,10 +405,12 @@ qkv_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w, i
 }  // namespace
 
 static int g_qkv_ring_pf = 3;
+static int g_qkv_tail_split = 1;    // probe knob 'qkv_tail_split'
 
 extern "C" {
 
 void hfl_internal_set_qkv_ring_pf(int v) { g_qkv_ring_pf = v == 2 ? 2 : 3; }
+void hfl_internal_set_qkv_tail_split(int v) { g_qkv_tail_split = v ? 1 : 0; }
 
 int64_t hfl_qkv_fused_pack_bytes(int channels) {
   if (channels != 128 && channels != 256) return 0;
@@ -410,6 +443,22 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
                                                              //  a stage takes 3-5 us: tools/qkv_fused_probe.py)
   p.stagger = p.n_tiles > (int64_t)grid * waves * nt ? 1 : 0;          // only when a workgroup walks several passes
   p.stagger_groups = 8;
+  p.full_passes = 0; p.tail_tile0 = 0; p.tail_sets = 0; p.tail_parts = 0;
+  {
+    // whole passes for everybody, then the left-over tiles with the output features split over the workgroups of a set
+    const int tpp = waves * nt, nst_all = 3 * channels / 32;
+    const int64_t full = p.n_tiles / ((int64_t)cus * tpp);
+    const int64_t rem = p.n_tiles - full * cus * tpp;
+    if (g_qkv_tail_split && full >= 1 && rem > 0) {
+      const int sets = (int)hfl_cdiv(rem, tpp);
+      int parts = 1;
+      for (int c = 2; c <= cus / sets && c <= nst_all / 2; ++c)
+        if (nst_all % c == 0 && (nst_all / c) % 2 == 0) parts = c;      // parts | stages, an even number of stages each
+      if (parts >= 2) {
+        p.full_passes = (int)full; p.tail_tile0 = (int)(full * cus * tpp); p.tail_sets = sets; p.tail_parts = parts;
+      }
+    }
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 20 + (size_t)waves * qkv_staging_blocks(channels, nt, waves) * 2048;
 #define HFL_QKV_LAUNCH(CC, NT, WW, PF)                                                                          \

@@ -193,6 +193,7 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 # filled: C = 128 from 24 576 rows on (118 096 rows: 71 vs 96 us for LayerNorm + qkv GEMM), C = 256 only when the last round of
 # 32 768 rows is at least half full (65 536 rows: 103 vs 114-122 us, but 66 775 rows -- 2.04 rounds, three passes -- 153 vs 127)
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
+_QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.5'))
 
 
 def _qkv_pack(att: 'OctreeAttention', rows: int):
@@ -203,7 +204,7 @@ def _qkv_pack(att: 'OctreeAttention', rows: int):
         return None
     if c == 256:
         fill = (rows % 32768) / 32768.0
-        if 0.0 < fill < 0.5:
+        if 0.0 < fill < _QKV_FUSED_MIN_FILL:
             return None
     w = lin.weight
     key = ('qkvpack', id(w))

@@ -495,10 +495,13 @@ def ln_mlp_fused(x, gamma, beta, eps: float, pack, b1, b2, out=None):
         assert out.shape == x.shape and out.dtype == torch.float32 and out.is_contiguous()
     assert out.data_ptr() != x.data_ptr(), 'the residual rows are re-read: cannot run in place'
     # algorithmic bytes: read x, write out (the LayerNorm input doubles as the residual); 2 * 2 * M * C * 4C flop
+    lib = _native.load()
+    ws_bytes = int(lib.hfl_ln_mlp_fused_workspace(m, c))      # partial sums of the rows left over after the last whole round
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
     with _timed('hfl_ln_mlp_fused', m * c * 8, 16 * m * c * c):
-        check(_native.load().hfl_ln_mlp_fused(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
-                                              float(eps), pack.data_ptr(), _f32c(b1).data_ptr(), _f32c(b2).data_ptr(), m, c,
-                                              _stream()), 'hfl_ln_mlp_fused')
+        check(lib.hfl_ln_mlp_fused_ws(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                      float(eps), pack.data_ptr(), _f32c(b1).data_ptr(), _f32c(b2).data_ptr(), m, c,
+                                      ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), 'hfl_ln_mlp_fused_ws')
     return out
 
 

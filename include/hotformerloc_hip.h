@@ -414,6 +414,15 @@ int64_t hfl_mlp_fused_pack_bytes(int channels);
 int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channels, hfl_stream_t stream);
 int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* b1, const float* b2, int64_t n_rows, int channels, hfl_stream_t stream);
+/*     The same launch with a workspace of hfl_ln_mlp_fused_workspace(n_rows, C) bytes (0: none needed): rows are dealt to
+ *     the workgroups in whole passes (128 rows at C = 256), and the rows left over after the last whole round -- fewer than
+ *     one pass per workgroup -- are computed with the HIDDEN dimension split over several workgroups per row set, whose fc2
+ *     partial sums go through the workspace and are added in a fixed order (bitwise reproducible).  Without a workspace the
+ *     left-over rows cost every workgroup that holds some a whole extra pass of the weight stream. */
+int64_t hfl_ln_mlp_fused_workspace(int64_t n_rows, int channels);
+int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                        const float* b1, const float* b2, int64_t n_rows, int channels, void* workspace,
+                        int64_t workspace_bytes, hfl_stream_t stream);
 
 /* 9d. LayerNorm -> qkv projection as ONE launch, written as the fp16 (hi, lo) operand rows of the window kernel
  *     (= hfl_layer_norm_split2 + hfl_linear_x3_qkv: norm1 -> attention.qkv, models/octformer_backbone.py:70,

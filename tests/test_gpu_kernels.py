@@ -913,6 +913,44 @@ def test_ln_mlp_fused_matches_fp64_and_the_unfused_launches(C):
         assert torch.equal(got, ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2))     # deterministic
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,n', [(256, 68167), (256, 33000), (128, 70001)])
+def test_ln_mlp_fused_tail_split_equals_whole_passes(C, n):
+    """Rows left over after the last whole round of passes (68167 rows at C = 256 are 2.08 rounds of the grid's 32768) are
+    computed with the hidden dimension split over several workgroups per row set and summed in a fixed order
+    (hfl_ln_mlp_fused_ws): same values as the whole-pass schedule up to the summation order of fc2's partial sums, the rows of
+    the whole passes bitwise equal, deterministic, and the workspace query says when the split applies."""
+    from hotformerloc_amd import _native
+    lib = _native.load()
+    g = torch.Generator().manual_seed(C + n)
+    w1 = (torch.randn(4 * C, C, generator=g) * 0.05).to(DEV)
+    w2 = (torch.randn(C, 4 * C, generator=g) * 0.05).to(DEV)
+    b1 = (torch.randn(4 * C, generator=g) * 0.1).to(DEV)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    pack = ops.mlp_fused_pack(w1, w2)
+    x = (torch.randn(n, C, generator=g) * 2).to(DEV)
+    ws = int(lib.hfl_ln_mlp_fused_workspace(n, C))
+    assert ws > 0, 'this shape has left-over rows: the split must apply'
+    assert int(lib.hfl_ln_mlp_fused_workspace(256 * (8 if C == 256 else 16) * 16 * 2, C)) == 0     # whole rounds: no workspace
+    split = ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2)
+    assert torch.equal(split, ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2))
+    try:
+        lib.hfl_set_variant(b'tail_split', 0)
+        assert int(lib.hfl_ln_mlp_fused_workspace(n, C)) == 0
+        whole = ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2)
+    finally:
+        lib.hfl_set_variant(b'tail_split', 1)
+    ref = _mlp_ref(x.cpu(), gamma.cpu(), beta.cpu(), 1e-5, w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu())
+    for got in (split, whole):
+        assert ((got.cpu().double() - ref).norm() / ref.norm()).item() < 1e-5
+    assert (split - whole).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    tail_rows = ws // (C * 4)                              # parts * tail rows; at least one part
+    assert 0 < tail_rows
+
+
+@pytest.mark.gpu
 def test_ln_mlp_fused_layout_exact_on_small_integers():
     """Fragment / stage layout check with exactly representable data: an identity-like LayerNorm (constant rows are avoided;
     gamma = 1, beta = 0 on rows whose statistics are exact is not available, so the LayerNorm is bypassed by feeding rows with

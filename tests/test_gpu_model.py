@@ -104,8 +104,8 @@ def test_descriptors_match_reference_golden(golden_dir, case, gemm_mode):
 _ORACLE_CACHE = {}
 
 
-@pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 4096, 1500, 4096]),
-                                                    ('cs-wild-places', 7, [7000, 4096])])
+@pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 1500, 4096]),
+                                                    ('cs-wild-places', 7, [5500, 4096])])
 def test_stage_by_stage_against_oracle(cfg, octree_depth, sizes, gemm_mode):
     """Fresh inputs (not in the fixtures), both weight profiles; oracle run live on the CPU."""
     params, _ = load_config(cfg)
@@ -159,10 +159,13 @@ def test_batch_composition_semantics():
     assert np.array_equal(full, again)
 
 
-@pytest.mark.parametrize('cfg,sizes,linear', [('cs-wild-places', [2500, 1800], 'x3'),
-                                              ('wild-places', [1500, 900, 1200], 'x3'),
-                                              ('wild-places', [1500, 900, 1200], 'fp32'),
-                                              ('cs-wild-places', [2500, 1800], 'bf16x3-lt')])
+_ORACLE_GRADS = {}
+
+
+@pytest.mark.parametrize('cfg,sizes,linear', [('cs-wild-places', [2000, 1400], 'x3'),
+                                              ('wild-places', [1300, 800, 1000], 'x3'),
+                                              ('wild-places', [1300, 800, 1000], 'fp32'),
+                                              ('cs-wild-places', [2000, 1400], 'bf16x3-lt')])
 def test_forward_backward_matches_oracle_autograd(cfg, sizes, linear):
     """BASELINE config 3 (fwd+bwd): parameter gradients of the HIP training path against torch
     autograd through the CPU oracle, drop_path = 0 (stochastic depth is RNG-dependent)."""
@@ -171,10 +174,14 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes, linear):
               for i, n in enumerate(sizes)]
     if params.coordinates == 'cylindrical':
         clouds = [syn.cylindrical(c) for c in clouds]
-    sd = {k: v.clone().requires_grad_() for k, v in synthetic_state_dict(params, 'stress').items()}
     proj = torch.from_numpy(syn.hash_uniform(4242, len(sizes) * 256).reshape(len(sizes), 256).astype(np.float32))
-    y_ref = hotformer_ref.forward_with_grad(sd, params, oracle_octree(clouds, depth))
-    (y_ref * proj).sum().backward()
+    key = (cfg, tuple(sizes))
+    if key not in _ORACLE_GRADS:                 # the CPU oracle's forward + backward is the slow part: once per workload
+        sd = {k: v.clone().requires_grad_() for k, v in synthetic_state_dict(params, 'stress').items()}
+        y_ref = hotformer_ref.forward_with_grad(sd, params, oracle_octree(clouds, depth))
+        (y_ref * proj).sum().backward()
+        _ORACLE_GRADS[key] = (y_ref.detach(), {k: v.grad for k, v in sd.items()})
+    y_ref, grads_ref = _ORACLE_GRADS[key]
     params.drop_path = 0.0                       # stochastic depth off: RNG parity is impossible
     model = model_factory(params)
     syn.fill_synthetic_weights(model, 'stress')
@@ -196,7 +203,7 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes, linear):
     assert rel <= REL_TOL, rel
     worst = {}
     for name, p in model.named_parameters():
-        gref = sd[name].grad
+        gref = grads_ref[name]
         assert p.grad is not None, name
         err = (p.grad.cpu() - gref).norm().item() / max(gref.norm().item(), 1e-12)
         kind = name.split('.')[-1] if 'rpe_table' not in name else 'rpe_table'

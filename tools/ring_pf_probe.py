@@ -27,7 +27,7 @@ def main():
     lib = _native.load()
     g = torch.Generator().manual_seed(1)
     dev = 'cuda'
-    for rows, C in ((68167, 256), (65536, 256), (32768, 256), (14276, 256), (2092, 256), (118096, 128), (131072, 128)):
+    for rows, C in ((68167, 256), (66775, 256), (65536, 256), (32768, 256), (40000, 256), (14276, 256), (118096, 128), (131072, 128)):
         x = (torch.randn(rows, C, generator=g) * 1.5 + 0.3).to(dev)
         w1 = (torch.randn(4 * C, C, generator=g) * 0.05).to(dev)
         w2 = (torch.randn(C, 4 * C, generator=g) * 0.05).to(dev)
@@ -39,6 +39,12 @@ def main():
         out = torch.empty_like(x)
         qout = torch.empty((rows, 3 * C), dtype=torch.float32, device=dev)
         res = {}
+        lib.hfl_set_variant(b'tail_split', 0)
+        lib.hfl_set_variant(b'ring_pf', 3)
+        t_nosplit = (timeit(lambda: ops.ln_mlp_fused(x, gamma, beta, 1e-5, mpack, b1, b2, out=out)),
+                     timeit(lambda: ops.ln_qkv_fused(x, gamma, beta, 1e-5, qpack, bq, 0.36, out=qout)))
+        lib.hfl_set_variant(b'tail_split', 1)
+        print('rows %6d C %3d | pf3 WITHOUT tail split: mlp %.1f us  qkv %.1f us' % (rows, C, t_nosplit[0], t_nosplit[1]))
         for pf in (2, 3, 2, 3):
             lib.hfl_set_variant(b'ring_pf', pf)
             tm = timeit(lambda: ops.ln_mlp_fused(x, gamma, beta, 1e-5, mpack, b1, b2, out=out))
