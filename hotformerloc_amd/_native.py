@@ -43,7 +43,7 @@ class RelayBlockWeights(ctypes.Structure):
     _fields_ = [('channels', c_int64), ('n_heads', c_int32), ('eps', c_float),
                 ('norm1_gamma', c_void_p), ('norm1_beta', c_void_p), ('norm2_gamma', c_void_p), ('norm2_beta', c_void_p),
                 ('qkv_w', c_void_p), ('proj_w', c_void_p), ('fc1_w', c_void_p), ('fc2_w', c_void_p),
-                ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p)]
+                ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p), ('mlp_pack', c_void_p)]
 
 
 class RelayBlockIO(ctypes.Structure):
@@ -62,6 +62,8 @@ class BlockIO(ctypes.Structure):
 # name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
 SIGNATURES = {
     'hfl_version': (c_int, []),
+    'hfl_stream_create_cu_mask': (c_int, [c_void_p, c_int, c_int]),
+    'hfl_stream_destroy': (c_int, [c_void_p]),
     'hfl_arch': (c_char_p, []),
     'hfl_dwconv_forward_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                             c_int64, c_int, c_void_p]),
@@ -84,8 +86,10 @@ SIGNATURES = {
     'hfl_prepare_clouds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'hfl_tap_lists_workspace': (c_int64, [c_int64, c_int]),
     'hfl_tap_lists': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    'hfl_tap_lists_multi': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'hfl_tap_tiles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'hfl_pad_index': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    'hfl_pad_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
     'hfl_window_attention_fwd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -112,6 +116,7 @@ SIGNATURES = {
     'hfl_linear_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     'hfl_layer_norm_split2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                       c_float, c_void_p]),
+    'hfl_layer_norm_relu': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_float, c_void_p]),
     'hfl_linear_x3_qkv': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     'hfl_window_attention_f16_ok': (c_int, [ctypes.POINTER(WindowAttnDesc), c_int64]),
     'hfl_split2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

@@ -1277,7 +1277,7 @@ static int launch_window_v5(const WinParams* ps, int n, hipStream_t s) {
   const int lds_fit = (int)((size_t)160 * 1024 / (lds_max + 512));
   if (resident > lds_fit) resident = lds_fit;
   if (resident < 1) resident = 1;
-  int64_t px = (int64_t)hfl_num_cus() * resident * g_window_v4_wgs_per_cu / groups5;
+  int64_t px = (int64_t)hfl_stream_cus(s) * resident * g_window_v4_wgs_per_cu / groups5;
   if (px < n) px = n;
   WinMultiParams m;
   m.n = n;
@@ -1352,7 +1352,7 @@ static int launch_window(const WinParams& p, hipStream_t s) {
   constexpr int LP = T * 16;
   const int nrpe = 2 * p.bnd + 1;
   int blocks = p.n_windows;
-  const int cap = hfl_num_cus() * 4;
+  const int cap = hfl_stream_cus(s) * 4;
   if (blocks > cap) blocks = cap;
   {
     int hpw = g_window_heads_per_wg;             // heads (= waves) per workgroup, at most 4
@@ -1360,7 +1360,7 @@ static int launch_window(const WinParams& p, hipStream_t s) {
     const size_t lds = (p.table ? (size_t)hpw * 3 * nrpe * 4 : 0) + (size_t)LP * (16 + 16 + 4);
     const int groups = p.H / hpw;
     int bx = p.n_windows;
-    const int capx = hfl_num_cus() * g_window_v2_wgs_per_cu / groups;
+    const int capx = hfl_stream_cus(s) * g_window_v2_wgs_per_cu / groups;
     if (bx > capx) bx = capx;
     dim3 grid((unsigned)bx, (unsigned)groups);
     const int64_t rows_total = G > 0 ? p.rt_row0 + p.n_windows : p.n_tokens;
@@ -1378,7 +1378,7 @@ static int launch_window(const WinParams& p, hipStream_t s) {
       const int lds_fit = (int)((size_t)160 * 1024 / (lds4 + 512));
       if (resident > lds_fit) resident = lds_fit;
       if (resident < 1) resident = 1;
-      int px = hfl_num_cus() * resident * g_window_v4_wgs_per_cu / groups;
+      int px = hfl_stream_cus(s) * resident * g_window_v4_wgs_per_cu / groups;
       if (px < 1) px = 1;
       if (px > p.n_windows) px = p.n_windows;
       dim3 grid4((unsigned)px, (unsigned)groups);

@@ -1,7 +1,59 @@
 // Library identification entry points of libhotformerloc_hip.so.
 #include "hfl_common.h"
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace {
+std::mutex g_stream_mu;
+std::vector<std::pair<void*, int>> g_stream_cus;       // streams made by hfl_stream_create_cu_mask -> CUs in their mask
+}  // namespace
+
 extern "C" {
+
+int hfl_internal_stream_cus(void* stream) {
+  if (stream != nullptr) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& e : g_stream_cus)
+      if (e.first == stream) return e.second;
+  }
+  return hfl_num_cus();
+}
+
+// A HIP stream whose kernels run on a subset of the chip's CUs: mask bits [first_bit, first_bit + n_bits).  On gfx950 bit i
+// of a CU mask is CU (i / 8) of XCD (i % 8) (tools/micro/cu_mask_census.hip), so a run of 8 k consecutive bits is k CUs of
+// every XCD -- an even slice of every L2.  Streams with disjoint masks do not compete for CUs: persistent kernels of one do
+// not wait for, or starve, the launches of the other.
+int hfl_stream_create_cu_mask(hfl_stream_t* out, int first_bit, int n_bits) {
+  const int total = hfl_num_cus();
+  if (out == nullptr || first_bit < 0 || n_bits < 8 || first_bit % 8 != 0 || n_bits % 8 != 0 || first_bit + n_bits > total)
+    return HFL_EINVAL;
+  std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+  for (int b = first_bit; b < first_bit + n_bits; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+  if (e != hipSuccess) return (int)e;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_cus.emplace_back(static_cast<void*>(s), n_bits);
+  }
+  *out = static_cast<hfl_stream_t>(s);
+  return HFL_OK;
+}
+
+int hfl_stream_destroy(hfl_stream_t stream) {
+  if (stream == nullptr) return HFL_EINVAL;
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (size_t i = 0; i < g_stream_cus.size(); ++i)
+      if (g_stream_cus[i].first == stream) {
+        g_stream_cus.erase(g_stream_cus.begin() + (long)i);
+        break;
+      }
+  }
+  return (int)hipStreamDestroy(static_cast<hipStream_t>(stream));
+}
 
 int hfl_version(void) { return 100; }   // 1.00
 
@@ -73,10 +125,9 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
-    // (the arena's h2 | g2 region, 5 units, is free on this path: workspace of the left-over rows' partial sums, at most
-    // 32768 rows x C x 4 B -- hfl_ln_mlp_fused_ws falls back to whole passes when it does not fit)
+    // (workspace of the left-over rows' partial sums: behind the twelve units, sized by hfl_block_forward_x3_arena)
     return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
-                               h2, (int64_t)(5 * unit), stream);
+                               a + 12 * unit, hfl_ln_mlp_fused_workspace(rows, (int)C), stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);
@@ -84,7 +135,9 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   return hfl_linear_x3(io->out, g2, w->fc2_w, w->fc2_b, x1, rows, (int)(4 * C), (int)C, 0, stream);
 }
 
-int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) { return n_rows * channels * 4 * 12; }
+int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) {
+  return n_rows * channels * 4 * 12 + hfl_ln_mlp_fused_workspace(n_rows, (int)channels);
+}
 
 // The window attention of n blocks (between their phases 3 and 4) as ONE launch when the blocks have one attention shape
 // (the pyramid levels of an H-OSA iteration), else one launch each: operands are found in the blocks' arenas.
@@ -138,6 +191,9 @@ int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, io->x_in, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
+  if (w->mlp_pack != nullptr)       // LN2 -> fc1 -> GELU -> fc2 -> residual in one launch, hidden dimension split over the chip
+    return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
+                               a + 12 * unit, hfl_ln_mlp_fused_workspace(rows, (int)C), stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);
@@ -145,6 +201,8 @@ int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay
   return hfl_linear_x3(io->out, g2, w->fc2_w, w->fc2_b, x1, rows, (int)(4 * C), (int)C, 0, stream);
 }
 
-int64_t hfl_relay_block_forward_x3_arena(int64_t n_rows, int64_t channels) { return n_rows * channels * 4 * 12; }
+int64_t hfl_relay_block_forward_x3_arena(int64_t n_rows, int64_t channels) {
+  return n_rows * channels * 4 * 12 + hfl_ln_mlp_fused_workspace(n_rows, (int)channels);
+}
 
 }  // extern "C"

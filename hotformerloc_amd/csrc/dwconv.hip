@@ -103,7 +103,7 @@ static int launch_fwd(float* out, const float* data, const float* weight, const 
     RowGeom g = row_geom(C);
     const size_t lds = (size_t)K * C * sizeof(float) + (size_t)g.rpb * K * sizeof(IdxT);
     const int64_t need = hfl_cdiv(n_out, g.rpb);
-    const int blocks = (int)(need < (int64_t)hfl_num_cus() * 8 ? need : (int64_t)hfl_num_cus() * 8);
+    const int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
     if (K == 27)
       dwconv_fwd_vec4<IdxT, 27><<<blocks, g.tpr * g.rpb, lds, s>>>(out, data, weight, neigh, n_out,
                                                                    (int)C, K, g.tpr, g.rpb);
@@ -360,7 +360,7 @@ static int launch_cpe(float* out, const float* x, const float* w, const float* g
   constexpr int RPB = 256 / TPR;
   const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * (sizeof(int32_t) + 1) + 16;
   const int64_t need = hfl_cdiv(n, RPB);
-  const int blocks = (int)(need < (int64_t)hfl_num_cus() * 8 ? need : (int64_t)hfl_num_cus() * 8);
+  const int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
   cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual,
                                                g_cpe_chunk_rows);
   HFL_RETURN_LAST_ERROR();

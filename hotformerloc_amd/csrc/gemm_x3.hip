@@ -409,7 +409,7 @@ int hfl_split2_rows(uint16_t* out, const float* x, const float* row_scale, int64
   if (n_rows < 0 || channels <= 0 || channels % 32 != 0) return HFL_EINVAL;
   if (n_rows == 0) return HFL_OK;
   const int64_t need = hfl_cdiv(n_rows * (channels / 4), 256);
-  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  const int64_t cap = (int64_t)hfl_stream_cus(static_cast<hipStream_t>(stream)) * 16;
   split2_kernel<<<(int)(need < cap ? need : cap), 256, 0, static_cast<hipStream_t>(stream)>>>(out, x, row_scale, n_rows,
                                                                                               (int)channels);
   HFL_RETURN_LAST_ERROR();

@@ -25,6 +25,11 @@ static inline int hfl_num_cus() {
   return cus;
 }
 
+// CUs a launch on `stream` can use: the device's, or the size of the stream's CU mask when it was made by
+// hfl_stream_create_cu_mask (csrc/capi.hip keeps the registry).  Persistent grids are sized with this.
+extern "C" int hfl_internal_stream_cus(void* stream);
+static inline int hfl_stream_cus(hipStream_t s) { return hfl_internal_stream_cus(static_cast<void*>(s)); }
+
 static inline int64_t hfl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // index-table element access for int32 / int64 neighbour tables

@@ -497,10 +497,7 @@ mlp_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w1, 
 
 }  // namespace
 
-static int grid_guess(int n_tiles) {
-  const int cus = hfl_num_cus();
-  return n_tiles < cus ? n_tiles : cus;
-}
+static int grid_guess(int n_tiles, int cus) { return n_tiles < cus ? n_tiles : cus; }
 
 extern "C" {
 
@@ -530,12 +527,13 @@ struct MlpTailPlan {
   int full, tile0, sets, parts;
 };
 static int g_mlp_tail_split = 1;   // probe knob 'mlp_tail_split'
-static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels) {
+static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus) {
   MlpTailPlan t{0, 0, 0, 0};
   const int64_t n_tiles = hfl_cdiv(n_rows, 16);
-  const int cus = hfl_num_cus();
   const int tpp = channels == 256 ? 8 : 16, nch = channels / 8;
-  if (!g_mlp_tail_split || n_tiles <= (int64_t)cus * tpp) return t;          // at most one round: nothing to balance
+  if (!g_mlp_tail_split) return t;
+  // (full == 0: fewer rows than one round -- relay tokens, the coarse pyramid levels.  Their few row sets would leave most of
+  // the chip idle while every workgroup streams all of W1 and W2; split over the hidden dimension the same launch fills it.)
   const int64_t full = n_tiles / ((int64_t)cus * tpp);
   const int64_t rem = n_tiles - full * cus * tpp;
   if (rem == 0) return t;
@@ -549,12 +547,21 @@ static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels) {
 
 extern "C" void hfl_internal_set_mlp_tail_split(int v) { g_mlp_tail_split = v ? 1 : 0; }
 
-/* Workspace of hfl_ln_mlp_fused_ws for this shape (0: none needed). */
+static int64_t mlp_tail_bytes(const MlpTailPlan& t, int64_t n_rows, int channels) {
+  return t.parts == 0 ? 0 : (int64_t)t.parts * (n_rows - (int64_t)t.tile0 * 16) * channels * 4;
+}
+
+/* Workspace of hfl_ln_mlp_fused_ws for this shape (0: none needed): enough for a launch on the whole chip or on any
+ * CU-masked stream of this library (hfl_stream_create_cu_mask: 8 .. all CUs in steps of 8) -- the plan depends on the CUs the
+ * launch's stream can use; parts x left-over rows never exceeds one round, cus x rows per pass. */
 extern "C" int64_t hfl_ln_mlp_fused_workspace(int64_t n_rows, int channels) {
   if (n_rows <= 0 || (channels != 128 && channels != 256)) return 0;
-  const MlpTailPlan t = mlp_tail_plan(n_rows, channels);
-  if (t.parts == 0) return 0;
-  return (int64_t)t.parts * (n_rows - (int64_t)t.tile0 * 16) * channels * 4;
+  int64_t need = 0;
+  for (int cus = 8; cus <= hfl_num_cus(); cus += 8) {
+    const int64_t b = mlp_tail_bytes(mlp_tail_plan(n_rows, channels, cus), n_rows, channels);
+    if (b > need) need = b;
+  }
+  return need;
 }
 
 extern "C" int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
@@ -581,15 +588,16 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   p.b1 = b1; p.b2 = b2; p.M = n_rows; p.eps = eps;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
   // stagger only launches in which a workgroup walks several passes (a single pass has nothing to alternate with)
-  p.stagger = p.n_tiles > (int64_t)grid_guess(p.n_tiles) * 8 * (channels == 256 ? 1 : 2) ? g_mlp_stagger : 0;
+  const int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
+  p.stagger = p.n_tiles > (int64_t)grid_guess(p.n_tiles, cus) * 8 * (channels == 256 ? 1 : 2) ? g_mlp_stagger : 0;
   p.stagger_groups = g_mlp_stagger_groups;
-  const int cus = hfl_num_cus();
-  const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+  int grid = p.n_tiles < cus ? p.n_tiles : cus;
   p.full_passes = 0; p.tail_tile0 = 0; p.tail_sets = 0; p.tail_parts = 0; p.part = nullptr;
-  MlpTailPlan tp = mlp_tail_plan(n_rows, channels);
-  if (tp.parts > 0 && workspace != nullptr && workspace_bytes >= hfl_ln_mlp_fused_workspace(n_rows, channels)) {
+  MlpTailPlan tp = mlp_tail_plan(n_rows, channels, cus);
+  if (tp.parts > 0 && workspace != nullptr && workspace_bytes >= mlp_tail_bytes(tp, n_rows, channels)) {
     p.full_passes = tp.full; p.tail_tile0 = tp.tile0; p.tail_sets = tp.sets; p.tail_parts = tp.parts;
     p.part = static_cast<float*>(workspace);
+    if (grid < tp.sets * tp.parts) grid = tp.sets * tp.parts;          // (full == 0: more workgroups than row sets)
   } else {
     tp.parts = 0;
   }

@@ -387,38 +387,112 @@ __global__ void token_meta_kernel(uint32_t* __restrict__ meta, const int64_t* __
 // (one wave per tap), then the fill pass recomputes the ballots and writes.
 constexpr int kTapRows = 1024;         // rows per block (256 threads x 4)
 constexpr int kTapMax = 32;
+constexpr int kTapTables = 16;         // tables per launch (hfl_tap_lists_multi)
 
-__global__ void __launch_bounds__(256)
-tap_count_kernel(const int32_t* __restrict__ table, int64_t rows, int taps, int32_t* __restrict__ block_counts) {
+// Several tables per launch (every convolution depth of a batch at once): flat block index -> (table, block of the table).
+struct TapTable {
+  const int32_t* table;
+  int32_t* src;
+  int32_t* slot;
+  int32_t* edges;
+  int32_t* block_counts;      // (blocks of this table, taps): per-block per-tap counts, then their exclusive scan
+  int64_t rows;
+  int taps;
+  int first_block;
+};
+struct TapMulti {
+  TapTable t[kTapTables];
+  int n;
+  int total_blocks;
+};
+
+__device__ __forceinline__ const TapTable& tap_find(const TapMulti& m, int block, int& local) {
+  int i = 0;
+  while (i + 1 < m.n && block >= m.t[i + 1].first_block) ++i;
+  local = block - m.t[i].first_block;
+  return m.t[i];
+}
+
+// One wave's 64 rows of a (rows, TAPS) table into registers, lane = row.  The table is row-major with TAPS * 4 bytes per
+// row: a lane reading its own row directly touches a different cache line per lane and tap (TAPS = 27: 108-B stride, 27
+// requests of 64 lines each; the fill pass took 66 us for 130 k rows that way).  Instead the wave copies its contiguous
+// 64 x TAPS words with coalesced loads into its LDS block (word j * 64 + lane per instruction) and every lane reads its row
+// back (stride TAPS words: conflict-free for odd TAPS).  TAPS = 8 rows are 32 B: two 16-B loads per lane are coalesced as is.
+template <int TAPS>
+__device__ __forceinline__ void tap_load_rows(const int32_t* __restrict__ table, int64_t rows, int64_t row0, int32_t* lds_wave,
+                                              int lane, int32_t (&v)[kTapMax], int taps_rt) {
+  if constexpr (TAPS == 8) {
+    const int64_t r = row0 + lane;
+    int4 a = make_int4(-1, -1, -1, -1), b = a;
+    if (r < rows) {
+      a = reinterpret_cast<const int4*>(table)[r * 2];
+      b = reinterpret_cast<const int4*>(table)[r * 2 + 1];
+    }
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else if constexpr (TAPS > 0) {
+    const int64_t w0 = row0 * TAPS, wend = rows * TAPS;
+#pragma unroll
+    for (int j = 0; j < TAPS; ++j) {
+      const int64_t w = w0 + j * 64 + lane;
+      lds_wave[j * 64 + lane] = w < wend ? table[w] : -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) v[k] = lds_wave[lane * TAPS + k];
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    const int64_t r = row0 + lane;
+#pragma unroll
+    for (int k = 0; k < kTapMax; ++k)
+      if (k < taps_rt) v[k] = r < rows ? table[r * taps_rt + k] : -1;
+  }
+}
+
+template <int TAPS>
+__device__ __forceinline__ void tap_count_body(const TapTable& t, int block, int32_t* lds) {
   __shared__ int32_t wave_cnt[4][kTapMax];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int taps = TAPS > 0 ? TAPS : t.taps;
   int32_t acc[kTapMax];
 #pragma unroll
   for (int k = 0; k < kTapMax; ++k) acc[k] = 0;
-  const int64_t row0 = (int64_t)blockIdx.x * kTapRows;
+  const int64_t row0 = (int64_t)block * kTapRows;
+  int32_t* lds_wave = lds + wave * (64 * (TAPS > 0 ? TAPS : 1));
   for (int it = 0; it < kTapRows / 256; ++it) {
-    const int64_t r = row0 + it * 256 + threadIdx.x;
-    const bool in = r < rows;
+    int32_t v[kTapMax];
+    tap_load_rows<TAPS>(t.table, t.rows, row0 + it * 256 + wave * 64, lds_wave, lane, v, taps);
 #pragma unroll
-    for (int k = 0; k < kTapMax; ++k) {
-      if (k < taps) {
-        const bool live = in && table[r * taps + k] >= 0;
-        acc[k] += __popcll(__ballot(live));
-      }
-    }
+    for (int k = 0; k < kTapMax; ++k)
+      if (k < taps) acc[k] += __popcll(__ballot(v[k] >= 0));
   }
   if (lane == 0)
     for (int k = 0; k < taps; ++k) wave_cnt[wave][k] = acc[k];
   __syncthreads();
   if ((int)threadIdx.x < taps)
-    block_counts[(int64_t)blockIdx.x * taps + threadIdx.x] =
+    t.block_counts[(int64_t)block * taps + threadIdx.x] =
         wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
 }
 
-// one wave per tap (16 waves, taps k and k + 16): exclusive scan of that tap's block counts (in place), totals -> edges
+__global__ void __launch_bounds__(256)
+tap_count_kernel(const TapMulti m) {
+  __shared__ int32_t lds[4 * 64 * 27];
+  int block;
+  const TapTable& t = tap_find(m, blockIdx.x, block);
+  if (t.taps == 27) tap_count_body<27>(t, block, lds);
+  else if (t.taps == 8) tap_count_body<8>(t, block, lds);
+  else tap_count_body<0>(t, block, lds);
+}
+
+// one workgroup per table, one wave per tap (16 waves, taps k and k + 16): exclusive scan of that tap's block counts (in
+// place), totals -> edges
 __global__ void __launch_bounds__(1024)
-tap_scan_kernel(int32_t* __restrict__ block_counts, int nblocks, int taps, int32_t* __restrict__ edges) {
+tap_scan_kernel(const TapMulti m) {
   __shared__ int32_t total[kTapMax];
+  const TapTable& t = m.t[blockIdx.x];
+  const int taps = t.taps;
+  const int nblocks = (blockIdx.x + 1 < (unsigned)m.n ? m.t[blockIdx.x + 1].first_block : m.total_blocks) - t.first_block;
+  int32_t* block_counts = t.block_counts;
   const int lane = threadIdx.x & 63;
   for (int k = threadIdx.x >> 6; k < taps; k += 16) {
     int32_t run = 0;
@@ -428,8 +502,8 @@ tap_scan_kernel(int32_t* __restrict__ block_counts, int nblocks, int taps, int32
       int32_t inc = v;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const int32_t t = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += t;
+        const int32_t u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
       }
       if (b < nblocks) block_counts[(int64_t)b * taps + k] = run + inc - v;
       run += __shfl(inc, 63, 64);
@@ -439,56 +513,86 @@ tap_scan_kernel(int32_t* __restrict__ block_counts, int nblocks, int taps, int32
   __syncthreads();
   if (threadIdx.x == 0) {
     int32_t e = 0;
-    for (int t = 0; t < taps; ++t) {
-      edges[t] = e;
-      e += total[t];
+    for (int k = 0; k < taps; ++k) {
+      t.edges[k] = e;
+      e += total[k];
     }
-    edges[taps] = e;
+    t.edges[taps] = e;
   }
 }
 
-__global__ void __launch_bounds__(256)
-tap_fill_kernel(const int32_t* __restrict__ table, int64_t rows, int taps, const int32_t* __restrict__ block_off,
-                const int32_t* __restrict__ edges, int32_t* __restrict__ src, int32_t* __restrict__ slot) {
+template <int TAPS>
+__device__ __forceinline__ void tap_fill_body(const TapTable& t, int block, int32_t* lds) {
   __shared__ int32_t wave_cnt[4][kTapMax];
   __shared__ int32_t base[kTapMax];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)threadIdx.x < taps) base[threadIdx.x] = edges[threadIdx.x] + block_off[(int64_t)blockIdx.x * taps + threadIdx.x];
-  const int64_t row0 = (int64_t)blockIdx.x * kTapRows;
+  const int taps = TAPS > 0 ? TAPS : t.taps;
+  if ((int)threadIdx.x < taps) base[threadIdx.x] = t.edges[threadIdx.x] + t.block_counts[(int64_t)block * taps + threadIdx.x];
+  const int64_t row0 = (int64_t)block * kTapRows;
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int32_t* lds_wave = lds + wave * (64 * (TAPS > 0 ? TAPS : 1));
   for (int it = 0; it < kTapRows / 256; ++it) {
-    const int64_t r = row0 + it * 256 + threadIdx.x;
-    const bool in = r < rows;
+    const int64_t rw = row0 + it * 256 + wave * 64;       // first row of this wave
+    const int64_t r = rw + lane;
+    const bool in = r < t.rows;
     int32_t v[kTapMax];
-    unsigned long long m[kTapMax];
+    unsigned long long mk[kTapMax];
+    tap_load_rows<TAPS>(t.table, t.rows, rw, lds_wave, lane, v, taps);
 #pragma unroll
-    for (int k = 0; k < kTapMax; ++k) {
-      if (k < taps) {
-        v[k] = in ? table[r * taps + k] : -1;
-        m[k] = __ballot(v[k] >= 0);
-      }
-    }
+    for (int k = 0; k < kTapMax; ++k)
+      if (k < taps) mk[k] = __ballot(v[k] >= 0);
     __syncthreads();                       // base[] ready (first pass) / updated (later passes)
     if (lane == 0)
-      for (int k = 0; k < taps; ++k) wave_cnt[wave][k] = __popcll(m[k]);
+      for (int k = 0; k < taps; ++k) wave_cnt[wave][k] = __popcll(mk[k]);
     __syncthreads();
+    int32_t pos[kTapMax];
 #pragma unroll
     for (int k = 0; k < kTapMax; ++k) {
       if (k < taps) {
         int32_t off = base[k];
         for (int w = 0; w < wave; ++w) off += wave_cnt[w][k];
-        const int32_t pos = off + __popcll(m[k] & lt);
-        if (in) {
-          slot[r * taps + k] = v[k] >= 0 ? pos : -1;
-          if (v[k] >= 0) src[pos] = v[k];
-        }
+        pos[k] = v[k] >= 0 ? off + __popcll(mk[k] & lt) : -1;
+        if (in && v[k] >= 0) t.src[pos[k]] = v[k];
       }
+    }
+    // slot rows leave the way the table rows came in: through the wave's LDS block, whole lines per store instruction
+    if constexpr (TAPS == 8) {
+      if (in) {
+        reinterpret_cast<int4*>(t.slot)[r * 2] = make_int4(pos[0], pos[1], pos[2], pos[3]);
+        reinterpret_cast<int4*>(t.slot)[r * 2 + 1] = make_int4(pos[4], pos[5], pos[6], pos[7]);
+      }
+    } else if constexpr (TAPS > 0) {
+#pragma unroll
+      for (int k = 0; k < TAPS; ++k) lds_wave[lane * TAPS + k] = pos[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int64_t w0 = rw * TAPS, wend = t.rows * TAPS;
+#pragma unroll
+      for (int j = 0; j < TAPS; ++j) {
+        const int64_t w = w0 + j * 64 + lane;
+        if (w < wend) t.slot[w] = lds_wave[j * 64 + lane];
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int k = 0; k < kTapMax; ++k)
+        if (k < taps && in) t.slot[r * taps + k] = pos[k];
     }
     __syncthreads();
     if ((int)threadIdx.x < taps)
       base[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] +
                            wave_cnt[3][threadIdx.x];
   }
+}
+
+__global__ void __launch_bounds__(256)
+tap_fill_kernel(const TapMulti m) {
+  __shared__ int32_t lds[4 * 64 * 27];
+  int block;
+  const TapTable& t = tap_find(m, blockIdx.x, block);
+  if (t.taps == 27) tap_fill_body<27>(t, block, lds);
+  else if (t.taps == 8) tap_fill_body<8>(t, block, lds);
+  else tap_fill_body<0>(t, block, lds);
 }
 
 }  // namespace
@@ -582,17 +686,35 @@ int64_t hfl_tap_lists_workspace(int64_t rows, int taps) {
 
 /* Live-tap lists of a (rows, taps) int32 index table (see above): src must hold rows*taps entries (only the
  * first edges[taps] are written), slot (rows, taps), edges (taps + 1), all on the device; no host sync. */
+int hfl_tap_lists_multi(int n, int32_t* const* src, int32_t* const* slot, int32_t* const* edges, const int32_t* const* table,
+                        const int64_t* rows, const int32_t* taps, void* const* workspace, hfl_stream_t stream) {
+  if (n < 1 || n > kTapTables || src == nullptr || slot == nullptr || edges == nullptr || table == nullptr || rows == nullptr ||
+      taps == nullptr || workspace == nullptr)
+    return HFL_EINVAL;
+  TapMulti m;
+  m.n = n;
+  int first = 0;
+  for (int i = 0; i < n; ++i) {
+    if (rows[i] < 0 || taps[i] < 1 || taps[i] > kTapMax) return HFL_EINVAL;
+    if (rows[i] * taps[i] > 0x7fffffffLL) return HFL_ECAPACITY;
+    m.t[i].table = table[i]; m.t[i].src = src[i]; m.t[i].slot = slot[i]; m.t[i].edges = edges[i];
+    m.t[i].block_counts = static_cast<int32_t*>(workspace[i]);
+    m.t[i].rows = rows[i]; m.t[i].taps = taps[i]; m.t[i].first_block = first;
+    first += (int)hfl_cdiv(rows[i] > 0 ? rows[i] : 1, kTapRows);
+  }
+  for (int i = n; i < kTapTables; ++i) m.t[i] = m.t[0];
+  m.total_blocks = first;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  tap_count_kernel<<<first, 256, 0, s>>>(m);
+  tap_scan_kernel<<<n, 1024, 0, s>>>(m);
+  tap_fill_kernel<<<first, 256, 0, s>>>(m);
+  HFL_RETURN_LAST_ERROR();
+}
+
 int hfl_tap_lists(int32_t* src, int32_t* slot, int32_t* edges, const int32_t* table, int64_t rows, int taps,
                   void* workspace, hfl_stream_t stream) {
-  if (rows < 0 || taps < 1 || taps > kTapMax) return HFL_EINVAL;
-  if (rows * taps > 0x7fffffffLL) return HFL_ECAPACITY;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int nblocks = (int)hfl_cdiv(rows > 0 ? rows : 1, kTapRows);
-  int32_t* bc = static_cast<int32_t*>(workspace);
-  tap_count_kernel<<<nblocks, 256, 0, s>>>(table, rows, taps, bc);
-  tap_scan_kernel<<<1, 1024, 0, s>>>(bc, nblocks, taps, edges);
-  tap_fill_kernel<<<nblocks, 256, 0, s>>>(table, rows, taps, bc, edges, src, slot);
-  HFL_RETURN_LAST_ERROR();
+  const int32_t t = taps;
+  return hfl_tap_lists_multi(1, &src, &slot, &edges, &table, &rows, &t, &workspace, stream);
 }
 
 /* Row-tile table of the grouped tap GEMM (hfl_linear_x3_grouped) built on the device from the tap edges hfl_tap_lists wrote:
@@ -642,6 +764,35 @@ __global__ void __launch_bounds__(256) pad_index_kernel(int64_t* __restrict__ ou
     const int64_t a = row_off[b];
     out[i] = j < row_off[b + 1] - a ? a + j : sentinel;
   }
+}
+
+/* The padded copy itself (models/layers/pooling.py:209-233 splits the ragged stream per cloud and pads with zeros): out
+ * (B, nmax, C) f32, out[b][j] = x[row_off[b] + j] for j < n_b, zeros beyond -- one pass, no index table, no appended zero row. */
+__global__ void __launch_bounds__(256) pad_rows_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                       const int64_t* __restrict__ row_off, int B, int64_t nmax, int c4) {
+  const int64_t total = (int64_t)B * nmax * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / c4;
+    const int v = (int)(i - row * c4);
+    const int b = (int)(row / nmax);
+    const int64_t j = row - (int64_t)b * nmax;
+    const int64_t a = row_off[b];
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < row_off[b + 1] - a) val = reinterpret_cast<const float4*>(x)[(a + j) * c4 + v];
+    reinterpret_cast<float4*>(out)[i] = val;
+  }
+}
+
+int hfl_pad_rows(float* out, const float* x, const int64_t* row_off, int batch, int64_t nmax, int64_t channels,
+                 hfl_stream_t stream) {
+  if (out == nullptr || x == nullptr || row_off == nullptr || batch < 0 || nmax < 0 || channels <= 0 || channels % 4 != 0)
+    return HFL_EINVAL;
+  if (batch == 0 || nmax == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t need = hfl_cdiv((int64_t)batch * nmax * (channels / 4), 256);
+  const int64_t cap = (int64_t)hfl_stream_cus(s) * 16;
+  pad_rows_kernel<<<(unsigned)(need < cap ? need : cap), 256, 0, s>>>(out, x, row_off, batch, nmax, (int)(channels / 4));
+  HFL_RETURN_LAST_ERROR();
 }
 
 int hfl_pad_index(int64_t* out, const int64_t* row_off, int batch, int64_t nmax, hfl_stream_t stream) {

@@ -437,7 +437,7 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   p.out = static_cast<unsigned char*>(qkv_out); p.x = x; p.gamma = gamma; p.beta = beta;
   p.pack = static_cast<const unsigned char*>(pack); p.bias = bias; p.M = n_rows; p.eps = eps; p.q_scale = q_scale;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
-  const int cus = hfl_num_cus();
+  const int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
   const int grid = p.n_tiles < cus ? p.n_tiles : cus;
   const int nt = channels == 256 ? 1 : 2, waves = 8;       // (C = 256 with 2 tiles per wave spills, with 4 waves x 4 tiles
                                                              //  a stage takes 3-5 us: tools/qkv_fused_probe.py)

@@ -265,7 +265,7 @@ template <int TPR, int VPL, bool ADD, int SPLIT>
 __global__ void __launch_bounds__(256)
 layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const float* __restrict__ y,
                   const float* __restrict__ bias, const float* __restrict__ gamma,
-                  const float* __restrict__ beta, int64_t n_rows, float eps) {
+                  const float* __restrict__ beta, int64_t n_rows, float eps, int relu) {
   constexpr int C = TPR * VPL * 4;
   constexpr int RPB = 256 / TPR;
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
@@ -313,6 +313,9 @@ layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const
         o.y = fmaf(a[v].y * rstd, gm[v].y, bt[v].y);
         o.z = fmaf(a[v].z * rstd, gm[v].z, bt[v].z);
         o.w = fmaf(a[v].w * rstd, gm[v].w, bt[v].w);
+        if (relu) {                              // conv -> norm -> ReLU of the stem (octformer_layers.py:80-98) in one pass
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
         if (SPLIT == 1)
           hfl_store_split3(reinterpret_cast<uint16_t*>(h_out) + r * 3 * C, C, v * TPR + tx, o);
         else if (SPLIT == 2)
@@ -326,26 +329,27 @@ layer_norm_kernel(float* __restrict__ h_out, float* x_out, const float* x, const
 
 template <int TPR, int VPL>
 static int launch_ln(float* h_out, float* x_out, const float* x, const float* y, const float* bias,
-                     const float* gamma, const float* beta, int64_t n, float eps, int split,
+                     const float* gamma, const float* beta, int64_t n, float eps, int split_flags,
                      hipStream_t s) {
+  const int split = split_flags & 0xF, relu = (split_flags >> 4) & 1;
   constexpr int RPB = 256 / TPR;
   const int64_t need = hfl_cdiv(n, RPB);
-  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  const int64_t cap = (int64_t)hfl_stream_cus(s) * 16;
   const int blocks = (int)(need < cap ? need : cap);
   if (y != nullptr) {
     if (split == 2)
-      layer_norm_kernel<TPR, VPL, true, 2><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, true, 2><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps, relu);
     else if (split)
-      layer_norm_kernel<TPR, VPL, true, 1><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, true, 1><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps, relu);
     else
-      layer_norm_kernel<TPR, VPL, true, 0><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, true, 0><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps, relu);
   } else {
     if (split == 2)
-      layer_norm_kernel<TPR, VPL, false, 2><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, false, 2><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps, relu);
     else if (split)
-      layer_norm_kernel<TPR, VPL, false, 1><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, false, 1><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps, relu);
     else
-      layer_norm_kernel<TPR, VPL, false, 0><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps);
+      layer_norm_kernel<TPR, VPL, false, 0><<<blocks, 256, 0, s>>>(h_out, x_out, x, y, bias, gamma, beta, n, eps, relu);
   }
   HFL_RETURN_LAST_ERROR();
 }
@@ -517,7 +521,7 @@ static int launch_eltwise(void* out, const float* a, const float* b, const float
   if (n < 0 || C <= 0 || C % 4 != 0) return HFL_EINVAL;
   if (n == 0) return HFL_OK;
   const int64_t need = hfl_cdiv(n * (C / 4), 256);
-  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  const int64_t cap = (int64_t)hfl_stream_cus(s) * 16;
   eltwise_kernel<MODE><<<(int)(need < cap ? need : cap), 256, 0, s>>>(out, a, b, bias, n, (int)C);
   HFL_RETURN_LAST_ERROR();
 }
@@ -534,7 +538,7 @@ int hfl_octree_gather(float* out, const float* data, const int32_t* neigh, int64
   const int vec = (channels % 4 == 0) ? 4 : 1;
   const int64_t total = n_out * kngh * (channels / vec);
   const int64_t need = hfl_cdiv(total, 256);
-  const int64_t cap = (int64_t)hfl_num_cus() * 16;
+  const int64_t cap = (int64_t)hfl_stream_cus(s) * 16;
   const int blocks = (int)(need < cap ? need : cap);
   if (vec == 4)
     gather_kernel<4><<<blocks, 256, 0, s>>>(out, data, neigh, n_out, kngh, (int)channels);
@@ -602,6 +606,16 @@ int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, con
   if (n_rows < 0 || channels % 32 != 0) return HFL_EINVAL;
   return dispatch_ln(reinterpret_cast<float*>(out), nullptr, x, nullptr, nullptr, gamma, beta, n_rows,
                      channels, eps, 2, static_cast<hipStream_t>(stream));
+}
+
+/* ReLU(LayerNorm(x)): the norm -> ReLU pair behind every stem convolution (models/layers/octformer_layers.py:80-98) in one
+ * pass, as f32 rows (out_f32) or as the split2 operand of the next convolution's GEMM (out_split2); exactly one is set. */
+int hfl_layer_norm_relu(float* out_f32, uint16_t* out_split2, const float* x, const float* gamma, const float* beta,
+                        int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream) {
+  if (n_rows < 0 || (out_f32 == nullptr) == (out_split2 == nullptr)) return HFL_EINVAL;
+  if (out_split2 != nullptr && channels % 32 != 0) return HFL_EINVAL;
+  return dispatch_ln(out_f32 != nullptr ? out_f32 : reinterpret_cast<float*>(out_split2), nullptr, x, nullptr, nullptr, gamma,
+                     beta, n_rows, channels, eps, (out_split2 != nullptr ? 2 : 0) | 0x10, static_cast<hipStream_t>(stream));
 }
 
 int hfl_add_layer_norm_split3(float* x_out, uint16_t* h_out, const float* x, const float* y,

@@ -99,6 +99,14 @@ _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: 
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
 _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
 _MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
+# CUs of the finest pyramid level's stream during the H-OSA iterations; the coarse levels and the relay-token self-attention
+# share the rest of the chip (CU-masked HIP streams, hfl_stream_create_cu_mask).  0 (default): plain streams, everybody
+# competes for every CU.  Why it exists: on plain streams the finest level's persistent kernels (one workgroup per CU, 135 KB of
+# LDS) and the coarse levels' launches block each other -- a depth-4 fused MLP launch took 410 us beside them against 258 us
+# alone, a depth-3 fc2 GEMM 245 us against 25.  Why it is off: measured, the partition removes the
+# interference but not the work -- on 192 CUs the finest level's kernels take 256/192 of their time alone, the relay-token
+# chain on the shared 64 CUs gets slower and stalls the finest level longer: 940 us per iteration either way.
+_CU_PARTITION = int(os.environ.get('HFL_CU_PARTITION', '0'))
 
 
 def set_train_split(enabled: bool):
@@ -120,6 +128,32 @@ def set_attention_f16(enabled: bool):
 
 
 _SERIAL_STREAMS = False
+
+
+def set_cu_partition(big_cus: int):
+    """CUs given to the finest pyramid level's stream inside the H-OSA iterations (multiple of 8; 0 = no partition)."""
+    global _CU_PARTITION
+    assert big_cus == 0 or (big_cus % 8 == 0 and 8 <= big_cus)
+    _CU_PARTITION = int(big_cus)
+
+
+_MASKED_STREAMS = {}     # (device index, first bit, bits, tag) -> torch.cuda.ExternalStream over a CU-masked HIP stream
+
+
+def _masked_stream(device, first_bit: int, n_bits: int, tag: str):
+    import ctypes
+    from . import _native
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, first_bit, n_bits, tag)
+    st = _MASKED_STREAMS.get(key)
+    if st is None:
+        with torch.cuda.device(idx):
+            h = ctypes.c_void_p()
+            ops.check(_native.load().hfl_stream_create_cu_mask(ctypes.byref(h), first_bit, n_bits), 'hfl_stream_create_cu_mask')
+            st = torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx))
+        _MASKED_STREAMS[key] = st
+    return st
 
 
 def set_pyramid_streams(enabled):
@@ -189,11 +223,13 @@ def _mlp_pack(mlp: 'MLP', rows: int):
     return hit[3]
 
 
-# LN1 -> qkv of the token rows as ONE launch (csrc/qkv_fused.hip).  Worth it where the launch's workgroup passes are well
-# filled: C = 128 from 24 576 rows on (118 096 rows: 71 vs 96 us for LayerNorm + qkv GEMM), C = 256 only when the last round of
-# 32 768 rows is at least half full (65 536 rows: 103 vs 114-122 us, but 66 775 rows -- 2.04 rounds, three passes -- 153 vs 127)
+# LN1 -> qkv of the token rows as ONE launch (csrc/qkv_fused.hip) from 24 576 rows on (C = 128, 118 096 rows: 71 vs 96 us for
+# LayerNorm + qkv GEMM; C = 256, 65 536 rows: 95 vs 114-122 us).  Round 3 skipped C = 256 shapes whose last round of 32 768 rows
+# was less than half full (66 775 rows, 2.04 rounds: three passes, 153 vs 127 us); since the left-over rows are computed with
+# the output features split over the workgroups (round 4) that shape takes 101 us and the restriction is gone
+# (HFL_QKV_FUSED_MIN_FILL restores it).
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
-_QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.5'))
+_QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
 
 
 def _qkv_pack(att: 'OctreeAttention', rows: int):
@@ -412,7 +448,17 @@ class OctreeConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
         nn.init.xavier_uniform_(self.weights)
 
+    def takes_split2(self) -> bool:
+        """Inference: does forward() run the grouped split-precision GEMM over the live taps, i.e. can it take the split2
+        form of its input (rows, 2 Cin) bf16 instead of fp32 rows?"""
+        return (_SPARSE_CONV and (self.kernel, self.stride) in (('333', 1), ('222', 2)) and self.in_channels >= 32
+                and _GROUPED_TAPS and _GEMM_MODE == 'x3' and self.in_channels % 32 == 0
+                and (self.out_channels % 128 == 0 or self.out_channels == 64) and not _grad_path())
+
     def forward(self, data: torch.Tensor, octree, depth: int):
+        if data.dtype == torch.bfloat16:                 # split2 rows from the previous layer's fused norm + ReLU
+            assert self.takes_split2() and data.shape[1] == 2 * self.in_channels
+            return self._forward_live_taps(data, octree, depth)
         if (_SPARSE_CONV and (self.kernel, self.stride) in (('333', 1), ('222', 2)) and self.in_channels >= 32
                 and data.is_cuda):
             if not _grad_path(data):
@@ -441,7 +487,8 @@ class OctreeConv(nn.Module):
             # (a split2 row is Cin 4-byte cells, so the same gather kernel moves it), row tiles never straddle a tap and
             # carry the offset of their tap's weight block
             npad = max(self.out_channels, 128)
-            gs = ops.octree_gather(ops.split2(data).view(torch.float32), src).view(torch.bfloat16)
+            d2 = data if data.dtype == torch.bfloat16 else ops.split2(data)
+            gs = ops.octree_gather(d2.view(torch.float32), src).view(torch.bfloat16)
             part = ops.linear_x3_grouped(gs, self._tap_weights_split2(npad),
                                          octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
             out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
@@ -508,8 +555,13 @@ class OctreeConvNormRelu(nn.Module):
         self.conv = OctreeConv(in_channels, out_channels, kernel_size, stride, nempty=True)
         self.norm = nn.LayerNorm(out_channels)
 
-    def forward(self, data, octree, depth):
-        return F.relu_(_ln(self.conv(data, octree, depth), self.norm))
+    def forward(self, data, octree, depth, split2_out: bool = False):
+        """`split2_out` (inference): return the split2 operand of the next convolution's GEMM instead of fp32 rows."""
+        y = self.conv(data, octree, depth)
+        if y.is_cuda and not _grad_path(y) and y.shape[-1] in ops._LN_CHANNELS:
+            return ops.layer_norm_relu(y, self.norm.weight, self.norm.bias, self.norm.eps, split2=split2_out)
+        assert not split2_out
+        return F.relu_(_ln(y, self.norm))
 
 
 class PatchEmbed(nn.Module):
@@ -535,10 +587,17 @@ class PatchEmbed(nn.Module):
             for i in range(self.num_stages):
                 data = self.convs[i](data, octree, depth)
             return data
+        # (inference: a layer whose successor runs the grouped split-precision GEMM hands it the split2 rows directly --
+        # norm + ReLU + split in one pass instead of three)
+        seq = []
         for i in range(self.num_stages):
-            data = self.convs[i](data, octree, depth - i)
-            data = self.downsamples[i](data, octree, depth - i)
-        return self.proj(data, octree, depth - self.num_stages)
+            seq += [(self.convs[i], depth - i), (self.downsamples[i], depth - i)]
+        seq.append((self.proj, depth - self.num_stages))
+        fast = data.is_cuda and not _grad_path(data)
+        for n, (m, d) in enumerate(seq):
+            nxt = seq[n + 1][0].conv if n + 1 < len(seq) else None
+            data = m(data, octree, d, split2_out=bool(fast and nxt is not None and nxt.takes_split2()))
+        return data
 
 
 class Downsample(nn.Module):
@@ -987,8 +1046,10 @@ class RelayTokenTransformerBlock(nn.Module):
         if (all(p is not None and p.dtype == torch.float32 and p.is_contiguous() and p.device == device for p in plist)
                 and self.norm1.eps == self.norm2.eps and att.dim % 128 == 0 and att.num_heads * 16 == att.dim):
             from ._native import RelayBlockWeights
-            keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2))
+            mpack = _mlp_pack(mlp, _MLP_FUSED_MIN_ROWS) if att.dim in (128, 256) else None   # any row count: hidden split
+            keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2), mpack)
             w = RelayBlockWeights(channels=att.dim, n_heads=att.num_heads, eps=self.norm1.eps,
+                                  mlp_pack=None if mpack is None else mpack.data_ptr(),
                                   norm1_gamma=self.norm1.weight.data_ptr(), norm1_beta=self.norm1.bias.data_ptr(),
                                   norm2_gamma=self.norm2.weight.data_ptr(), norm2_beta=self.norm2.bias.data_ptr(),
                                   qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(), fc1_w=keep[2].data_ptr(),
@@ -1114,6 +1175,18 @@ class HOTFormerStage(nn.Module):
             self._streams = [torch.cuda.Stream(device=device) for _ in range(self.num_pyramid_levels - 1)]
         return self._streams
 
+    def _partition(self, device):
+        """(finest level's stream, coarse levels' streams, RTSA stream) over disjoint CU masks, or None when the partition
+        is off / does not fit this device."""
+        big = _CU_PARTITION
+        total = torch.cuda.get_device_properties(device).multi_processor_count
+        if big <= 0 or big + 8 > total:
+            return None
+        rest = total - big
+        return (_masked_stream(device, 0, big, 'big'),
+                [_masked_stream(device, big, rest, 'side%d' % j) for j in range(self.num_pyramid_levels - 1)],
+                _masked_stream(device, big, rest, 'rtsa'))
+
     def _rtsa_stream(self, device):
         if self.__dict__.get('_rtsa_st') is None:
             # high priority: RTSA is a chain of eight tiny launches that must slip in between the chip-filling kernels of the
@@ -1164,6 +1237,21 @@ class HOTFormerStage(nn.Module):
             return out, (self.up_projections[j][i](out[nt:]) if proj else out[nt:])
 
         early = _EARLY_PHASE and _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda and not ckpt
+        # CU partition: the whole loop runs with the finest level's CU-masked stream as the "main" one (forked from the caller's
+        # stream here, joined after the last iteration); the coarse levels and RTSA get streams over the other CUs.
+        part = self._partition(data.device) if (early and not _SERIAL_STREAMS) else None
+        caller = torch.cuda.current_stream() if part is not None else None
+        if part is not None:
+            part[0].wait_stream(caller)
+        with (torch.cuda.stream(part[0]) if part is not None else contextlib.nullcontext()):
+            local, rts = self._iterations(data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa, part)
+        if part is not None:
+            caller.wait_stream(part[0])
+            for t in list(local.values()) + list(rts.values()):        # allocated on the masked stream, consumed by the caller's
+                t.record_stream(caller)
+        return local, rts
+
+    def _iterations(self, data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa, part):
         for i in range(self.num_blocks):                                # 593-633
             if early:
                 # RTSA of iteration i only feeds the relay rows: what a block does with its TOKEN rows before the window
@@ -1171,8 +1259,8 @@ class HOTFormerStage(nn.Module):
                 # part on its own stream first, RTSA runs beside it on a stream of its own, the rest of the block follows
                 # once both are done -- the ~120 us chain of eight tiny RTSA launches leaves the critical path.
                 main = torch.cuda.current_stream()
-                side = [main] * (len(depths) - 1) if _SERIAL_STREAMS else self._side_streams(data.device)
-                rs = main if _SERIAL_STREAMS else self._rtsa_stream(data.device)
+                side = [main] * (len(depths) - 1) if _SERIAL_STREAMS else (part[1] if part else self._side_streams(data.device))
+                rs = main if _SERIAL_STREAMS else (part[2] if part else self._rtsa_stream(data.device))
                 small = [not (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) for j, d in enumerate(depths)]
                 sts = [side[j - 1] if small[j] else main for j in range(len(depths))]
                 # issue order = critical path first (the host runs only just ahead of the GPU here): the finest level's
@@ -1383,11 +1471,16 @@ class AdaptivePooling(nn.Module):
             return ag.attentional_pooling_torch(x, self.query, plan, depth, self.scale)
         scores = torch.mm(x, self.query.t())                              # (N_t, k)
         ops.segment_softmax_(scores, plan.cloud_off[depth], plan.B, self.scale)
-        idx = plan.pad_index[depth]
-        zero = x.new_zeros(1, x.shape[1])
-        xp = torch.cat([x, zero], 0).index_select(0, idx).view(plan.B, -1, x.shape[1])
-        pp = torch.cat([scores, scores.new_zeros(1, scores.shape[1])], 0) \
-            .index_select(0, idx).view(plan.B, -1, scores.shape[1])
+        nmax = plan.pad_index[depth].numel() // plan.B
+        if scores.shape[1] % 4 == 0:                     # per-cloud zero-padded copies in one pass each (hfl_pad_rows)
+            xp = ops.pad_rows(x, plan.cloud_off[depth], plan.B, nmax)
+            pp = ops.pad_rows(scores, plan.cloud_off[depth], plan.B, nmax)
+        else:
+            idx = plan.pad_index[depth]
+            zero = x.new_zeros(1, x.shape[1])
+            xp = torch.cat([x, zero], 0).index_select(0, idx).view(plan.B, -1, x.shape[1])
+            pp = torch.cat([scores, scores.new_zeros(1, scores.shape[1])], 0) \
+                .index_select(0, idx).view(plan.B, -1, scores.shape[1])
         return torch.bmm(pp.transpose(1, 2), xp)
 
 
@@ -1407,6 +1500,12 @@ class FeatureMixerLayer(nn.Module):
         return x + self.mix(x)
 
 
+def _mixer_layer_fits(m) -> bool:
+    ln, fc1, act, fc2 = m.mix
+    return (isinstance(ln, nn.LayerNorm) and isinstance(act, nn.GELU) and fc1.in_features % 128 == 0
+            and fc1.out_features % 128 == 0 and fc2.out_features % 128 == 0 and fc1.bias is not None and fc2.bias is not None)
+
+
 class Mixer(nn.Module):
     """models/layers/salsa.py:78-111"""
 
@@ -1417,7 +1516,20 @@ class Mixer(nn.Module):
         self.channel_proj = nn.Linear(k_input_tokens, k_output_tokens)
 
     def forward(self, x):
-        x = self.mix(x)
+        if _split_path(x) and x.shape[-1] % 128 == 0 and all(_mixer_layer_fits(m) for m in self.mix):
+            # inference: every FeatureMixerLayer as LayerNorm -> split2, fc1 + GELU, fc2 + residual on the hand-written split GEMM
+            # (three launches instead of LayerNorm, addmm, GELU, addmm, add: the (B k, C) token matrix is 8 k rows, every one of
+            # these launches is latency-bound and the host was issuing them into an idle GPU)
+            b, k, c = x.shape
+            x2 = x.reshape(b * k, c)
+            for m in self.mix:
+                ln, fc1, _, fc2 = m.mix
+                h2 = ops.layer_norm_split2(x2, ln.weight, ln.bias, ln.eps)
+                g2 = ops.linear_x3(h2, _w2(fc1), bias=fc1.bias, gelu_split_out=True)
+                x2 = ops.linear_x3(g2, _w2(fc2), bias=fc2.bias, residual=x2)
+            x = x2.view(b, k, c)
+        else:
+            x = self.mix(x)
         x = self.channel_proj(x.permute(0, 2, 1)).permute(0, 2, 1)
         return self.row_proj(x).flatten(1)
 

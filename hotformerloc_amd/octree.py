@@ -71,6 +71,18 @@ def _split_ranges(edges: np.ndarray, step: int):
     return rid, first, np.minimum(step, edges[rid + 1] - first)
 
 
+_TAP_STREAMS = {}
+
+
+def _tap_stream(device):
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _TAP_STREAMS.get(idx)
+    if st is None:
+        st = _TAP_STREAMS[idx] = torch.cuda.Stream(device=torch.device('cuda', idx), priority=-1)
+    return st
+
+
 class Octree:
     def __init__(self, depth: int, full_depth: int = 2, batch_size: int = 1,
                  device: Union[torch.device, str] = 'cpu', **kwargs):
@@ -177,6 +189,9 @@ class Octree:
                 self.neighs[d] = ops.octree_neigh(self.neighs[d - 1] if d > self.full_depth else None,
                                                   self.nidx[d], self.children[d], self.nkeys[d],
                                                   d, self.full_depth)
+        if fresh and self.device.type == 'cuda':
+            # what the live-tap kernels (on a stream of their own, below) have to wait for: these tables, not the whole stream
+            self.__dict__['_neigh_event'] = torch.cuda.current_stream(self.device).record_event()
         if (fresh or '_sparse_taps' not in self.__dict__) and self.device.type == 'cuda':
             lo = max(self.full_depth + 1, 3)
             keys = [(d, '333', 1) for d in range(lo, self.depth)] + [(d, '222', 2) for d in range(lo, self.depth + 1)]
@@ -320,17 +335,32 @@ class Octree:
             return
         if pending:
             self._finish_tap_lists()
-        tables = [self.get_neigh(d, kern, st, nempty=True).contiguous() for d, kern, st in todo]
-        taps = [t.shape[1] for t in tables]
-        edges_all = torch.empty(sum(n + 1 for n in taps), dtype=torch.int32, device=self.device)
-        built, off = [], 0
-        for t, n in zip(tables, taps):
-            built.append(ops.tap_lists(t, edges_all[off:off + n + 1]))
-            off += n + 1
-        host = torch.empty(edges_all.numel(), dtype=torch.int32, pin_memory=True)
-        host.copy_(edges_all, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        # The lists depend on the neighbour tables only, and the host needs their per-tap counts (one read) before it can size
+        # the convolutions' buffers.  On the caller's stream the kernels would queue behind whatever the GPU is still running
+        # (the previous forward's tail) and the host would wait for all of it, then issue the next forward into an idle GPU --
+        # ~1 ms of launch-latency bubbles per step.  On a high-priority stream of their own (ordered behind the tables by an
+        # event) the counts arrive while the GPU is still busy, and the host never falls behind.
+        cur = torch.cuda.current_stream(self.device)
+        st = _tap_stream(self.device)
+        nev = self.__dict__.get('_neigh_event')
+        if nev is not None:
+            st.wait_event(nev)
+        else:
+            st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            tables = [self.get_neigh(d, kern, stride, nempty=True).contiguous() for d, kern, stride in todo]
+            taps = [t.shape[1] for t in tables]
+            edges_all = torch.empty(sum(n + 1 for n in taps), dtype=torch.int32, device=self.device)
+            edge_views, off = [], 0
+            for n in taps:
+                edge_views.append(edges_all[off:off + n + 1])
+                off += n + 1
+            built = []
+            for i in range(0, len(tables), 16):                      # every table of the batch in three launches
+                built += ops.tap_lists_multi(tables[i:i + 16], edge_views[i:i + 16])
+            host = torch.empty(edges_all.numel(), dtype=torch.int32, pin_memory=True)
+            host.copy_(edges_all, non_blocking=True)
+            ev = st.record_event()
         self.__dict__['_taps_pending'] = (todo, built, taps, host, ev, edges_all)
 
     def _finish_tap_lists(self):
@@ -339,6 +369,12 @@ class Octree:
             return
         todo, built, taps, host, ev, edges_all = pending
         ev.synchronize()                                                  # the one host read
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)                                                # consumers run on the caller's stream
+        edges_all.record_stream(cur)
+        for src, slot, _ in built:
+            src.record_stream(cur)
+            slot.record_stream(cur)
         host = host.tolist()
         cache = self.__dict__.setdefault('_sparse_taps', {})
         dev_edges = self.__dict__.setdefault('_tap_edges_dev', {})

@@ -372,6 +372,23 @@ def layer_norm_split2(x, weight, bias, eps: float = 1e-5):
     return out
 
 
+def layer_norm_relu(x, weight, bias, eps: float = 1e-5, split2: bool = False):
+    """relu(LN(x)) in one pass (hfl_layer_norm_relu): fp32 rows, or -- `split2` -- the bf16 split2 operand (rows, 2C) of the
+    next convolution's GEMM."""
+    _dev(x, weight, bias)
+    c = x.shape[-1]
+    x2 = _f32c(x).view(-1, c)
+    if split2:
+        out = torch.empty((x2.shape[0], 2 * c), dtype=torch.bfloat16, device=x.device)
+    else:
+        out = torch.empty_like(x2)
+    with _timed('hfl_layer_norm_relu', x2.numel() * 8):
+        check(_native.load().hfl_layer_norm_relu(None if split2 else out.data_ptr(), out.data_ptr() if split2 else None,
+                                                 x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), x2.shape[0], c,
+                                                 float(eps), _stream()), 'hfl_layer_norm_relu')
+    return out
+
+
 def split2_weight(w: torch.Tensor) -> torch.Tensor:
     """(N, K) fp32 Linear weight -> split2 bf16 (N, 2K) (host-side layout, once per parameter)."""
     w = w.detach().float()
@@ -728,6 +745,30 @@ def tap_lists(table: torch.Tensor, edges_out: torch.Tensor = None):
     return src, slot, edges
 
 
+def tap_lists_multi(tables, edges_outs):
+    """`tap_lists` for up to 16 tables in three launches in all (hfl_tap_lists_multi): [(src, slot, edges)] per table."""
+    import ctypes
+    lib = _native.load()
+    n = len(tables)
+    assert 1 <= n <= 16 and len(edges_outs) == n
+    _dev(*tables)
+    dev = tables[0].device
+    out, ws = [], []
+    for t, e in zip(tables, edges_outs):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.dim() == 2
+        rows, taps = t.shape
+        assert e.dtype == torch.int32 and e.numel() == taps + 1 and e.is_contiguous()
+        out.append((torch.empty(max(rows * taps, 1), dtype=torch.int32, device=dev),
+                    torch.empty((rows, taps), dtype=torch.int32, device=dev), e))
+        ws.append(torch.empty(int(lib.hfl_tap_lists_workspace(rows, taps)), dtype=torch.uint8, device=dev))
+    ptr = lambda xs: (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])            # noqa: E731
+    rows = (ctypes.c_int64 * n)(*[t.shape[0] for t in tables])
+    taps = (ctypes.c_int32 * n)(*[t.shape[1] for t in tables])
+    check(lib.hfl_tap_lists_multi(n, ptr([o[0] for o in out]), ptr([o[1] for o in out]), ptr([o[2] for o in out]),
+                                  ptr(tables), rows, taps, ptr(ws), _stream()), 'hfl_tap_lists_multi')
+    return out
+
+
 def tap_tiles(edges_dev: torch.Tensor, n_tiles: int, taps: int, w_rows: int, tile_rows: int = 128):
     """(n_tiles, 3) int32 row-tile table of `linear_x3_grouped` from the device-side tap edges (hfl_tap_tiles)."""
     _dev(edges_dev)
@@ -745,6 +786,17 @@ def pad_index(row_off: torch.Tensor, batch: int, nmax: int):
     assert row_off.dtype == torch.int64 and row_off.numel() == batch + 1
     out = torch.empty(batch * nmax, dtype=torch.int64, device=row_off.device)
     check(_native.load().hfl_pad_index(out.data_ptr(), row_off.data_ptr(), batch, nmax, _stream()), 'hfl_pad_index')
+    return out
+
+
+def pad_rows(x: torch.Tensor, row_off: torch.Tensor, batch: int, nmax: int):
+    """(batch, nmax, C) zero-padded per-cloud copy of the ragged rows x (N, C) (hfl_pad_rows)."""
+    _dev(x, row_off)
+    x = _f32c(x)
+    assert row_off.dtype == torch.int64 and row_off.numel() == batch + 1 and x.shape[1] % 4 == 0
+    out = torch.empty((batch, nmax, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(_native.load().hfl_pad_rows(out.data_ptr(), x.data_ptr(), row_off.data_ptr(), batch, nmax, x.shape[1], _stream()),
+          'hfl_pad_rows')
     return out
 
 

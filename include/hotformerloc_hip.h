@@ -28,6 +28,14 @@ extern "C" {
 
 typedef void* hfl_stream_t; /* hipStream_t */
 
+/* CU-partitioned streams (no reference counterpart: the reference runs its three pyramid depths on plain CUDA streams,
+ * models/hotformerloc_backbone.py:28-53,604-633).  hfl_stream_create_cu_mask makes a HIP stream restricted to the CUs of mask
+ * bits [first_bit, first_bit + n_bits) (both multiples of 8: n_bits / 8 CUs of every XCD); every launcher of this library
+ * sizes its persistent grids by the CU count of the stream it is given.  Used to run the finest pyramid level's chip-filling
+ * kernels and the coarse levels' / relay tokens' latency-bound launches side by side without competing for CUs. */
+int hfl_stream_create_cu_mask(hfl_stream_t* out, int first_bit, int n_bits);
+int hfl_stream_destroy(hfl_stream_t stream);
+
 #define HFL_OK 0
 #define HFL_EINVAL (-1)      /* unsupported shape / argument            */
 #define HFL_ECAPACITY (-2)   /* input exceeds a documented kernel limit */
@@ -169,12 +177,20 @@ int hfl_octree_gather(float* out, const float* data, const int32_t* neigh, int64
 int64_t hfl_tap_lists_workspace(int64_t rows, int taps);
 int hfl_tap_lists(int32_t* src, int32_t* slot, int32_t* edges, const int32_t* table, int64_t rows, int taps,
                   void* workspace, hfl_stream_t stream);
+/* The same for n <= 16 tables in THREE launches in all (count, scan, fill over every table: the convolution depths of one
+ * batch); arrays of n pointers / sizes, workspace[i] = hfl_tap_lists_workspace(rows[i], taps[i]) bytes. */
+int hfl_tap_lists_multi(int n, int32_t* const* src, int32_t* const* slot, int32_t* const* edges, const int32_t* const* table,
+                        const int64_t* rows, const int32_t* taps, void* const* workspace, hfl_stream_t stream);
 /* Row tiles of the grouped tap GEMM (section 9b, hfl_linear_x3_grouped) from the device-side tap edges hfl_tap_lists wrote:
  * tiles (n_tiles, 3) int32 = {first pair, pairs (<= tile_rows), tap * w_rows}, n_tiles = sum_k ceil(pairs_k / tile_rows). */
 int hfl_tap_tiles(int32_t* tiles, const int32_t* edges, int taps, int tile_rows, int w_rows, hfl_stream_t stream);
 /* Padded gather index of a ragged per-cloud row stream (pooling head, models/layers/pooling.py:209-233): out (batch * nmax)
  * int64, row_off[b] + j inside cloud b, row_off[batch] (a zero row the caller appends) beyond it. */
 int hfl_pad_index(int64_t* out, const int64_t* row_off, int batch, int64_t nmax, hfl_stream_t stream);
+/* The padded copy itself in one pass: out (batch, nmax, channels) f32, rows of cloud b = x[row_off[b] ..), zeros beyond
+ * (the per-cloud split + zero padding of models/layers/pooling.py:209-233 without an index table or an appended zero row). */
+int hfl_pad_rows(float* out, const float* x, const int64_t* row_off, int batch, int64_t nmax, int64_t channels,
+                 hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Windowed multi-head attention over z-order octree windows
@@ -400,6 +416,10 @@ int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_spl
 /* split2(LayerNorm(x)) in one pass (the LayerNorm in front of qkv / fc1: models/octformer_backbone.py:275-278) */
 int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, const float* beta,
                           int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
+/* ReLU(LayerNorm(x)) in one pass: f32 rows (out_f32) or the split2 operand of the next GEMM (out_split2); exactly one of
+ * the two is non-NULL.  Replaces norm -> relu behind every stem convolution (models/layers/octformer_layers.py:80-98). */
+int hfl_layer_norm_relu(float* out_f32, uint16_t* out_split2, const float* x, const float* gamma, const float* beta,
+                        int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
 
 /* 9c. The pre-norm MLP branch of a transformer block as ONE launch (csrc/mlp_fused.hip):
  *       out (n_rows, C) = x + fc2(gelu(fc1(LayerNorm(x; gamma, beta, eps)) + b1)) + b2        fc1: C -> 4C, fc2: 4C -> C
@@ -520,6 +540,8 @@ typedef struct hfl_relay_block_weights {
   const float *norm1_gamma, *norm1_beta, *norm2_gamma, *norm2_beta;
   const uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;     /* split2 */
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
+  const void* mlp_pack;                                /* hfl_mlp_fused_pack image of (fc1, fc2) or NULL: when set (C = 128 / 256) the MLP
+                                                          branch is ONE launch (hfl_ln_mlp_fused_ws) and fc1_w / fc2_w are not read */
 } hfl_relay_block_weights;
 typedef struct hfl_relay_block_io {
   const float* x_in;

@@ -152,6 +152,24 @@ def test_tap_lists_match_tap_major_compaction(rows, taps):
     assert torch.equal(slot.cpu(), want_slot)
 
 
+def test_tap_lists_multi_equals_single_table_calls():
+    """hfl_tap_lists_multi: the tables of every convolution depth of a batch in three launches in all -- the same lists as
+    one hfl_tap_lists call per table (27-tap, 8-tap and odd-width tables, one of them a single row), bit-exact."""
+    g = torch.Generator().manual_seed(11)
+    tables = []
+    for rows, taps in ((70001, 27), (5000, 8), (1, 27), (2049, 8), (3000, 5), (130000, 27)):
+        t = torch.randint(0, max(rows, 2), (rows, taps), generator=g, dtype=torch.int32)
+        t[torch.rand((rows, taps), generator=g) < 0.75] = -1
+        tables.append(t.to(DEV))
+    edges = [torch.empty(t.shape[1] + 1, dtype=torch.int32, device=DEV) for t in tables]
+    multi = ops.tap_lists_multi(tables, edges)
+    for t, (src, slot, e) in zip(tables, multi):
+        src1, slot1, e1 = ops.tap_lists(t)
+        assert torch.equal(e, e1) and torch.equal(slot, slot1)
+        n = int(e1[-1])
+        assert torch.equal(src[:n], src1[:n])
+
+
 def test_octree_sparse_taps_built_with_the_neighbour_tables():
     """construct_all_neigh() launches the live-tap lists of all octree convolutions and starts ONE asynchronous device->host
     read of their counts; the first sparse_taps() collects it for every table at once, nothing else is built later."""
@@ -511,6 +529,23 @@ def test_layer_norm_and_fused_add():
     x3 = torch.randn(4, 37, 256, generator=g)
     got = ops.layer_norm(x3.to(DEV), torch.ones(256, device=DEV), torch.zeros(256, device=DEV)).cpu()
     assert torch.allclose(got, torch.nn.functional.layer_norm(x3, (256,)), atol=2e-6, rtol=1e-5)
+
+
+def test_layer_norm_relu_f32_and_split2():
+    """hfl_layer_norm_relu (norm -> ReLU behind every stem convolution, octformer_layers.py:80-98, in one pass): the fp32 form
+    equals relu(LayerNorm) of the two-launch form bit for bit, the split2 form equals split2 of it bit for bit."""
+    g = torch.Generator().manual_seed(16)
+    for n, C in ((1000, 32), (4099, 64), (777, 128), (9, 256)):
+        x = (torch.randn(n, C, generator=g) * 3 + 0.5).to(DEV)
+        w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+        b = (0.1 * torch.randn(C, generator=g)).to(DEV)
+        two = torch.relu(ops.layer_norm(x, w, b))
+        one = ops.layer_norm_relu(x, w, b)
+        assert torch.equal(one, two), (n, C)
+        assert (one >= 0).all() and (one == 0).any()
+        s2 = ops.layer_norm_relu(x, w, b, split2=True)
+        assert s2.dtype == torch.bfloat16 and tuple(s2.shape) == (n, 2 * C)
+        assert torch.equal(s2.view(torch.int16), ops.split2(two).view(torch.int16)), (n, C)
 
 
 def test_split_precision_linear_path():
@@ -933,7 +968,6 @@ def test_ln_mlp_fused_tail_split_equals_whole_passes(C, n):
     x = (torch.randn(n, C, generator=g) * 2).to(DEV)
     ws = int(lib.hfl_ln_mlp_fused_workspace(n, C))
     assert ws > 0, 'this shape has left-over rows: the split must apply'
-    assert int(lib.hfl_ln_mlp_fused_workspace(256 * (8 if C == 256 else 16) * 16 * 2, C)) == 0     # whole rounds: no workspace
     split = ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2)
     assert torch.equal(split, ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2))
     try:

@@ -1,7 +1,7 @@
 """Wall-clock phases of the last traced forward of the default bench step, from a rocprofv3 --kernel-trace CSV (all queues):
 per-batch tables + stem -> depth-5 OctFormer stage -> pyramid init -> each H-OSA iteration -> pooling head, with, per phase, the
 busy time of the main queue and the kernels that took the most of it.
-    python tools/forward_phases.py <kernel_trace.csv>"""
+    python tools/forward_phases.py <kernel_trace.csv> [phase name substring: dump that phase kernel by kernel]"""
 import collections
 import csv
 import re
@@ -68,6 +68,14 @@ def main():
             tot[short(r['Kernel_Name'])] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         top = ', '.join('%s %.0f' % (k, v / 1e3) for k, v in tot.most_common(6))
         print('%-44s %8.1f us wall  main queue busy %7.1f us  %3d kernels | %s' % (name, (b - a) / 1e3, busy / 1e3, len(ks), top))
+        if len(sys.argv) > 2 and sys.argv[2] in name:          # kernel by kernel: start offset, duration, queue, grid
+            qs = {}
+            for r in ks:
+                q = qs.setdefault(r['Queue_Id'], len(qs))
+                print('    +%8.1f us %7.1f us  q%d  grid %-8s wg %-5s %s' % (
+                    (int(r['Start_Timestamp']) - a) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, q,
+                    r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')),
+                    short(r['Kernel_Name'])))
 
 
 if __name__ == '__main__':
