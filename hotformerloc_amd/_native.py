@@ -126,6 +126,8 @@ SIGNATURES = {
     'hfl_relay_block_forward_x3_arena': (c_int64, [c_int64, c_int64]),
     'hfl_relay_block_forward_x3': (c_int, [c_void_p, c_void_p, c_void_p]),
     'hfl_linear_x3_grouped': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    'hfl_linear_x3_grouped_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                     c_int, c_void_p]),
     'hfl_split2_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_linear_x3_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_linear_x3_gelu_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -191,6 +193,12 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # probe knobs from the environment (A/B runs of bench.py): HFL_VARIANTS="key=value,key=value" -> hfl_set_variant
+    for kv in os.environ.get('HFL_VARIANTS', '').split(','):
+        if '=' in kv:
+            k, v = kv.split('=', 1)
+            if lib.hfl_set_variant(k.strip().encode(), int(v)) != 0:
+                raise NativeLibraryError('HFL_VARIANTS: unknown knob %r' % k)
     return lib
 
 

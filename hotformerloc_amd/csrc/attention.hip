@@ -1491,6 +1491,10 @@ void hfl_internal_set_mlp_stagger(int v);
 void hfl_internal_set_mlp_ring_pf(int v);
 void hfl_internal_set_qkv_ring_pf(int v);
 void hfl_internal_set_mlp_tail_split(int v);
+void hfl_internal_set_mlp_dynamic(int v);
+void hfl_internal_set_cu_reserve(int v);
+void hfl_internal_set_x3_ring(int v);
+void hfl_internal_set_qkv_dynamic(int v);
 void hfl_internal_set_qkv_tail_split(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
 int hfl_internal_attn_timing(int on) {
@@ -1544,6 +1548,17 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_qkv_ring_pf(3);
     hfl_internal_set_mlp_tail_split(1);
     hfl_internal_set_qkv_tail_split(1);
+    hfl_internal_set_mlp_dynamic(1);
+    hfl_internal_set_qkv_dynamic(1);
+    hfl_internal_set_cu_reserve(0);
+    hfl_internal_set_x3_ring(0);
+  } else if (is("x3_ring")) {
+    hfl_internal_set_x3_ring(value);
+  } else if (is("cu_reserve")) {
+    hfl_internal_set_cu_reserve(value);
+  } else if (is("dynamic_units")) {
+    hfl_internal_set_mlp_dynamic(value);
+    hfl_internal_set_qkv_dynamic(value);
   } else if (is("tail_split")) {
     hfl_internal_set_mlp_tail_split(value);
     hfl_internal_set_qkv_tail_split(value);

@@ -8,17 +8,25 @@
 namespace {
 std::mutex g_stream_mu;
 std::vector<std::pair<void*, int>> g_stream_cus;       // streams made by hfl_stream_create_cu_mask -> CUs in their mask
+int g_cu_reserve = 0;                                  // probe knob 'cu_reserve'
 }  // namespace
 
 extern "C" {
 
+// CUs a launch sizes its persistent grid for.  `cu_reserve` CUs are left out on purpose: the chip-filling kernels of the
+// finest pyramid level occupy a CU completely (8 waves x 256 VGPRs, 135-150 KB of LDS), so while one of them runs no launch
+// of another stream -- the coarse levels' and the relay tokens' short kernels -- finds a free slot anywhere; with a few CUs
+// never claimed by the persistent grids those chains keep moving.
+void hfl_internal_set_cu_reserve(int v) { g_cu_reserve = v < 0 ? 0 : v; }
+
 int hfl_internal_stream_cus(void* stream) {
+  int n = hfl_num_cus();
   if (stream != nullptr) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
     for (auto& e : g_stream_cus)
-      if (e.first == stream) return e.second;
+      if (e.first == stream) n = e.second;
   }
-  return hfl_num_cus();
+  return n - g_cu_reserve >= 8 ? n - g_cu_reserve : n;
 }
 
 // A HIP stream whose kernels run on a subset of the chip's CUs: mask bits [first_bit, first_bit + n_bits).  On gfx950 bit i

@@ -32,6 +32,7 @@
 //    share an XCD), so the row tile's activations are fetched from HBM once and re-read from that XCD's L2.
 #include "hfl_common.h"
 #include "x3_math.h"
+#include "stage_stream.h"
 
 namespace {
 
@@ -48,6 +49,8 @@ struct X3Params {
   const float* bias;        // (N) or null
   const float* residual;    // (M, N) or null (EPI 0 only; may alias out)
   const int32_t* tiles;     // grouped launch (EPI 0): per row tile {first row, rows (<= 128), first row of its W block}, or null
+  const int32_t* gather;    // grouped launch: row m of the A operand is x[gather[m]] (the live pairs' input rows: the octree
+                            // convolution's gather done by the tile loader), or null: x[m]
   const float* row_scale;   // EPI 0: (M) or null: out = (acc + bias) * row_scale[m] + residual (per-cloud stochastic depth)
   float* aux;               // EPI 3: f32 (M, N) pre-activation written next to the split2 output; EPI 4: the same, read
   int64_t M;
@@ -61,6 +64,10 @@ struct X3Params {
 };
 
 static int g_x3_dbg = 0;
+static int g_x3_ring = 0;   // probe knob 'x3_ring': the NS-stage ring kernel for launches of at most one workgroup per CU.
+                            // Off: alone it halves the time of the relay tokens' K = 1024 GEMM, inside the step it loses 3 %
+                            // (2361 -> 2442 clouds/s without it): its 128 KB of LDS need a nearly empty CU, the one-stage kernel's
+                            // 32 KB slip in beside the finest level's workgroups
 static int g_x3_nt = 0;     // measured: no end-to-end difference (the consumer kernel re-reads the output anyway)
 
 // Epilogue shared by the kernels below.  acc[i][j]: features 16 i + 4 fq .. +3 (registers) of row 16 j + frow of the
@@ -205,7 +212,8 @@ gemm_x3_kernel(const X3Params p) {
   // lane -> (row within the 8, physical slot); the slot it fills holds logical chunk t = slot ^ ((row >> 1) & 7)
   const int srow = lane >> 3, sslot = lane & 7;
   // uniform tile bases (SGPRs) + 32-bit per-lane offsets: tail rows fetch the last valid row, never stored
-  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
+  const bool gathered = p.gather != nullptr;
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + (gathered ? 0 : m0 * row_b);
   const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + w_row0 * row_b;
   const int rows_valid = (int)((m_end - m0) < BM ? (m_end - m0) : BM);
   uint32_t xoff[MT], woff[4];
@@ -214,7 +222,8 @@ gemm_x3_kernel(const X3Params p) {
     const int row = wave * (8 * MT) + i * 8 + srow;
     const int t = sslot ^ ((row >> 1) & 7);
     const int xr = row < rows_valid ? row : rows_valid - 1;
-    xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
+    // gathered: the pair's input row (the launcher checked rows * row bytes < 2^32)
+    xoff[i] = (gathered ? (uint32_t)p.gather[m0 + xr] : (uint32_t)xr) * (uint32_t)row_b + t * 16;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -281,6 +290,117 @@ gemm_x3_kernel(const X3Params p) {
   x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
 }
 
+// The same tile on a RING of NS stages for launches that put at most one workgroup on a CU (relay tokens, the coarsest
+// pyramid level: 2 k rows, 15-100 workgroups).  With one stage and nobody co-resident to cover it, every k-step is a full
+// L2 -> LDS round trip (~3.7 us: the relay tokens' fc2, K = 1024, took 120 us for 1.9 k rows); with NS - 1 stages in
+// flight the round trips overlap.  Protocol of csrc/mlp_fused.hip: at the barrier of step kt every wave has left step kt - 1,
+// so that slot takes stage kt + NS - 1; one counted vmcnt per step (this wave's own pieces of the younger stages may stay in
+// flight), fragment reads in inline asm (hipcc would wait vmcnt(0) in front of every LDS read it sees while a DMA is in
+// flight).
+template <int EPI, int NS>
+__global__ void __launch_bounds__(256, 1)
+gemm_x3_ring_kernel(const X3Params p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // NS stages: x tile | w tile each
+  constexpr int MT = 4;
+  constexpr int BM = 32 * MT;
+  constexpr int XTILE_B = BM * 128;
+  constexpr int STAGE_B = XTILE_B + XT * 128;
+  constexpr int DPS = MT + 4;                                                 // DMA instructions per wave and stage
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wm = wave & 1;
+  int64_t wg = blockIdx.x;
+  {
+    const int64_t q = p.n_wg >> 3, r = p.n_wg & 7;
+    const int64_t xcd = wg & 7, loc = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int64_t m0 = (wg / p.tiles_n) * BM;
+  const int n0 = (int)(wg % p.tiles_n) * XT;
+  const int nk = p.K >> 5;
+  const int64_t row_b = (int64_t)p.K * 4;
+  const int64_t m_end = p.M;
+  const int srow = lane >> 3, sslot = lane & 7;
+  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
+  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
+  const int rows_valid = (int)((m_end - m0) < BM ? (m_end - m0) : BM);
+  uint32_t xoff[MT], woff[4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wave * (8 * MT) + i * 8 + srow;
+    const int t = sslot ^ ((row >> 1) & 7);
+    const int xr = row < rows_valid ? row : rows_valid - 1;
+    xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + srow;
+    woff[i] = (uint32_t)row * (uint32_t)row_b + (sslot ^ ((row >> 1) & 7)) * 16;
+  }
+  auto stage = [&](int kt) {
+    unsigned char* dst = smem + (kt % NS) * STAGE_B;
+    const unsigned char* xk = xbase + (int64_t)kt * 128;
+    const unsigned char* wk = wbase + (int64_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
+                                       (__attribute__((address_space(3))) void*)(dst + (wave * (8 * MT) + i * 8) * 128), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
+                                       (__attribute__((address_space(3))) void*)(dst + XTILE_B + (wave * 32 + i * 8) * 128), 16, 0,
+                                       0);
+  };
+  const int frow = lane & 15, fq = lane >> 4;
+  const int rn0 = wn * 64 + frow, rm0 = wm * (16 * MT) + frow;
+  const int offw_hi = XTILE_B + rn0 * 128 + ((fq ^ ((rn0 >> 1) & 7)) << 4), offw_lo = offw_hi ^ 64;
+  const int offx_hi = rm0 * 128 + ((fq ^ ((rm0 >> 1) & 7)) << 4), offx_lo = offx_hi ^ 64;
+
+  f32x4 acc[4][MT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) stage(s);
+  const uint32_t sbase = (uint32_t)(uintptr_t)smem;
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    // stages issued after stage kt so far: kt + 1 .. kt + NS - 2 (those that exist)
+    const int ahead = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
+    if (ahead >= 2) HFL_WAIT_VM(2 * DPS);
+    else if (ahead == 1) HFL_WAIT_VM(DPS);
+    else HFL_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) stage(kt + NS - 1);
+    const uint32_t st = sbase + (uint32_t)((kt % NS) * STAGE_B);
+    const uint32_t awh = st + (uint32_t)offw_hi, awl = st + (uint32_t)offw_lo;
+    const uint32_t axh = st + (uint32_t)offx_hi, axl = st + (uint32_t)offx_lo;
+    bf16x8 wh[4], wl[4], xh[MT], xl[MT];
+    HFL_LDS_READ4_FIRST(wh[0], wl[0], wh[1], wl[1], awh, awl, 0, 2048);
+    HFL_LDS_READ4_FIRST(wh[2], wl[2], wh[3], wl[3], awh, awl, 4096, 6144);
+    HFL_LDS_READ4_FIRST(xh[0], xl[0], xh[1], xl[1], axh, axl, 0, 2048);
+    HFL_LDS_READ4_FIRST(xh[2], xl[2], xh[3], xl[3], axh, axl, 4096, 6144);
+    HFL_LDS_WAIT4(wh[0], wl[0], wh[1], wl[1]);
+    HFL_LDS_WAIT4(wh[2], wl[2], wh[3], wl[3]);
+    HFL_LDS_WAIT4(xh[0], xl[0], xh[1], xl[1]);
+    HFL_LDS_WAIT4(xh[2], xl[2], xh[3], xl[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // (the compiler's wait-count pass: vmcnt(0) was waited in the last step)
+  __syncthreads();                         // every wave has left the last stage: the epilogue reuses the LDS
+  x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
+}
+
 // fp32 (rows, C) [* row_scale[row]] -> split2 (rows, C/32, 2, 32) bf16
 __global__ void __launch_bounds__(256)
 split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const float* __restrict__ row_scale, int64_t n_rows,
@@ -310,6 +430,8 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const flo
 
 extern "C" {
 
+void hfl_internal_set_x3_ring(int v) { g_x3_ring = v ? 1 : 0; }
+
 void hfl_internal_set_x3_dbg(int v) {
   if (v >= 0x200) return;                   // (knobs of removed tile variants)
   if (v >= 0x100) g_x3_nt = v & 3;          // 0x100 | nt bits
@@ -319,7 +441,8 @@ void hfl_internal_set_x3_dbg(int v) {
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
                      float q_scale, hfl_stream_t stream, float* aux = nullptr, const float* row_scale = nullptr,
-                     const int32_t* tiles = nullptr, int64_t n_tiles = 0);
+                     const int32_t* tiles = nullptr, int64_t n_tiles = 0, const int32_t* gather = nullptr,
+                     int64_t n_src_rows = 0);
 
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
@@ -341,6 +464,19 @@ int hfl_linear_x3_grouped(float* out, const uint16_t* x_split2, const uint16_t* 
   if (n_tiles == 0) return HFL_OK;
   return x3_launch(out, x_split2, w_split2, nullptr, nullptr, n_rows, in_features, out_features, 0, 1.0f, stream, nullptr,
                    nullptr, tiles, n_tiles);
+}
+
+/* hfl_linear_x3_grouped with the octree convolution's gather done by the tile loader: row m of the A operand is
+ * x_split2[gather[m]] (x_split2 (n_src_rows, 2 K) bf16: the split2 form of the convolution's INPUT rows; gather (n_rows) int32
+ * = the input row of every live (row, tap) pair).  The gathered (pairs x Cin) matrix never exists in memory. */
+int hfl_linear_x3_grouped_gather(float* out, const uint16_t* x_split2, const int32_t* gather, int64_t n_src_rows,
+                                 const uint16_t* w_split2, const int32_t* tiles, int64_t n_tiles, int64_t n_rows,
+                                 int in_features, int out_features, hfl_stream_t stream) {
+  if (tiles == nullptr || gather == nullptr || n_tiles < 0 || n_src_rows <= 0) return HFL_EINVAL;
+  if (n_src_rows * (int64_t)in_features * 4 >= ((int64_t)1 << 32)) return HFL_ECAPACITY;       // 32-bit per-lane byte offsets
+  if (n_tiles == 0) return HFL_OK;
+  return x3_launch(out, x_split2, w_split2, nullptr, nullptr, n_rows, in_features, out_features, 0, 1.0f, stream, nullptr,
+                   nullptr, tiles, n_tiles, gather, n_src_rows);
 }
 
 int hfl_linear_x3_qkv(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
@@ -367,7 +503,7 @@ int hfl_linear_x3_gelu_bwd(uint16_t* out_split2, const uint16_t* dy_split2, cons
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
                      float q_scale, hfl_stream_t stream, float* aux, const float* row_scale, const int32_t* tiles,
-                     int64_t n_tiles) {
+                     int64_t n_tiles, const int32_t* gather, int64_t n_src_rows) {
   const int gelu_split_out = epi == 1 || epi == 3 || epi == 4;
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
   const bool narrow = tiles != nullptr && epi == 0 && out_features == 64;       // W blocks padded to 128 rows by the caller
@@ -379,6 +515,8 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual; p.aux = aux;
   p.row_scale = row_scale;
   p.tiles = tiles;
+  p.gather = gather;
+  (void)n_src_rows;
   p.M = n_rows; p.N = out_features; p.K = in_features;
   p.tiles_n = narrow ? 1 : out_features / XT;
   // 128-row tiles, 3 workgroups per CU.  (A 256-row tile and a 128 x 256 eight-wave tile were built and measured 10 - 120 %
@@ -391,6 +529,21 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
   const size_t lds = (size_t)(128 + XT) * 128 + (size_t)(g_x3_dbg & 0xFF) * 1024;   // (+ probe: extra KiB to cut occupancy)
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g_x3_ring && tiles == nullptr && row_scale == nullptr && (epi == 0 || epi == 1 || epi == 2) && in_features >= 256 &&
+      p.n_wg <= hfl_stream_cus(s)) {
+    constexpr int NS = 4;
+    const size_t lds4 = (size_t)NS * (128 + XT) * 128;
+#define HFL_X3_RING(E)                                                                                   \
+  {                                                                                                      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_ring_kernel<E, NS>),        \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);           \
+    if (e != hipSuccess) return (int)e;                                                                  \
+    gemm_x3_ring_kernel<E, NS><<<(unsigned)p.n_wg, 256, lds4, s>>>(p);                                   \
+  }
+    if (epi == 2) HFL_X3_RING(2) else if (epi == 1) HFL_X3_RING(1) else HFL_X3_RING(0)
+#undef HFL_X3_RING
+    HFL_RETURN_LAST_ERROR();
+  }
 #define HFL_X3_LAUNCH(E, M)                                                                              \
   {                                                                                                      \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<E, M>),              \

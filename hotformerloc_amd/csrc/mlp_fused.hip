@@ -34,6 +34,8 @@
 #include "x3_math.h"
 #include "stage_stream.h"
 
+#include <mutex>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -62,6 +64,13 @@ struct MlpFusedParams {
   int tail_sets;
   int tail_parts;
   float* part;                // (tail_parts, tail rows, C)
+  // Work units: whole passes first (full_units of them when the tail is split, else ceil(n_tiles / tiles per pass)), then
+  // the tail units (set, part).  ticket == nullptr: workgroup g takes the units g, g + G, ...; else the units are handed out
+  // by an atomic counter (ticket[0]; ticket[1] counts finished workgroups, the last one resets both): a workgroup that
+  // starts late or shares its CU with another stream's kernels simply takes fewer units -- beside the coarse levels' launches
+  // the static split let the slowest workgroup set the launch's time (410 us against 258 us alone).
+  int full_units;
+  unsigned int* ticket;
 };
 
 static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
@@ -91,27 +100,10 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
 
-  // ---- this workgroup's share of the 16-row tiles
-  const int G = gridDim.x, g = blockIdx.x;
-  int tile0, tile_end;
-  // tail work of this workgroup: set `tset` (tiles [tail_lo, tail_hi)), hidden chunks [tc0, tc0 + tnch)
-  int tail_lo = 0, tail_hi = 0, tc0 = 0, tnch = 0, tpart = 0;
-  if (p.tail_sets > 0) {
-    tile0 = g * p.full_passes * TPP;
-    tile_end = tile0 + p.full_passes * TPP;
-    if (g < p.tail_sets * p.tail_parts) {
-      const int tset = g % p.tail_sets;
-      tpart = g / p.tail_sets;
-      tail_lo = p.tail_tile0 + tset * TPP;
-      tail_hi = tail_lo + TPP < p.n_tiles ? tail_lo + TPP : p.n_tiles;
-      tnch = NCH / p.tail_parts;
-      tc0 = tpart * tnch;
-    }
-  } else {
-    const int base = p.n_tiles / G, extra = p.n_tiles % G;
-    tile0 = g * base + (g < extra ? g : extra);
-    tile_end = tile0 + base + (g < extra ? 1 : 0);
-  }
+  // ---- work units of this launch (see MlpFusedParams)
+  const int n_full = p.tail_sets > 0 ? p.full_units : (p.n_tiles + TPP - 1) / TPP;
+  const int n_units = n_full + (p.tail_sets > 0 ? p.tail_sets * p.tail_parts : 0);
+  __shared__ int s_unit;
 
   // small vectors live in LDS for the whole kernel: read per use with ds_read (a global load per use would be a dependent
   // L2 round trip each -- the register file has no room to hold them)
@@ -183,16 +175,26 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     const int naps = (int)(blockIdx.x % (unsigned)p.stagger_groups) * p.stagger;
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(63);          // ~4000 cycles each
   }
-  bool tail = false;
-  for (;;) {
-    if (tile0 >= tile_end) {
-      if (tail || tnch == 0) break;
-      tail = true;                          // the last pass: this workgroup's part of a tail set
-      tile0 = tail_lo;
-      tile_end = tail_hi;
-      c0 = tc0;
+  for (int unit = blockIdx.x; unit < n_units;) {
+    int tile0, tile_end, tpart = 0;
+    const bool tail = unit >= n_full;
+    if (!tail) {                            // a whole pass: TPP tiles, every hidden chunk
+      tile0 = unit * TPP;
+      tile_end = tile0 + TPP < p.n_tiles ? tile0 + TPP : p.n_tiles;
+      c0 = 0;
+      nst = NST;
+    } else {                                // part `tpart` of a tail set: its share of the hidden chunks
+      const int v = unit - n_full;
+      const int tset = v % p.tail_sets;
+      tpart = v / p.tail_sets;
+      tile0 = p.tail_tile0 + tset * TPP;
+      tile_end = tile0 + TPP < p.n_tiles ? tile0 + TPP : p.n_tiles;
+      const int tnch = NCH / p.tail_parts;
+      c0 = tpart * tnch;
       nst = 2 * tnch;
     }
+    int next_unit = unit + (int)gridDim.x;      // (wave-uniform: the ticket travels in `ticket_val` of thread 0 only)
+    int ticket_val = 0;
     const int nch = nst / 2;                // hidden chunks of this pass (even)
     const int ntile = tile_end - tile0 < TPP ? tile_end - tile0 : TPP;    // tiles of this pass
     // ---- LayerNorm of this wave's rows -> B-operand fragments (lane: row fr of the tile, channels 32 ks + 8 fq + j)
@@ -251,6 +253,9 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     // an ordinary load's result, which would turn the row loads above into 16 dependent round trips.
     // (Every wave has left the previous pass's last stage: the barrier orders it.)
     __builtin_amdgcn_s_barrier();
+    // the next unit's ticket: requested here (older than this pass's weight stream on the memory counter, so the stream's
+    // counted waits cover it), read at the bottom of the pass
+    if (p.ticket != nullptr && tid == 0) ticket_val = (int)atomicAdd(p.ticket, 1u);
     issue(0, seq % NSLOT);
     issue(1, (seq + 1) % NSLOT);
     if (PF == 3 && nst > 2) issue(2, (seq + 2) % NSLOT);
@@ -408,9 +413,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
 #pragma unroll
         for (int i = 0; i < FT; ++i) *reinterpret_cast<f32x4*>(orow + i * 16) = oacc[i][t];
       }
-      tile0 += ntile;
-      continue;
-    }
+    } else {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (!have[t] || row[t] >= p.M) continue;
@@ -425,7 +428,20 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
         *reinterpret_cast<f32x4*>(orow + i * 16) = oacc[i][t] + b + res[i];
       }
     }
-    tile0 += ntile;
+    }
+    if (p.ticket != nullptr) {              // thread 0 holds the next unit: through LDS to everybody
+      __syncthreads();
+      if (tid == 0) s_unit = (int)gridDim.x + ticket_val;
+      __syncthreads();
+      next_unit = __builtin_amdgcn_readfirstlane(s_unit);
+    }
+    unit = next_unit;
+  }
+  if (p.ticket != nullptr && tid == 0) {    // the last workgroup out resets the counters for the next launch on this slot
+    if (atomicAdd(p.ticket + 1, 1u) == gridDim.x - 1) {
+      p.ticket[0] = 0u;
+      p.ticket[1] = 0u;
+    }
   }
 }
 
@@ -527,6 +543,25 @@ struct MlpTailPlan {
   int full, tile0, sets, parts;
 };
 static int g_mlp_tail_split = 1;   // probe knob 'mlp_tail_split'
+static int g_mlp_dynamic = 1;      // probe knob 'mlp_dynamic': work units by atomic ticket (0: static, strided by workgroup)
+
+// Ticket slots (two counters each, one 128-B line per slot), zero-initialised once; launches take them round-robin and the
+// last workgroup of a launch leaves its slot zeroed, so a slot is clean again long before it comes round (64 launches later).
+constexpr int kTicketSlots = 64;
+unsigned int* hfl_internal_ticket_slot() {
+  static std::mutex mu;
+  static unsigned int* base = nullptr;
+  static unsigned int next = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (base == nullptr) {
+    unsigned int* b = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&b), (size_t)kTicketSlots * 128) != hipSuccess) return nullptr;
+    if (hipMemset(b, 0, (size_t)kTicketSlots * 128) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    base = b;
+  }
+  return base + (size_t)(next++ % kTicketSlots) * 32;
+}
+static unsigned int* ticket_slot() { return hfl_internal_ticket_slot(); }
 static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus) {
   MlpTailPlan t{0, 0, 0, 0};
   const int64_t n_tiles = hfl_cdiv(n_rows, 16);
@@ -546,6 +581,7 @@ static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus) {
 }
 
 extern "C" void hfl_internal_set_mlp_tail_split(int v) { g_mlp_tail_split = v ? 1 : 0; }
+extern "C" void hfl_internal_set_mlp_dynamic(int v) { g_mlp_dynamic = v ? 1 : 0; }
 
 static int64_t mlp_tail_bytes(const MlpTailPlan& t, int64_t n_rows, int channels) {
   return t.parts == 0 ? 0 : (int64_t)t.parts * (n_rows - (int64_t)t.tile0 * 16) * channels * 4;
@@ -601,6 +637,13 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   } else {
     tp.parts = 0;
   }
+  const int tpp = channels == 256 ? 8 : 16;
+  p.full_units = tp.parts > 0 ? tp.full * cus : 0;
+  const int n_units = tp.parts > 0 ? p.full_units + tp.sets * tp.parts : (int)hfl_cdiv(p.n_tiles, tpp);
+  if (grid > n_units) grid = n_units;
+  if (tp.parts > 0 && tp.full > 0 && grid < cus) grid = cus < n_units ? cus : n_units;
+  // tickets only when a workgroup can get more than one unit (else the static deal is the same thing without the atomics)
+  p.ticket = (g_mlp_dynamic && n_units > grid) ? ticket_slot() : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
 #define HFL_MLP_LAUNCH(CC, NT, PF)                                                                              \

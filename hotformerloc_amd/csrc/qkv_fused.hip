@@ -411,6 +411,9 @@ extern "C" {
 
 void hfl_internal_set_qkv_ring_pf(int v) { g_qkv_ring_pf = v == 2 ? 2 : 3; }
 void hfl_internal_set_qkv_tail_split(int v) { g_qkv_tail_split = v ? 1 : 0; }
+// (work units by atomic ticket as in csrc/mlp_fused.hip were tried here too: the unit decode in the pass loop pushed the C = 256
+// instance from 256 VGPRs / no scratch to 14 spilled dwords with reloads behind the stage barriers; the static deal stays)
+void hfl_internal_set_qkv_dynamic(int) {}
 
 int64_t hfl_qkv_fused_pack_bytes(int channels) {
   if (channels != 128 && channels != 256) return 0;

@@ -95,6 +95,7 @@ _TRAIN_LN = os.environ.get('HFL_TRAIN_LN', '1') != '0'    # training-path LayerN
 _TRAIN_MLP = os.environ.get('HFL_TRAIN_MLP', '1') != '0'          # fused fc1 -> GELU -> fc2 autograd Function
 _GROUPED_TAPS = os.environ.get('HFL_GROUPED_TAPS', '1') != '0'     # live-tap convolutions: one grouped x3 launch for all taps
 _SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
+_GATHER_IN_GEMM = os.environ.get('HFL_GATHER_IN_GEMM', '1') != '0'   # grouped tap GEMM gathers its A rows itself
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
 _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
@@ -229,6 +230,7 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 # the output features split over the workgroups (round 4) that shape takes 101 us and the restriction is gone
 # (HFL_QKV_FUSED_MIN_FILL restores it).
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
+_RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
 
 
@@ -254,12 +256,12 @@ def _qkv_pack(att: 'OctreeAttention', rows: int):
     return hit[2]
 
 
-def _block_tail_x3(x, attn_out2, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP'):
+def _block_tail_x3(x, attn_out2, attn: 'OctreeAttention', norm2: nn.LayerNorm, mlp: 'MLP', fused_any_rows: bool = False):
     """proj (+bias +residual) -> LN2 -> fc1 (+bias, GELU, re-split) -> fc2 (+bias +residual): the proj launch of the
     hand-written GEMM, then the MLP branch as one fused launch (hidden activation in registers) or, for small row counts,
     as LayerNorm + two GEMM launches (the M x 4C hidden activation crosses HBM once each way as 4 B per element)."""
     x = ops.linear_x3(attn_out2, _w2(attn.proj), bias=attn.proj.bias, residual=x)
-    pack = _mlp_pack(mlp, x.shape[0])
+    pack = _mlp_pack(mlp, _MLP_FUSED_MIN_ROWS if fused_any_rows else x.shape[0])
     if pack is not None:
         return ops.ln_mlp_fused(x, norm2.weight, norm2.bias, norm2.eps, pack, mlp.fc1.bias, mlp.fc2.bias)
     h2 = ops.layer_norm_split2(x, norm2.weight, norm2.bias, norm2.eps)
@@ -488,9 +490,14 @@ class OctreeConv(nn.Module):
             # carry the offset of their tap's weight block
             npad = max(self.out_channels, 128)
             d2 = data if data.dtype == torch.bfloat16 else ops.split2(data)
-            gs = ops.octree_gather(d2.view(torch.float32), src).view(torch.bfloat16)
-            part = ops.linear_x3_grouped(gs, self._tap_weights_split2(npad),
-                                         octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
+            if _GATHER_IN_GEMM and d2.shape[0] * self.in_channels * 4 < (1 << 32):
+                # the GEMM's tile loader fetches the pairs' input rows itself: no (pairs, Cin) matrix in memory
+                part = ops.linear_x3_grouped_gather(d2, src, self._tap_weights_split2(npad),
+                                                    octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
+            else:
+                gs = ops.octree_gather(d2.view(torch.float32), src).view(torch.bfloat16)
+                part = ops.linear_x3_grouped(gs, self._tap_weights_split2(npad),
+                                             octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
             out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
             return out if self.bias is None else out + self.bias
         g = ops.octree_gather(data, src)                                  # (P, Cin)
@@ -1046,7 +1053,10 @@ class RelayTokenTransformerBlock(nn.Module):
         if (all(p is not None and p.dtype == torch.float32 and p.is_contiguous() and p.device == device for p in plist)
                 and self.norm1.eps == self.norm2.eps and att.dim % 128 == 0 and att.num_heads * 16 == att.dim):
             from ._native import RelayBlockWeights
-            mpack = _mlp_pack(mlp, _MLP_FUSED_MIN_ROWS) if att.dim in (128, 256) else None   # any row count: hidden split
+            # (the MLP branch as the fused launch with the hidden dimension split over the chip: 27 us against 48 us for the
+            # three launches alone, and inside the step the relay tokens' fc2 -- K = 1024 over 28 workgroups -- took 120 us:
+            # 2361 -> 2417 clouds/s, three alternating runs each)
+            mpack = _mlp_pack(mlp, _MLP_FUSED_MIN_ROWS) if (_RTSA_MLP_FUSED and att.dim in (128, 256)) else None
             keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2), mpack)
             w = RelayBlockWeights(channels=att.dim, n_heads=att.num_heads, eps=self.norm1.eps,
                                   mlp_pack=None if mpack is None else mpack.data_ptr(),
@@ -1070,7 +1080,7 @@ class RelayTokenTransformerBlock(nn.Module):
             a2 = ops.layer_norm_split2(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             qkv = ops.linear_x3(a2, _w2(att.qkv), bias=att.qkv.bias)
             o2 = ops.split2(ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, att.num_heads, plan.max_seq_len))
-            return _block_tail_x3(rt, o2, att, self.norm2, self.mlp)
+            return _block_tail_x3(rt, o2, att, self.norm2, self.mlp, fused_any_rows=_RTSA_MLP_FUSED and att.dim in (128, 256))
         if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
             bid = plan.relay_cloud()
             rt = rt + self.drop_path(self.gamma1 * self.rt_attention(_ln(rt, self.norm1), plan), bid, plan.B)

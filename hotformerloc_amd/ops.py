@@ -480,6 +480,23 @@ def linear_x3_grouped(x2: torch.Tensor, w2: torch.Tensor, tiles: torch.Tensor, o
     return out
 
 
+def linear_x3_grouped_gather(x2: torch.Tensor, src: torch.Tensor, w2: torch.Tensor, tiles: torch.Tensor,
+                             out_features: int) -> torch.Tensor:
+    """`linear_x3_grouped` over the rows x2[src[m]] without materialising them (hfl_linear_x3_grouped_gather): x2 (N, 2K) split2
+    input rows of an octree convolution, src (P) or (P, 1) int32 the input row of every live pair; returns (P, out_features)."""
+    _dev(x2, src, w2, tiles)
+    assert x2.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x2.is_contiguous() and w2.is_contiguous()
+    assert tiles.dtype == torch.int32 and tiles.is_contiguous() and tiles.shape[1] == 3 and w2.shape[1] == x2.shape[1]
+    assert src.dtype == torch.int32 and src.is_contiguous()
+    m, k = src.numel(), x2.shape[1] // 2
+    out = torch.empty((m, out_features), dtype=torch.float32, device=x2.device)
+    with _timed('hfl_linear_x3', m * k * 4 + m * out_features * 4, 2 * m * k * out_features):
+        check(_native.load().hfl_linear_x3_grouped_gather(out.data_ptr(), x2.data_ptr(), src.data_ptr(), x2.shape[0],
+                                                          w2.data_ptr(), tiles.data_ptr(), tiles.shape[0], m, k, out_features,
+                                                          _stream()), 'hfl_linear_x3_grouped_gather')
+    return out
+
+
 def mlp_fused_ok(channels: int) -> bool:
     """Channel widths `ln_mlp_fused` takes (hfl_mlp_fused_pack_bytes > 0)."""
     return int(_native.load().hfl_mlp_fused_pack_bytes(int(channels))) > 0

@@ -379,6 +379,13 @@ int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, 
  * written).  out_features % 128 == 0, or out_features == 64 with every weight block padded to 128 rows (zeros). */
 int hfl_linear_x3_grouped(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const int32_t* tiles,
                           int64_t n_tiles, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream);
+/* The same with the octree convolution's gather done by the GEMM's tile loader: row m of the A operand is
+ * x_split2[gather[m]] -- x_split2 (n_src_rows, 2 K) bf16 is the split2 form of the convolution's INPUT rows, gather (n_rows)
+ * int32 the input row of every live (row, tap) pair (src of hfl_tap_lists).  Replaces hfl_octree_gather + hfl_linear_x3_grouped:
+ * the gathered (pairs x Cin) matrix never exists in memory.  n_src_rows * K * 4 < 2^32. */
+int hfl_linear_x3_grouped_gather(float* out, const uint16_t* x_split2, const int32_t* gather, int64_t n_src_rows,
+                                 const uint16_t* w_split2, const int32_t* tiles, int64_t n_tiles, int64_t n_rows,
+                                 int in_features, int out_features, hfl_stream_t stream);
 /* Per-row scaled forms for per-cloud stochastic depth (OctreeDropPath, models/layers/octformer_layers.py:213-289) inside the
  * fused residual branches: out = (x W^T + bias) * row_scale[m] + residual, and split2(x * row_scale[row]) for the branch's
  * incoming gradient.  row_scale (n_rows) may be NULL (= 1). */

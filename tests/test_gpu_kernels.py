@@ -698,6 +698,15 @@ def test_linear_x3_grouped_matches_per_block_products():
                 assert torch.equal(got, ref.float()), (cin, cout)
             else:
                 assert ((got.double() - ref).norm() / ref.norm()).item() < 1e-5, (cin, cout)
+            # the gather done by the GEMM's tile loader (hfl_linear_x3_grouped_gather): row m = source[src[m]], same bits as
+            # the GEMM over the materialised rows
+            n_src = 3000
+            source = torch.randint(-3, 4, (n_src, cin), generator=g).float() if integer else torch.randn(n_src, cin, generator=g)
+            src = torch.randint(0, n_src, (edges[-1],), generator=g, dtype=torch.int32)
+            w2 = ops.split2(wp.reshape(nb * npad, cin).to(DEV))
+            mat = ops.linear_x3_grouped(ops.split2(source[src.long()].to(DEV)), w2, tiles_t, cout)
+            fused = ops.linear_x3_grouped_gather(ops.split2(source.to(DEV)), src.to(DEV), w2, tiles_t, cout)
+            assert torch.equal(mat, fused), (cin, cout, integer)
 
 
 def test_wgrad_x3_matches_fp64_and_is_reproducible():
