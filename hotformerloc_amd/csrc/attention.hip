@@ -865,6 +865,7 @@ window_attn_kernel_v5(const WinMultiParams m) {
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 
   const int tstep = p.D;
+  const bool nt_loads = (p.dbg & 16) != 0;
   // ---- request a window: metadata word + every fragment of this wave's head (index arithmetic only) ----------------
   // A quad of lanes reads ONE row's 64 B (lane l: row l >> 2 of the tile, 16-B chunk l & 3): 16 requests per load
   // instruction instead of the 64 of the MFMA operand mapping (lane (c, g): row c, chunk g -- four rows per quad), and the
@@ -892,9 +893,19 @@ window_attn_kernel_v5(const WinMultiParams m) {
       kr[t] = qr[t] = vr[t] = zero4;
       if (ok) {
         const char* base = qkv_b + (uint32_t)row * row_q + col_l;
-        qr[t] = *reinterpret_cast<const uint4*>(base);
-        kr[t] = *reinterpret_cast<const uint4*>(base + reg_k);
-        vr[t] = *reinterpret_cast<const uint4*>(base + 2u * reg_k);
+        if (nt_loads) {        // probe (window_debug bit 4): the operand rows are read once -- non-temporal loads
+          typedef unsigned int att_u4v __attribute__((ext_vector_type(4)));
+          const att_u4v a = __builtin_nontemporal_load(reinterpret_cast<const att_u4v*>(base));
+          const att_u4v b = __builtin_nontemporal_load(reinterpret_cast<const att_u4v*>(base + reg_k));
+          const att_u4v c = __builtin_nontemporal_load(reinterpret_cast<const att_u4v*>(base + 2u * reg_k));
+          qr[t] = make_uint4(a[0], a[1], a[2], a[3]);
+          kr[t] = make_uint4(b[0], b[1], b[2], b[3]);
+          vr[t] = make_uint4(c[0], c[1], c[2], c[3]);
+        } else {
+          qr[t] = *reinterpret_cast<const uint4*>(base);
+          kr[t] = *reinterpret_cast<const uint4*>(base + reg_k);
+          vr[t] = *reinterpret_cast<const uint4*>(base + 2u * reg_k);
+        }
       }
     }
   };
@@ -1494,9 +1505,14 @@ void hfl_internal_set_mlp_tail_split(int v);
 void hfl_internal_set_mlp_dynamic(int v);
 void hfl_internal_set_cu_reserve(int v);
 void hfl_internal_set_x3_ring(int v);
+void hfl_internal_set_attn_fused_split(int v);
+extern "C" void hfl_internal_set_mlp_reserve(int v);
+void hfl_internal_set_qkv_reserve(int v);
 void hfl_internal_set_qkv_dynamic(int v);
 void hfl_internal_set_qkv_tail_split(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
+int hfl_internal_rpe_form(int depth, int bnd, int f16) { return rpe_form(depth, bnd, f16); }     // (csrc/attn_fused.hip)
+
 int hfl_internal_attn_timing(int on) {
   std::lock_guard<std::mutex> lk(g_attn_mu);
   for (auto& r : g_attn_recs) attn_rec_drop(r);
@@ -1552,6 +1568,15 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_qkv_dynamic(1);
     hfl_internal_set_cu_reserve(0);
     hfl_internal_set_x3_ring(0);
+    hfl_internal_set_mlp_reserve(0);
+    hfl_internal_set_qkv_reserve(0);
+  } else if (is("mlp_reserve")) {
+    hfl_internal_set_mlp_reserve(value);
+  } else if (is("qkv_reserve")) {
+    hfl_internal_set_qkv_reserve(value);
+    hfl_internal_set_attn_fused_split(1);
+  } else if (is("attn_fused_split")) {
+    hfl_internal_set_attn_fused_split(value);
   } else if (is("x3_ring")) {
     hfl_internal_set_x3_ring(value);
   } else if (is("cu_reserve")) {

@@ -67,6 +67,14 @@ int hfl_version(void) { return 100; }   // 1.00
 
 const char* hfl_arch(void) { return "gfx950"; }
 
+// upper bound of hfl_ln_mlp_fused_workspace over every row count <= n_rows (the executor launches the fused MLP on all rows
+// or on the token rows alone): parts x left-over rows <= min(16 n_rows, one round of the whole chip)
+static int64_t mlp_ws_bound(int64_t n_rows, int64_t channels) {
+  const int64_t round = (int64_t)hfl_num_cus() * (channels == 256 ? 8 : 16) * 16;
+  const int64_t r = 16 * n_rows < round ? 16 * n_rows : round;
+  return r * channels * 4;
+}
+
 // One transformer block of the inference path as ONE call: the launches a block makes (CPE, relay-row copy, LN1 -> split2,
 // qkv GEMM into the fp16 attention operand, window attention, proj GEMM + residual, then either LN2 -> split2, fc1 GEMM + GELU,
 // fc2 GEMM + residual or the fused MLP launch) issued back to back from native code.  Nothing new runs on the GPU; what goes away is eight Python launch wrappers
@@ -89,7 +97,25 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
   int rc;
   const int phase = io->phase;
-  if (phase < 0 || phase > 4) return HFL_EINVAL;
+  if (phase < 0 || phase > 6) return HFL_EINVAL;
+  if (phase == 5 || phase == 6) {
+    // proj + residual and the MLP branch of the RELAY rows (5) or of the TOKEN rows (6) alone: per-row operators, so the relay
+    // rows -- all the next iteration's relay-token self-attention waits for -- can go first, as three small launches, and that
+    // self-attention then runs beside the token rows' proj / MLP instead of after them
+    const int64_t r0 = phase == 5 ? nt : 0, nr = phase == 5 ? rows - nt : nt;
+    if (nr == 0) return HFL_OK;
+    rc = hfl_linear_x3(x1 + r0 * C, o2 + r0 * 2 * C, w->proj_w, w->proj_b, x0 + r0 * C, nr, (int)C, (int)C, 0, stream);
+    if (rc != HFL_OK) return rc;
+    if (phase == 6 && w->mlp_pack != nullptr)
+      return hfl_ln_mlp_fused_ws(io->out + r0 * C, x1 + r0 * C, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b,
+                                 w->fc2_b, nr, (int)C, a + 12 * unit, mlp_ws_bound(rows, C), stream);
+    if (w->fc1_w == nullptr || w->fc2_w == nullptr) return HFL_EINVAL;
+    rc = hfl_layer_norm_split2(h2 + r0 * 2 * C, x1 + r0 * C, w->norm2_gamma, w->norm2_beta, nr, C, w->eps, stream);
+    if (rc != HFL_OK) return rc;
+    rc = hfl_linear_x3(g2 + r0 * 8 * C, h2 + r0 * 2 * C, w->fc1_w, w->fc1_b, nullptr, nr, (int)C, (int)(4 * C), 1, stream);
+    if (rc != HFL_OK) return rc;
+    return hfl_linear_x3(io->out + r0 * C, g2 + r0 * 8 * C, w->fc2_w, w->fc2_b, x1 + r0 * C, nr, (int)(4 * C), (int)C, 0, stream);
+  }
   // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention)
   if (phase <= 1 && nt > 0) {
     rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
@@ -114,7 +140,16 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
                                   static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return (int)e;
   }
-  if (phase != 4) {
+  // blocks without relay rows (the OctFormer stage), whole-block call: LN1 -> qkv -> window attention as ONE launch, q / k / v
+  // never in HBM (csrc/attn_fused.hip), when the configuration is one it takes
+  const bool fused_attn = phase == 0 && rows == nt && w->fuse_attention != 0 && w->qkv_pack != nullptr &&
+                          hfl_attn_fused_ok(desc, (int)C, w->rpe_table != nullptr) != 0;
+  if (fused_attn) {
+    rc = hfl_attn_fused_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, io->tok_meta,
+                            w->rpe_table, desc, stream);
+    if (rc != HFL_OK) return rc;
+  }
+  if (phase != 4 && !fused_attn) {
     // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phases 2, 3)
     const int64_t r0 = phase != 0 ? nt : 0, nr = rows - r0;
     if (nr > 0) {
@@ -126,7 +161,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
     }
   }
   if (phase == 3) return HFL_OK;
-  if (phase != 4) {
+  if (phase != 4 && !fused_attn) {
     rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
     if (rc != HFL_OK) return rc;
   }
@@ -135,7 +170,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
     // (workspace of the left-over rows' partial sums: behind the twelve units, sized by hfl_block_forward_x3_arena)
     return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
-                               a + 12 * unit, hfl_ln_mlp_fused_workspace(rows, (int)C), stream);
+                               a + 12 * unit, mlp_ws_bound(rows, C), stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);
@@ -144,7 +179,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
 }
 
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) {
-  return n_rows * channels * 4 * 12 + hfl_ln_mlp_fused_workspace(n_rows, (int)channels);
+  return n_rows * channels * 4 * 12 + mlp_ws_bound(n_rows, channels);
 }
 
 // The window attention of n blocks (between their phases 3 and 4) as ONE launch when the blocks have one attention shape

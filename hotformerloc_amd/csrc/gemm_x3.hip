@@ -370,8 +370,8 @@ gemm_x3_ring_kernel(const X3Params p) {
   for (int kt = 0; kt < nk; ++kt) {
     // stages issued after stage kt so far: kt + 1 .. kt + NS - 2 (those that exist)
     const int ahead = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
-    if (ahead >= 2) HFL_WAIT_VM(2 * DPS);
-    else if (ahead == 1) HFL_WAIT_VM(DPS);
+    if (NS >= 4 && ahead >= 2) HFL_WAIT_VM(2 * DPS);
+    else if (NS >= 3 && ahead >= 1) HFL_WAIT_VM(DPS);
     else HFL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     if (kt + NS - 1 < nk) stage(kt + NS - 1);
@@ -430,7 +430,7 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const flo
 
 extern "C" {
 
-void hfl_internal_set_x3_ring(int v) { g_x3_ring = v ? 1 : 0; }
+void hfl_internal_set_x3_ring(int v) { g_x3_ring = v == 1 ? 4 : v; }      // stages of the ring kernel (2..4), 0 = off
 
 void hfl_internal_set_x3_dbg(int v) {
   if (v >= 0x200) return;                   // (knobs of removed tile variants)
@@ -529,18 +529,20 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
   const size_t lds = (size_t)(128 + XT) * 128 + (size_t)(g_x3_dbg & 0xFF) * 1024;   // (+ probe: extra KiB to cut occupancy)
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (g_x3_ring && tiles == nullptr && row_scale == nullptr && (epi == 0 || epi == 1 || epi == 2) && in_features >= 256 &&
+  if (g_x3_ring >= 2 && tiles == nullptr && row_scale == nullptr && (epi == 0 || epi == 1 || epi == 2) && in_features >= 256 &&
       p.n_wg <= hfl_stream_cus(s)) {
-    constexpr int NS = 4;
-    const size_t lds4 = (size_t)NS * (128 + XT) * 128;
-#define HFL_X3_RING(E)                                                                                   \
+#define HFL_X3_RING(E, NSV)                                                                              \
   {                                                                                                      \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_ring_kernel<E, NS>),        \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);           \
+    const size_t ldsr = (size_t)(NSV) * (128 + XT) * 128;                                                \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_ring_kernel<E, NSV>),       \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);           \
     if (e != hipSuccess) return (int)e;                                                                  \
-    gemm_x3_ring_kernel<E, NS><<<(unsigned)p.n_wg, 256, lds4, s>>>(p);                                   \
+    gemm_x3_ring_kernel<E, NSV><<<(unsigned)p.n_wg, 256, ldsr, s>>>(p);                                  \
   }
-    if (epi == 2) HFL_X3_RING(2) else if (epi == 1) HFL_X3_RING(1) else HFL_X3_RING(0)
+#define HFL_X3_RING_E(NSV) \
+  if (epi == 2) HFL_X3_RING(2, NSV) else if (epi == 1) HFL_X3_RING(1, NSV) else HFL_X3_RING(0, NSV)
+    if (g_x3_ring == 2) { HFL_X3_RING_E(2) } else if (g_x3_ring == 3) { HFL_X3_RING_E(3) } else { HFL_X3_RING_E(4) }
+#undef HFL_X3_RING_E
 #undef HFL_X3_RING
     HFL_RETURN_LAST_ERROR();
   }

@@ -544,6 +544,7 @@ struct MlpTailPlan {
 };
 static int g_mlp_tail_split = 1;   // probe knob 'mlp_tail_split'
 static int g_mlp_dynamic = 1;      // probe knob 'mlp_dynamic': work units by atomic ticket (0: static, strided by workgroup)
+static int g_mlp_reserve = 0;      // probe knob 'mlp_reserve': CUs a chip-filling launch leaves to the other streams
 
 // Ticket slots (two counters each, one 128-B line per slot), zero-initialised once; launches take them round-robin and the
 // last workgroup of a launch leaves its slot zeroed, so a slot is clean again long before it comes round (64 launches later).
@@ -582,6 +583,7 @@ static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus) {
 
 extern "C" void hfl_internal_set_mlp_tail_split(int v) { g_mlp_tail_split = v ? 1 : 0; }
 extern "C" void hfl_internal_set_mlp_dynamic(int v) { g_mlp_dynamic = v ? 1 : 0; }
+extern "C" void hfl_internal_set_mlp_reserve(int v) { g_mlp_reserve = v < 0 ? 0 : v; }
 
 static int64_t mlp_tail_bytes(const MlpTailPlan& t, int64_t n_rows, int channels) {
   return t.parts == 0 ? 0 : (int64_t)t.parts * (n_rows - (int64_t)t.tile0 * 16) * channels * 4;
@@ -624,7 +626,9 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   p.b1 = b1; p.b2 = b2; p.M = n_rows; p.eps = eps;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
   // stagger only launches in which a workgroup walks several passes (a single pass has nothing to alternate with)
-  const int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
+  int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
+  // (a launch of several rounds: leave g_mlp_reserve CUs unclaimed, see hfl_internal_stream_cus)
+  if (g_mlp_reserve > 0 && cus - g_mlp_reserve >= 64 && p.n_tiles > (int64_t)cus * (channels == 256 ? 8 : 16)) cus -= g_mlp_reserve;
   p.stagger = p.n_tiles > (int64_t)grid_guess(p.n_tiles, cus) * 8 * (channels == 256 ? 1 : 2) ? g_mlp_stagger : 0;
   p.stagger_groups = g_mlp_stagger_groups;
   int grid = p.n_tiles < cus ? p.n_tiles : cus;

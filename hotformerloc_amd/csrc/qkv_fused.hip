@@ -414,6 +414,8 @@ void hfl_internal_set_qkv_tail_split(int v) { g_qkv_tail_split = v ? 1 : 0; }
 // (work units by atomic ticket as in csrc/mlp_fused.hip were tried here too: the unit decode in the pass loop pushed the C = 256
 // instance from 256 VGPRs / no scratch to 14 spilled dwords with reloads behind the stage barriers; the static deal stays)
 void hfl_internal_set_qkv_dynamic(int) {}
+static int g_qkv_reserve = 0;       // probe knob 'qkv_reserve': CUs a chip-filling launch leaves to the other streams
+void hfl_internal_set_qkv_reserve(int v) { g_qkv_reserve = v < 0 ? 0 : v; }
 
 int64_t hfl_qkv_fused_pack_bytes(int channels) {
   if (channels != 128 && channels != 256) return 0;
@@ -440,7 +442,8 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   p.out = static_cast<unsigned char*>(qkv_out); p.x = x; p.gamma = gamma; p.beta = beta;
   p.pack = static_cast<const unsigned char*>(pack); p.bias = bias; p.M = n_rows; p.eps = eps; p.q_scale = q_scale;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
-  const int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
+  int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
+  if (g_qkv_reserve > 0 && cus - g_qkv_reserve >= 64 && p.n_tiles > (int64_t)cus * (channels == 256 ? 8 : 16)) cus -= g_qkv_reserve;
   const int grid = p.n_tiles < cus ? p.n_tiles : cus;
   const int nt = channels == 256 ? 1 : 2, waves = 8;       // (C = 256 with 2 tiles per wave spills, with 4 waves x 4 tiles
                                                              //  a stage takes 3-5 us: tools/qkv_fused_probe.py)

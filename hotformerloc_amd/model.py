@@ -231,6 +231,18 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 # (HFL_QKV_FUSED_MIN_FILL restores it).
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
 _RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
+# LN1 -> qkv -> window attention of the blocks without relay tokens (OctFormer stage) as one launch (csrc/attn_fused.hip)
+_ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
+# H-OSA iterations, relay rows first: after the window attention every level runs proj + MLP of its RELAY rows (2 % of the
+# rows, three small launches) before those of its token rows, so that the next iteration's relay-token self-attention -- which
+# needs nothing else -- starts beside the token rows' proj / MLP instead of after the slowest level's.  Why: the kernel trace
+# of the step shows the iteration's cycle is [coarse levels' MLP launches, starved while the finest level's fused MLP holds
+# every CU] -> [relay-token self-attention, 8 launches] -> [finest level: relay qkv, attention, proj, MLP]; the finest
+# level's own CPE + qkv ride beside it for free.  Relay-first takes the first two links out of the cycle -- and measured, it
+# does not pay: 2505-2531 clouds/s with the relay tails on the levels' own streams, 2608-2617 with them on the RTSA stream,
+# against 2619-2690 without (same box, alternating runs): twelve more small launches per iteration compete with the finest
+# level's persistent kernels for the CUs the cycle's links were waiting on anyway.  Off by default.
+_RELAY_FIRST = os.environ.get('HFL_RELAY_FIRST', '0') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
 
 
@@ -865,13 +877,14 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     mlp = block.mlp
     qpack = _qkv_pack(att, nt)
     w.qkv_pack = None if qpack is None else qpack.data_ptr()
+    w.fuse_attention = 1 if _ATTN_FUSED else 0
     pack = _mlp_pack(mlp, rows)
-    if pack is not None:
+    if pack is not None and not _RELAY_FIRST:
         w.mlp_pack, w.fc1_w, w.fc2_w = pack.data_ptr(), None, None
-    else:
+    else:               # (the relay rows' tail of the relay-first schedule runs the two GEMM launches also beside a pack)
         if keep[2] is None:
             keep[2], keep[3] = _w2(mlp.fc1), _w2(mlp.fc2)
-        w.mlp_pack, w.fc1_w, w.fc2_w = None, keep[2].data_ptr(), keep[3].data_ptr()
+        w.mlp_pack, w.fc1_w, w.fc2_w = (None if pack is None else pack.data_ptr()), keep[2].data_ptr(), keep[3].data_ptr()
     desc = WindowAttnDesc(n_tokens=nt, rt_row0=nt, n_windows=plan.n_windows[depth], patch_size=att.patch_size,
                           dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
                           batch_size=plan.B, scale=16 ** -0.5, depth=depth,
@@ -1261,7 +1274,107 @@ class HOTFormerStage(nn.Module):
                 t.record_stream(caller)
         return local, rts
 
+    def _iterations_relay_first(self, data, plan, depths, bufs, rts, nts, proj, part):
+        """The early-phase schedule with the relay rows' block tail first (see _RELAY_FIRST); returns None when a block of
+        the first iteration is not eligible for the native executor (the caller then runs the plain early schedule)."""
+        main = torch.cuda.current_stream()
+        side = part[1] if part else self._side_streams(data.device)
+        rs = part[2] if part else self._rtsa_stream(data.device)
+        small = [not (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) for j, d in enumerate(depths)]
+        sts = [side[j - 1] if small[j] else main for j in range(len(depths))]
+        order = sorted(range(len(depths)), key=lambda j: -bufs[depths[j]].shape[0])
+        nlev = len(depths)
+
+        def rtsa(i, ready):
+            """RTSA of iteration i on its stream, behind the events `ready`; returns (rows of all levels, event)"""
+            for ev in ready:
+                rs.wait_event(ev)
+            with torch.cuda.stream(rs):
+                out = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
+                return out, rs.record_event()
+
+        rt_all, ev_rt = rtsa(0, [main.record_event()])
+        keep = []                                                        # buffers other streams still read: until the join
+        for i in range(self.num_blocks):
+            ev0 = main.record_event()
+            calls = {}
+            for j in order:                                              # (prepared first: nothing is issued if a block is not eligible)
+                with torch.cuda.stream(sts[j]):
+                    calls[depths[j]] = _native_block_call(self.hosa_blocks[j][i], bufs[depths[j]], plan, depths[j])
+            if any(c is None for c in calls.values()):
+                if i == 0:
+                    main.wait_stream(rs)                                 # (RTSA 0 is simply recomputed by the plain schedule)
+                    return None
+                raise RuntimeError('relay-first schedule: a block of iteration %d lost its native call' % i)
+            for j in order:                                              # token rows: CPE, LN1, qkv (finest level first)
+                d = depths[j]
+                if sts[j] is not main:
+                    sts[j].wait_event(ev0)
+                with torch.cuda.stream(sts[j]):
+                    calls[d].run(1)
+            fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
+            keep.append((dict(bufs), dict(rts), rt_all, fresh))
+            group = [j for j in order if small[j]] if _MERGED_ATTN else []
+            if len(group) < 2:
+                group = []
+            for j in order:                                              # relay rows in, their LN1 / qkv
+                d = depths[j]
+                sts[j].wait_event(ev_rt)
+                with torch.cuda.stream(sts[j]):
+                    calls[d].run(3, self.down_projections[j][i](fresh[d]) if proj else fresh[d])
+            for j in order:                                              # window attention (the small levels in one launch)
+                if j in group:
+                    continue
+                with torch.cuda.stream(sts[j]):
+                    ops.block_attention_multi([calls[depths[j]]])
+            if group:
+                lead = sts[group[0]]
+                for j in group[1:]:
+                    lead.wait_event(sts[j].record_event())
+                with torch.cuda.stream(lead):
+                    ops.block_attention_multi([calls[depths[j]] for j in group])
+                    ev_att = lead.record_event()
+                for j in group:
+                    if sts[j] is not lead:
+                        sts[j].wait_event(ev_att)
+            # the relay rows' proj + MLP of every level go to the RTSA stream (they feed nothing else), the token rows' follow on
+            # the level's own stream at once: the two touch disjoint rows of the block's buffers
+            for j in order:
+                rs.wait_event(sts[j].record_event())
+            with torch.cuda.stream(rs):
+                for j in order:
+                    d = depths[j]
+                    out = calls[d].run(5)
+                    rts[d] = self.up_projections[j][i](out[nts[j]:]) if proj else out[nts[j]:]
+            if i + 1 < self.num_blocks:                                  # ... the next RTSA starts behind them ...
+                rt_all, ev_rt = rtsa(i + 1, [])
+            else:
+                ev_last = rs.record_event()
+            for j in order:                                              # ... beside the token rows' proj + MLP
+                with torch.cuda.stream(sts[j]):
+                    bufs[depths[j]] = calls[depths[j]].run(6)
+            for j in order:                                              # (relay-token propagation reads the relay rows too)
+                d = depths[j]
+                if self.hosa_blocks[j][i].propagate:
+                    sts[j].wait_event(ev_last if i + 1 == self.num_blocks else ev_rt)
+                    with torch.cuda.stream(sts[j]):
+                        bufs[d] = self.hosa_blocks[j][i]._tail(bufs[d], plan, d)
+                        rts[d] = self.up_projections[j][i](bufs[d][nts[j]:]) if proj else bufs[d][nts[j]:]
+            keep.append(calls)
+            for j in range(nlev):
+                if sts[j] is not main:
+                    main.wait_stream(sts[j])
+            if i + 1 == self.num_blocks:
+                main.wait_stream(rs)
+            keep = keep[-2:]
+        del keep
+        return {d: bufs[d][:nt] for d, nt in zip(depths, nts)}, rts
+
     def _iterations(self, data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa, part):
+        if early and _RELAY_FIRST and not _SERIAL_STREAMS and _NATIVE_BLOCK:
+            res = self._iterations_relay_first(data, plan, depths, bufs, rts, nts, proj, part)
+            if res is not None:
+                return res
         for i in range(self.num_blocks):                                # 593-633
             if early:
                 # RTSA of iteration i only feeds the relay rows: what a block does with its TOKEN rows before the window

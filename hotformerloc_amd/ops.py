@@ -672,6 +672,46 @@ def ln_qkv_fused(x, gamma, beta, eps: float, pack, bias, q_scale: float, out=Non
     return out
 
 
+def attn_fused_ok(n_tokens: int, n_windows: int, patch_size: int, dilation: int, n_relay: int, n_heads: int, depth: int,
+                  channels: int, has_rpe: bool) -> bool:
+    """Whether `attn_fused` (LayerNorm -> qkv -> window attention in one launch) takes this configuration."""
+    desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=n_tokens, n_windows=n_windows, patch_size=patch_size, dilation=dilation,
+                          n_relay=n_relay, n_heads=n_heads, pos_bnd=int(0.8 * patch_size * dilation ** 0.5),
+                          batch_size=1, scale=16 ** -0.5, depth=depth)
+    return bool(_native.load().hfl_attn_fused_ok(ctypes.byref(desc), int(channels), 1 if has_rpe else 0))
+
+
+def attn_fused(x, gamma, beta, eps: float, qkv_pack, qkv_bias, q_scale: float, tok_meta, rpe_table, n_tokens: int,
+               n_windows: int, patch_size: int, dilation: int, n_heads: int, batch_size: int, depth: int, out=None):
+    """split2(window_attention(qkv(LayerNorm(x)))) in ONE launch (hfl_attn_fused_fwd): x (n_tokens, C) f32 -> (n_tokens, 2C)
+    bf16, the operand of the proj GEMM -- bitwise what `ln_qkv_fused` + `window_attention(..., out_split=2, qkv_f16=True)` give."""
+    _dev(x, gamma, beta, qkv_pack, qkv_bias, tok_meta, rpe_table)
+    x = _f32c(x)
+    c = x.shape[1]
+    assert x.shape[0] >= n_tokens
+    if out is None:
+        out = torch.empty((x.shape[0], 2 * c), dtype=torch.bfloat16, device=x.device)
+    desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=n_tokens, n_windows=n_windows, patch_size=patch_size, dilation=dilation,
+                          n_relay=0, n_heads=n_heads, pos_bnd=int(0.8 * patch_size * dilation ** 0.5),
+                          batch_size=batch_size, scale=16 ** -0.5, depth=depth)
+    table_ptr, expanded = None, None
+    if rpe_table is not None:
+        expanded = rpe_expand(rpe_table, n_heads, desc.pos_bnd, depth, True)
+        assert expanded is not None
+        desc.rpe_expanded = expanded.data_ptr()
+        rpe_table = _f32c(rpe_table)
+        table_ptr = rpe_table.data_ptr()
+    # algorithmic bytes: read x, write the split2 output (8 B per (row, channel)) + 8 B of metadata per token
+    real_windows = -(-n_tokens // patch_size)
+    with _timed('hfl_attn_fused_fwd', n_tokens * c * 8 + n_tokens * 8,
+                6 * n_tokens * c * c + 4 * patch_size * patch_size * c * real_windows):
+        check(_native.load().hfl_attn_fused_fwd(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                                float(eps), qkv_pack.data_ptr(), _f32c(qkv_bias).data_ptr(), float(q_scale),
+                                                tok_meta.data_ptr(), table_ptr, ctypes.byref(desc), _stream()),
+              'hfl_attn_fused_fwd')
+    return out
+
+
 def window_attention_f16_ok(n_rows: int, patch_size: int, dilation: int, n_relay: int, n_heads: int, depth: int) -> bool:
     """Whether the window kernel takes the fp16 (hi, lo) qkv layout for this launch (else: fp32 qkv)."""
     desc = WindowAttnDesc(n_tokens=n_rows, rt_row0=0, n_windows=1, patch_size=patch_size, dilation=dilation,

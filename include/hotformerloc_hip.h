@@ -461,6 +461,19 @@ int hfl_qkv_fused_pack(void* pack, const float* w_qkv, int channels, hfl_stream_
 int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* bias, float q_scale, int64_t n_rows, int channels, hfl_stream_t stream);
 
+/* 9e. LayerNorm -> qkv projection -> window attention as ONE launch (csrc/attn_fused.hip): norm1 -> attention.qkv -> mask /
+ *     RPE bias / SDPA of `x = x + attn(norm1(x))` (models/octformer_backbone.py:52-93,275-276) up to the attention output,
+ *     q, k, v never in HBM.  Built for the OctFormer stage: C = 128 (8 heads of 16), patch_size 48, no relay tokens,
+ *     dilation 1 / 2 / 4, octree depth <= 7, RPE through the three clamped 1-D expanded tables
+ *     (hfl_window_rpe_expand with f16_operand = 1 at a depth where it builds that form) or none.  hfl_attn_fused_ok says
+ *     whether a configuration is taken.  x (n_tokens, C) f32; qkv_pack = hfl_qkv_fused_pack image; out_split2 (n_tokens, 2 C)
+ *     bf16 = the operand of the proj GEMM (hfl_linear_x3), bitwise what hfl_ln_qkv_fused + hfl_window_attention_fwd_ex
+ *     (out_split3 = 2 | 0x100) produce. */
+int hfl_attn_fused_ok(const hfl_window_attn_desc* desc, int channels, int has_rpe);
+int hfl_attn_fused_fwd(void* out_split2, const float* x, const float* gamma, const float* beta, float eps, const void* qkv_pack,
+                       const float* qkv_bias, float q_scale, const uint32_t* tok_meta, const float* rpe_table,
+                       const hfl_window_attn_desc* desc, hfl_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * 10. Backward kernels (training path; autograd glue in hotformerloc_amd/autograd.py).
  *     The reference gets these from PyTorch autograd over its materialised formulation and from
@@ -508,6 +521,9 @@ typedef struct hfl_block_weights {
   const void* qkv_pack;                                /* hfl_qkv_fused_pack image of qkv_w or NULL: when set, phase 1 runs LN1 -> qkv
                                                           of the token rows as ONE launch (hfl_ln_qkv_fused); qkv_w is still
                                                           read for the relay rows */
+  int32_t fuse_attention;                              /* != 0: a whole-block call (phase 0) of a block WITHOUT relay rows runs LN1
+                                                          -> qkv -> window attention as ONE launch (hfl_attn_fused_fwd) when
+                                                          hfl_attn_fused_ok takes the configuration; needs qkv_pack */
 } hfl_block_weights;
 typedef struct hfl_block_io {
   const float* x_in;
@@ -524,6 +540,9 @@ typedef struct hfl_block_io {
                                                           MLP.  3 + 4 split phase 2 around the attention: 3 = relay rows in and
                                                           their LN1 / qkv, 4 = proj and MLP; between them the caller runs the
                                                           attention of this and other blocks with hfl_block_attention_x3_multi.
+                                                          5 + 6 split phase 4 by rows: 5 = proj and MLP of the RELAY rows (needs
+                                                          fc1_w / fc2_w also when mlp_pack is set), 6 = of the token rows; after
+                                                          5 the next iteration's relay-token self-attention has its input.
                                                           All phases of a block share `arena`. */
 } hfl_block_io;
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels);

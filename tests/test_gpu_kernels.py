@@ -1087,3 +1087,44 @@ def test_window_attention_multi_launch_equals_single_launches():
     assert torch.equal(mixed[1][:nt5].view(torch.int16), want5[:nt5].view(torch.int16))
     used0 = probs[0]['n_tokens'] + (-(-probs[0]['n_tokens'] // K))
     assert torch.equal(mixed[0][:used0].view(torch.int16), single[0][:used0].view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 30, 2500, 4096]), ('cs-wild-places', 7, [6000, 4096]),
+                                                    ('oxford', 9, [4096, 1000])])
+def test_attn_fused_equals_the_two_launches(cfg, octree_depth, sizes):
+    """hfl_attn_fused_fwd (LayerNorm -> qkv -> window attention in ONE launch, q / k / v never in HBM; built for the OctFormer
+    stage: C = 128, K = 48, no relay tokens) against (a) hfl_ln_qkv_fused + the fp16 window kernel, whose arithmetic it
+    repeats operation for operation: BITWISE equal, dilation 1 and 4, with and without RPE, ragged batches whose last tile
+    and windows are partly padding, at the attention depths of the three configs (5, 5, 7).  The two-launch path is the one
+    the oracle tests above pin (test_ln_qkv_fused_*, test_window_attention_matches_oracle): equal bits carry that parity over."""
+    clouds = [syn.unit_ball_cloud(900 + i, n) for i, n in enumerate(sizes)]
+    params, ref, dev, oplan, plan = _plans(clouds, cfg, octree_depth)
+    K = params.patch_size
+    depth = plan.stage_depths[0] if hasattr(plan, 'stage_depths') else max(plan.n_tokens.keys())
+    H, C = 8, 128
+    nt = plan.n_tokens[depth]
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(nt, C, device='cuda', generator=g) * 1.3 + 0.2
+    gamma = torch.rand(C, device='cuda', generator=g) + 0.5
+    beta = torch.randn(C, device='cuda', generator=g) * 0.1
+    w = torch.randn(3 * C, C, device='cuda', generator=g) * 0.08
+    b = torch.randn(3 * C, device='cuda', generator=g) * 0.1
+    qs = 16 ** -0.5 * 1.4426950408889634
+    pack = ops.qkv_fused_pack(w)
+    for dil in (1, 4):
+        W = -(-nt // (K * dil)) * dil
+        bnd = int(0.8 * K * dil ** 0.5)
+        for with_rpe in (True, False):
+            table = torch.randn(3 * (2 * bnd + 1), H, device='cuda', generator=g) * 0.3 if with_rpe else None
+            if K != 48:                                     # (CS-Wild-Places windows hold 64 tokens: not a shape it is built for)
+                assert not ops.attn_fused_ok(nt, W, K, dil, 0, H, depth, C, with_rpe)
+                continue
+            assert ops.attn_fused_ok(nt, W, K, dil, 0, H, depth, C, with_rpe), (cfg, depth, dil, with_rpe)
+            qkv = ops.ln_qkv_fused(x, gamma, beta, 1e-5, pack, b, qs)
+            two = ops.window_attention(qkv, plan.meta[depth], table, nt, W, K, dil, 0, H, plan.B, rt_row0=nt, depth=depth,
+                                       out_split=2, qkv_f16=True)
+            one = ops.attn_fused(x, gamma, beta, 1e-5, pack, b, qs, plan.meta[depth], table, nt, W, K, dil, H, plan.B, depth)
+            assert torch.equal(one[:nt].view(torch.int16), two[:nt].view(torch.int16)), (cfg, dil, with_rpe)
+            assert torch.equal(one, ops.attn_fused(x, gamma, beta, 1e-5, pack, b, qs, plan.meta[depth], table, nt, W, K, dil,
+                                                   H, plan.B, depth))
