@@ -3,7 +3,8 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched as
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per
-GPU over RCCL.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by a barrier +
+GPU over RCCL -- or plainly as `python bench.py --gpus N`: with no RANK in the environment the script starts its own
+ranks that way (a child process; this parent never touches the GPU) and relays rank 0's line and the exit code.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by a barrier +
 `torch.cuda.synchronize()`; max over ranks; rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[1]): batch of 32 synthetic 4096-point clouds per GPU,
@@ -26,7 +27,11 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
                  reference's arithmetic
   e2e            a FRESH octree per step from device-resident points: device build + neighbour tables + forward
   train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process
-and then, outside any timed value: the `roofline` legs (HIP events per launch) and the `cpu_baseline`
+  oxford         BASELINE config 5's per-rank workload (Oxford cfg, B = 64, octree depth 9), in a child process
+  pinned_host    the headline step with the process pinned to 1/8 of the host's logical CPUs (what one of 8 ranks sharing a
+                 host gets), in a child process; every leg's `host_issue` = host time to queue the K steps vs their wall time
+and then, outside any timed value: the `roofline` legs (HIP events per launch: the fp16 window kernel, `roofline_fused` for the
+one-kernel LayerNorm -> qkv -> attention launch of the OctFormer stage, `roofline_fp32` for the fp32 leg) and the `cpu_baseline`
 (the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol) whose descriptors are also the
 `parity` reference of the timed workload's GPU descriptors (BASELINE metric: "descriptor L2 vs ref").
 """
@@ -385,7 +390,7 @@ def main():
                 'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup}
 
     extras = world == 1 and not args.train and not args.no_extras
-    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = None
+    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = fused_roof = None
     with (torch.enable_grad() if args.train else torch.inference_mode()):
         # ---- the headline: W warm-ups, K timed steps, nothing instrumented inside the timed region
         elapsed = timed(step, args.steps, args.warmup, tag='value')
@@ -443,6 +448,7 @@ def main():
                     step()
                     rec, iso_sizes = native_attention_timing(step, args.steps)
                     kern_iso = {ATTN: rec}
+                    fused_roof = native_fused_timing(step, args.steps)
                     set_pyramid_streams(True)
             elif not args.no_streams:
                 set_pyramid_streams(False)
@@ -519,6 +525,8 @@ def main():
         }
         if roof32:
             line['roofline_fp32'] = roof32
+        if fused_roof:
+            line['roofline_fused'] = fused_roof
         if per_rank is not None:
             line['per_rank_ms_per_step'] = {'min': min(per_rank), 'max': max(per_rank), 'ranks': per_rank}
         if allgather_ms is not None:
@@ -624,6 +632,47 @@ def native_attention_timing(step, steps):
     return rec, [(b, c, t) for b, (c, t) in sorted(groups.items(), reverse=True)]
 
 
+def native_fused_timing(step, steps):
+    """HIP-event timing of the hfl_attn_fused_fwd launches (LN -> qkv -> window attention in one kernel) of `steps` steps:
+    None when the step issues none."""
+    import ctypes
+    import torch
+    from hotformerloc_amd import _native
+    lib = _native.load()
+    lib.hfl_internal_fused_timing.argtypes = [ctypes.c_int]
+    lib.hfl_internal_fused_timing_read.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int]
+    lib.hfl_internal_fused_timing(1)
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        cap = 1 << 14
+        ms, nb, fg, fa = ((ctypes.c_double * cap)() for _ in range(4))
+        n = lib.hfl_internal_fused_timing_read(ms, nb, fg, fa, cap)
+    finally:
+        lib.hfl_internal_fused_timing(0)
+    if n <= 0:
+        return None
+    n = min(n, cap)
+    t = sum(ms[i] for i in range(n)) * 1e-3
+    useful = sum(fg[i] + fa[i] for i in range(n))
+    # issued on the matrix cores: 3 bf16 MFMA terms per GEMM product, 3.5 fp16 MFMA per useful attention flop (see roofline.mfma)
+    issued = sum(3.0 * fg[i] + 3.5 * fa[i] for i in range(n))
+    nbytes = sum(nb[i] for i in range(n))
+    return {'kernel': 'hfl_attn_fused_fwd', 'what': 'LayerNorm -> qkv -> window attention in ONE kernel, q / k / v never in HBM '
+            '(OctFormer stage: C = 128, 8 heads, K = 48, no relay tokens); outputs bitwise equal to hfl_ln_qkv_fused + the fp16 '
+            'window kernel', 'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_F16_PEAK_TFLOPS,
+            'achieved': round(issued / t / 1e12, 1), 'frac': round(issued / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            'useful_tflops_fp32_equivalent': round(useful / t / 1e12, 2),
+            'useful_over_f32_mfma_peak': round(useful / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
+            'hbm': {'algorithmic_bytes_per_launch': int(nbytes / n), 'GBps': round(nbytes / t / 1e9, 1),
+                    'frac_of_8TBps': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+                    'note': 'x in + split2 out = 8 B per (row, channel) + 8 B of metadata per token; the two launches it '
+                            'replaces move 24 B per (row, channel)'},
+            'timing': 'HIP event pair around every launch, recorded by the library, serialised schedule, after the timed region'}
+
+
 def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32, serialised):
     rec = (kern or {}).get(ATTN)
     if not rec:
@@ -631,7 +680,7 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
     n, ms, nbytes, flops, moved = rec
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for cand in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for cand in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         pmc = os.path.join(ROOT, 'profiles', cand)
         if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command

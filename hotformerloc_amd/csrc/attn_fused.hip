@@ -26,6 +26,9 @@
 #include "x3_math.h"
 #include "stage_stream.h"
 
+#include <mutex>
+#include <vector>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -474,6 +477,15 @@ attn_fused_kernel(const FusedAttnParams p) {
 
 }  // namespace
 
+// per-launch HIP events for bench.py's roofline leg (the launches sit inside hfl_block_forward_x3: no Python timer sees them)
+struct FusedTimingRec {
+  hipEvent_t e0, e1;
+  double bytes, flops_gemm, flops_attn;
+};
+static int g_fused_timing = 0;
+static std::vector<FusedTimingRec> g_fused_recs;
+static std::mutex g_fused_mu;
+
 extern "C" int hfl_internal_rpe_form(int depth, int bnd, int f16);
 static int g_attn_fused_split = 1;      // probe knob 'attn_fused_split'
 extern "C" void hfl_internal_set_attn_fused_split(int v) { g_attn_fused_split = v ? 1 : 0; }
@@ -520,9 +532,54 @@ int hfl_attn_fused_fwd(void* out_split2, const float* x, const float* gamma, con
   }
   const int n_units = p.full_tiles + (p.n_tiles - p.full_tiles) * p.tail_parts;
   const int grid = n_units < cus ? n_units : cus;
+  FusedTimingRec rec{};
+  const bool timed = g_fused_timing != 0;
+  if (timed) {
+    // algorithmic bytes: x in + split2 out = 8 B per (row, channel) + 8 B of metadata per token; useful flop: the qkv GEMM
+    // 2 M C 3C and the attention core 4 L^2 C per real window
+    rec.bytes = (double)d->n_tokens * FC * 8.0 + (double)d->n_tokens * 8.0;
+    rec.flops_gemm = 6.0 * (double)d->n_tokens * FC * FC;
+    rec.flops_attn = 4.0 * FK * FK * FC * (double)((d->n_tokens + FK - 1) / FK);
+    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess || hipEventRecord(rec.e0, s) != hipSuccess) {
+      if (rec.e0) (void)hipEventDestroy(rec.e0);
+      if (rec.e1) (void)hipEventDestroy(rec.e1);
+      return HFL_EINVAL;
+    }
+  }
   if (p.rpe2 != nullptr) attn_fused_kernel<2><<<grid, FW * 64, 0, s>>>(p);
   else attn_fused_kernel<0><<<grid, FW * 64, 0, s>>>(p);
+  if (timed) {
+    (void)hipEventRecord(rec.e1, s);
+    std::lock_guard<std::mutex> lk(g_fused_mu);
+    g_fused_recs.push_back(rec);
+  }
   HFL_RETURN_LAST_ERROR();
+}
+
+// bench.py: per-launch timing of hfl_attn_fused_fwd on / off (both drop what was recorded) ...
+int hfl_internal_fused_timing(int on) {
+  std::lock_guard<std::mutex> lk(g_fused_mu);
+  for (auto& r : g_fused_recs) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_fused_recs.clear();
+  g_fused_timing = on ? 1 : 0;
+  return HFL_OK;
+}
+// ... and read it: per launch the duration (ms), algorithmic bytes, useful GEMM and attention flop; returns the launches recorded
+int hfl_internal_fused_timing_read(double* ms, double* bytes, double* flops_gemm, double* flops_attn, int cap) {
+  std::lock_guard<std::mutex> lk(g_fused_mu);
+  int n = 0;
+  for (auto& r : g_fused_recs) {
+    if (n >= cap) break;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -1;
+    ms[n] = t; bytes[n] = r.bytes; flops_gemm[n] = r.flops_gemm; flops_attn[n] = r.flops_attn;
+    ++n;
+  }
+  return (int)g_fused_recs.size();
 }
 
 }  // extern "C"
