@@ -1500,6 +1500,7 @@ void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
 void hfl_internal_set_mlp_ring_pf(int v);
+void hfl_internal_set_mlp_waves(int v);
 void hfl_internal_set_qkv_ring_pf(int v);
 void hfl_internal_set_mlp_tail_split(int v);
 void hfl_internal_set_mlp_dynamic(int v);
@@ -1561,6 +1562,7 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_cpe_chunk(0);
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
     hfl_internal_set_mlp_ring_pf(3);
+    hfl_internal_set_mlp_waves(8);
     hfl_internal_set_qkv_ring_pf(3);
     hfl_internal_set_mlp_tail_split(1);
     hfl_internal_set_qkv_tail_split(1);
@@ -1587,6 +1589,8 @@ int hfl_set_variant(const char* key, int value) {
   } else if (is("tail_split")) {
     hfl_internal_set_mlp_tail_split(value);
     hfl_internal_set_qkv_tail_split(value);
+  } else if (is("mlp_waves")) {
+    hfl_internal_set_mlp_waves(value);
   } else if (is("ring_pf")) {
     hfl_internal_set_mlp_ring_pf(value);
     hfl_internal_set_qkv_ring_pf(value);

@@ -76,19 +76,22 @@ struct MlpFusedParams {
 static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
 static int g_mlp_stagger_groups = 8;
 static int g_mlp_ring_pf = 3;      // probe knob 'ring_pf': stages of the weight stream in flight ahead of the consumed one (2 | 3)
+static int g_mlp_waves = 8;        // probe knob 'mlp_waves': waves per workgroup (8: one 16-row tile each at C = 256; 4: two each)
 
-template <int C, int NT, int PF>
-__global__ void __launch_bounds__(512, 2)
+template <int C, int NT, int PF, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
 ln_mlp_fused_kernel(const MlpFusedParams p) {
   static_assert(PF == 2 || PF == 3, "stages in flight ahead of the one being consumed");
+  static_assert(NW == 8 || NW == 4, "waves per workgroup: two per SIMD with 256 registers each, or one with 512");
+  constexpr int NTHR = NW * 64;
   constexpr int KS = C / 32;               // k-steps of GEMM1
   constexpr int FT = C / 16;               // 16-feature tiles of the output
   constexpr int NCH = C / 8;               // chunks of 32 hidden features (hidden = 4 C)
   constexpr int STAGE_B = C * 128;         // bytes of one stage: C rows x 128 B
   constexpr int NSLOT = 4;
-  constexpr int DPW = STAGE_B / 1024 / 8;  // LDS-DMA instructions per wave and stage
+  constexpr int DPW = STAGE_B / 1024 / NW; // LDS-DMA instructions per wave and stage
   constexpr int NST = 2 * NCH;             // stages per pass
-  constexpr int TPP = 8 * NT;              // 16-row tiles per pass
+  constexpr int TPP = NW * NT;             // 16-row tiles per pass
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* b1s = reinterpret_cast<float*>(smem + NSLOT * STAGE_B);       // (4C) fc1 bias | (C) gamma | (C) beta | (C) fc2 bias
   float* gms = b1s + 4 * C;
@@ -107,8 +110,8 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
 
   // small vectors live in LDS for the whole kernel: read per use with ds_read (a global load per use would be a dependent
   // L2 round trip each -- the register file has no room to hold them)
-  for (int i = tid; i < C; i += 512) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-  for (int i = tid; i < C / 4; i += 512) {
+  for (int i = tid; i < C; i += NTHR) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < C / 4; i += NTHR) {
     reinterpret_cast<float4*>(gms)[i] = reinterpret_cast<const float4*>(p.gamma)[i];
     reinterpret_cast<float4*>(bts)[i] = reinterpret_cast<const float4*>(p.beta)[i];
     reinterpret_cast<float4*>(b2s)[i] = reinterpret_cast<const float4*>(p.b2)[i];
@@ -203,7 +206,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     bool have[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int k = t * 8 + wave;                                   // tile k of the pass -> wave k % 8, slot k / 8
+      const int k = t * NW + wave;                                  // tile k of the pass -> wave k % NW, slot k / NW
       have[t] = k < ntile;
       int64_t r = (int64_t)(tile0 + k) * 16 + fr;
       row[t] = r;
@@ -518,6 +521,7 @@ static int grid_guess(int n_tiles, int cus) { return n_tiles < cus ? n_tiles : c
 extern "C" {
 
 void hfl_internal_set_mlp_ring_pf(int v) { g_mlp_ring_pf = v == 2 ? 2 : 3; }
+void hfl_internal_set_mlp_waves(int v) { g_mlp_waves = v == 4 ? 4 : 8; }
 
 void hfl_internal_set_mlp_stagger(int v) {
   g_mlp_stagger = v & 0xFF;
@@ -650,17 +654,19 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   p.ticket = (g_mlp_dynamic && n_units > grid) ? ticket_slot() : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
-#define HFL_MLP_LAUNCH(CC, NT, PF)                                                                              \
+#define HFL_MLP_LAUNCH(CC, NT, PF, NW)                                                                          \
   {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT, PF>),          \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT, PF, NW>),      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     if (e != hipSuccess) return (int)e;                                                                         \
-    ln_mlp_fused_kernel<CC, NT, PF><<<grid, 512, lds, s>>>(p);                                                  \
+    ln_mlp_fused_kernel<CC, NT, PF, NW><<<grid, NW * 64, lds, s>>>(p);                                          \
   }
-  if (g_mlp_ring_pf == 3) {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3) else HFL_MLP_LAUNCH(128, 2, 3)
+  if (g_mlp_waves == 4) {
+    if (channels == 256) HFL_MLP_LAUNCH(256, 2, 3, 4) else HFL_MLP_LAUNCH(128, 4, 3, 4)
+  } else if (g_mlp_ring_pf == 3) {
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3, 8) else HFL_MLP_LAUNCH(128, 2, 3, 8)
   } else {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2) else HFL_MLP_LAUNCH(128, 2, 2)
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2, 8) else HFL_MLP_LAUNCH(128, 2, 2, 8)
   }
 #undef HFL_MLP_LAUNCH
   if (tp.parts > 0) {

@@ -230,6 +230,7 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 # the output features split over the workgroups (round 4) that shape takes 101 us and the restriction is gone
 # (HFL_QKV_FUSED_MIN_FILL restores it).
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
+_QKV_FUSED_MIN_ROWS = int(os.environ.get('HFL_QKV_FUSED_MIN_ROWS', '24576'))
 _RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
 # LN1 -> qkv -> window attention of the blocks without relay tokens (OctFormer stage) as one launch (csrc/attn_fused.hip)
 _ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
@@ -243,6 +244,8 @@ _ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
 # against 2619-2690 without (same box, alternating runs): twelve more small launches per iteration compete with the finest
 # level's persistent kernels for the CUs the cycle's links were waiting on anyway.  Off by default.
 _RELAY_FIRST = os.environ.get('HFL_RELAY_FIRST', '0') != '0'
+# join every pyramid stream at the end of every H-OSA iteration (the schedule of rounds 2-3); 0: only the true dependencies
+_ITER_JOIN = os.environ.get('HFL_ITER_JOIN', '0') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
 
 
@@ -250,7 +253,7 @@ def _qkv_pack(att: 'OctreeAttention', rows: int):
     """Weight image of the fused LN1 -> qkv launch for this block, or None when the launch does not apply / does not pay."""
     lin = att.qkv
     c = lin.in_features
-    if not (_QKV_FUSED and rows >= _MLP_FUSED_MIN_ROWS and c in (128, 256) and lin.out_features == 3 * c and lin.bias is not None):
+    if not (_QKV_FUSED and rows >= _QKV_FUSED_MIN_ROWS and c in (128, 256) and lin.out_features == 3 * c and lin.bias is not None):
         return None
     if c == 256:
         fill = (rows % 32768) / 32768.0
@@ -1375,6 +1378,8 @@ class HOTFormerStage(nn.Module):
             res = self._iterations_relay_first(data, plan, depths, bufs, rts, nts, proj, part)
             if res is not None:
                 return res
+        done = None          # early schedule: per-level end-of-iteration events of the previous iteration
+        first = None         # ... and the buffers the schedule started from (allocated on the main stream, read by the others)
         for i in range(self.num_blocks):                                # 593-633
             if early:
                 # RTSA of iteration i only feeds the relay rows: what a block does with its TOKEN rows before the window
@@ -1389,12 +1394,21 @@ class HOTFormerStage(nn.Module):
                 # issue order = critical path first (the host runs only just ahead of the GPU here): the finest level's
                 # token phase, RTSA, then the small levels
                 order = sorted(range(len(depths)), key=lambda j: -bufs[depths[j]].shape[0])
-                ev0 = main.record_event()
+                # Who waits for whom.  A level's block i needs that level's block i - 1 (stream order) and, for its relay rows,
+                # RTSA i; RTSA i needs every level's block i - 1.  Nothing else: in particular the finest level's CPE / LN1 /
+                # qkv of iteration i do not wait for the coarse levels' MLP launches of iteration i - 1, which run (starved)
+                # beside and after the finest level's chip-filling fused MLP -- with a join of all streams at the end of every
+                # iteration (HFL_ITER_JOIN=1, rounds 2-3) the finest level's queue stood idle ~80 us per iteration there
+                # (kernel trace, profiles/r04_phases_iteration_timeline_join.log).
+                join = _ITER_JOIN or done is None
+                ev0 = main.record_event() if join else None
+                if first is None:
+                    first = (dict(bufs), dict(rts))
                 calls = {}
 
                 def phase1(j):
                     d = depths[j]
-                    if sts[j] is not main:
+                    if join and sts[j] is not main:
                         sts[j].wait_event(ev0)
                     with torch.cuda.stream(sts[j]):
                         calls[d] = _native_block_call(self.hosa_blocks[j][i], bufs[d], plan, d)
@@ -1402,7 +1416,11 @@ class HOTFormerStage(nn.Module):
                             calls[d].run(1)
 
                 phase1(order[0])
-                rs.wait_event(ev0)
+                if join:
+                    rs.wait_event(ev0)
+                else:
+                    for ev in done:
+                        rs.wait_event(ev)
                 with torch.cuda.stream(rs):
                     rt_all = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
                     ev_rt = rs.record_event()
@@ -1448,9 +1466,12 @@ class HOTFormerStage(nn.Module):
                     with torch.cuda.stream(sts[j]):
                         bufs[depths[j]] = outs[j]
                         rts[depths[j]] = self.up_projections[j][i](outs[j][nts[j]:]) if proj else outs[j][nts[j]:]
-                for j in range(len(depths)):
-                    if sts[j] is not main:
-                        main.wait_stream(sts[j])
+                if _ITER_JOIN or i + 1 == self.num_blocks:
+                    for j in range(len(depths)):
+                        if sts[j] is not main:
+                            main.wait_stream(sts[j])
+                else:
+                    done = [st.record_event() for st in dict.fromkeys(sts)]
                 del calls, old, fresh, rt_all
                 continue
             rt_all = torch.cat([rts[d] for d in depths], 0)
