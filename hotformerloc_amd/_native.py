@@ -90,6 +90,10 @@ SIGNATURES = {
     'hfl_tap_tiles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'hfl_pad_index': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'hfl_pad_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    'hfl_attn_pool_ok': (c_int, [c_int]),
+    'hfl_attn_pool_workspace': (c_int64, [c_int, c_int, c_int, c_int64]),
+    'hfl_attn_pool': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float, c_void_p,
+                              c_int64, c_void_p]),
     'hfl_window_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
                                          ctypes.POINTER(WindowAttnDesc), c_void_p]),
     'hfl_window_attention_fwd_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

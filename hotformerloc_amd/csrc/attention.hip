@@ -1501,6 +1501,7 @@ void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
 void hfl_internal_set_mlp_ring_pf(int v);
 void hfl_internal_set_mlp_waves(int v);
+void hfl_internal_set_qkv_waves(int v);
 void hfl_internal_set_qkv_ring_pf(int v);
 void hfl_internal_set_mlp_tail_split(int v);
 void hfl_internal_set_mlp_dynamic(int v);
@@ -1563,6 +1564,7 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
     hfl_internal_set_mlp_ring_pf(3);
     hfl_internal_set_mlp_waves(8);
+    hfl_internal_set_qkv_waves(8);
     hfl_internal_set_qkv_ring_pf(3);
     hfl_internal_set_mlp_tail_split(1);
     hfl_internal_set_qkv_tail_split(1);
@@ -1589,6 +1591,8 @@ int hfl_set_variant(const char* key, int value) {
   } else if (is("tail_split")) {
     hfl_internal_set_mlp_tail_split(value);
     hfl_internal_set_qkv_tail_split(value);
+  } else if (is("qkv_waves")) {
+    hfl_internal_set_qkv_waves(value);
   } else if (is("mlp_waves")) {
     hfl_internal_set_mlp_waves(value);
   } else if (is("ring_pf")) {

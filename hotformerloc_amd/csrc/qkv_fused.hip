@@ -405,11 +405,13 @@ qkv_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w, i
 }  // namespace
 
 static int g_qkv_ring_pf = 3;
+static int g_qkv_waves = 8;       // probe knob 'qkv_waves' (8 | 4)
 static int g_qkv_tail_split = 1;    // probe knob 'qkv_tail_split'
 
 extern "C" {
 
 void hfl_internal_set_qkv_ring_pf(int v) { g_qkv_ring_pf = v == 2 ? 2 : 3; }
+void hfl_internal_set_qkv_waves(int v) { g_qkv_waves = v == 4 ? 4 : 8; }
 void hfl_internal_set_qkv_tail_split(int v) { g_qkv_tail_split = v ? 1 : 0; }
 // (work units by atomic ticket as in csrc/mlp_fused.hip were tried here too: the unit decode in the pass loop pushed the C = 256
 // instance from 256 VGPRs / no scratch to 14 spilled dwords with reloads behind the stage barriers; the static deal stays)
@@ -445,8 +447,8 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
   if (g_qkv_reserve > 0 && cus - g_qkv_reserve >= 64 && p.n_tiles > (int64_t)cus * (channels == 256 ? 8 : 16)) cus -= g_qkv_reserve;
   const int grid = p.n_tiles < cus ? p.n_tiles : cus;
-  const int nt = channels == 256 ? 1 : 2, waves = 8;       // (C = 256 with 2 tiles per wave spills, with 4 waves x 4 tiles
-                                                             //  a stage takes 3-5 us: tools/qkv_fused_probe.py)
+  // (C = 256 with 8 waves x 2 tiles spills; probe knob 'qkv_waves' = 4: one wave per SIMD with 512 registers, 2 [4] tiles each)
+  const int waves = g_qkv_waves, nt = (channels == 256 ? 1 : 2) * (8 / waves);
   p.stagger = p.n_tiles > (int64_t)grid * waves * nt ? 1 : 0;          // only when a workgroup walks several passes
   p.stagger_groups = 8;
   p.full_passes = 0; p.tail_tile0 = 0; p.tail_sets = 0; p.tail_parts = 0;
@@ -474,7 +476,9 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
     if (e != hipSuccess) return (int)e;                                                                         \
     ln_qkv_fused_kernel<CC, NT, WW, PF><<<grid, WW * 64, lds, s>>>(p);                                          \
   }
-  if (g_qkv_ring_pf == 3) {
+  if (waves == 4) {
+    if (channels == 256) HFL_QKV_LAUNCH(256, 2, 4, 3) else HFL_QKV_LAUNCH(128, 4, 4, 3)
+  } else if (g_qkv_ring_pf == 3) {
     if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 3) else HFL_QKV_LAUNCH(128, 2, 8, 3)
   } else {
     if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 2) else HFL_QKV_LAUNCH(128, 2, 8, 2)

@@ -234,6 +234,9 @@ _QKV_FUSED_MIN_ROWS = int(os.environ.get('HFL_QKV_FUSED_MIN_ROWS', '24576'))
 _RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
 # LN1 -> qkv -> window attention of the blocks without relay tokens (OctFormer stage) as one launch (csrc/attn_fused.hip)
 _ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
+# attentional pooling of the head as one launch per level (csrc/attn_pool.hip) instead of GEMM + segment softmax + two
+# padding copies + batched GEMM
+_ATTN_POOL = os.environ.get('HFL_ATTN_POOL', '1') != '0'
 # H-OSA iterations, relay rows first: after the window attention every level runs proj + MLP of its RELAY rows (2 % of the
 # rows, three small launches) before those of its token rows, so that the next iteration's relay-token self-attention -- which
 # needs nothing else -- starts beside the token rows' proj / MLP instead of after the slowest level's.  Why: the kernel trace
@@ -1609,10 +1612,13 @@ class AdaptivePooling(nn.Module):
         self.query = nn.Parameter(torch.randn(k_pooled_tokens, feature_dim))
         self.scale = feature_dim ** -0.5
 
-    def forward(self, x, plan: WindowPlan, depth: int):
-        """x (N_t, C) ragged over clouds -> (B, k, C)."""
+    def forward(self, x, plan: WindowPlan, depth: int, out=None):
+        """x (N_t, C) ragged over clouds -> (B, k, C) (`out`: where to, e.g. this level's slice of the token matrix)."""
         if _grad_path(x):
             return ag.attentional_pooling_torch(x, self.query, plan, depth, self.scale)
+        if _ATTN_POOL and _GEMM_MODE == 'x3' and _split_path(x) and x.dtype == torch.float32 and ops.attn_pool_ok(x.shape[1]):
+            # scores -> softmax over the cloud's rows -> weighted sum in one launch, nothing padded (csrc/attn_pool.hip)
+            return ops.attn_pool(x, plan.cloud_off[depth], self.query, plan.B, self.scale, out=out)
         scores = torch.mm(x, self.query.t())                              # (N_t, k)
         ops.segment_softmax_(scores, plan.cloud_off[depth], plan.B, self.scale)
         nmax = plan.pad_index[depth].numel() // plan.B
@@ -1704,6 +1710,20 @@ class PyramidAttnPoolWrapper(nn.Module):
         self.descriptor_extractor = Mixer(total, k_out, feature_size, mix_depth, mlp_ratio, out_d)
 
     def forward(self, local_feat_dict, plan: WindowPlan, depth=None):
+        feats = list(local_feat_dict.items())
+        if (not self.use_projections and not _grad_path() and feats and feats[0][1].is_cuda
+                and all(f.shape[1] == feats[0][1].shape[1] and f.dtype == torch.float32 for _, f in feats)):
+            # every level writes its k_j tokens straight into the (B, sum k, C) token matrix: no torch.cat
+            all_t = torch.empty((plan.B, sum(self.k_pooled_tokens), feats[0][1].shape[1]), dtype=torch.float32,
+                                device=feats[0][1].device)
+            off = 0
+            for j, (d, f) in enumerate(feats):
+                k = self.k_pooled_tokens[j]
+                t = self.attpool[j](f, plan, d, out=all_t[:, off:off + k])
+                if t.data_ptr() != all_t[:, off:off + k].data_ptr():
+                    all_t[:, off:off + k].copy_(t)
+                off += k
+            return self.descriptor_extractor(all_t)
         toks = []
         for j, d in enumerate(local_feat_dict.keys()):
             t = self.attpool[j](local_feat_dict[d], plan, d)

@@ -857,6 +857,28 @@ def pad_rows(x: torch.Tensor, row_off: torch.Tensor, batch: int, nmax: int):
     return out
 
 
+def attn_pool_ok(channels: int) -> bool:
+    return bool(_native.load().hfl_attn_pool_ok(int(channels)))
+
+
+def attn_pool(x: torch.Tensor, row_off: torch.Tensor, query: torch.Tensor, batch: int, scale: float, out=None):
+    """(batch, k, C) = per cloud softmax(scale * query x^T) x over the cloud's rows of the ragged x (N, C)
+    (hfl_attn_pool: salsa.py:25-55).  `out`: a (batch, k, C) view, possibly a slice of a wider token matrix along dim 1."""
+    _dev(x, row_off, query)
+    x, query = _f32c(x), _f32c(query)
+    assert row_off.dtype == torch.int64 and row_off.numel() == batch + 1 and query.shape[1] == x.shape[1]
+    k, c = query.shape
+    if out is None:
+        out = torch.empty((batch, k, c), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape == (batch, k, c) and out.stride(2) == 1 and out.stride(1) == c
+    lib = _native.load()
+    nb = lib.hfl_attn_pool_workspace(batch, k, c, x.shape[0])
+    ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=x.device)
+    check(lib.hfl_attn_pool(out.data_ptr(), out.stride(0), x.data_ptr(), row_off.data_ptr(), query.data_ptr(), batch, k, c,
+                            x.shape[0], float(scale), ws.data_ptr(), int(nb), _stream()), 'hfl_attn_pool')
+    return out
+
+
 # ---------------------------------------------------------------------- attention
 _RPE2_CACHE = {}        # (id(table), depth) -> (weakref to table, version, expanded table)
 

@@ -191,6 +191,18 @@ int hfl_pad_index(int64_t* out, const int64_t* row_off, int batch, int64_t nmax,
  * (the per-cloud split + zero padding of models/layers/pooling.py:209-233 without an index table or an appended zero row). */
 int hfl_pad_rows(float* out, const float* x, const int64_t* row_off, int batch, int64_t nmax, int64_t channels,
                  hfl_stream_t stream);
+/* Attentional pooling of a level's ragged per-cloud rows by learned queries as ONE launch (+ a combine when the rows of a
+ * cloud are split over workgroups) -- AdaptivePooling.forward, models/layers/salsa.py:25-55, per level from
+ * PyramidAttnPoolWrapper.forward, models/layers/pooling.py:209-233:
+ *     out[b, q, :] = sum_r softmax_r(scale * <query[q], x[r]>) x[r],   r over rows row_off[b] .. row_off[b + 1] of x (n_rows, C)
+ * out + b * out_cloud_stride + q * C is row q of cloud b (so a level can write its slice of the concatenated token matrix).
+ * Products as bf16 (hi, lo) splits with fp32 accumulation, softmax in fp32.  channels in {128, 256} (hfl_attn_pool_ok);
+ * workspace: hfl_attn_pool_workspace bytes (without it a cloud's rows stay in one workgroup per 64 queries). */
+int hfl_attn_pool_ok(int channels);
+int64_t hfl_attn_pool_workspace(int batch, int n_queries, int channels, int64_t n_rows);
+int hfl_attn_pool(float* out, int64_t out_cloud_stride, const float* x, const int64_t* row_off, const float* query, int batch,
+                  int n_queries, int channels, int64_t n_rows, float scale, void* workspace, int64_t workspace_bytes,
+                  hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 4. Windowed multi-head attention over z-order octree windows

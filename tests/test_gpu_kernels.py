@@ -531,6 +531,49 @@ def test_layer_norm_and_fused_add():
     assert torch.allclose(got, torch.nn.functional.layer_norm(x3, (256,)), atol=2e-6, rtol=1e-5)
 
 
+def test_attn_pool_matches_fp64_pooling():
+    """hfl_attn_pool (scores -> softmax over the cloud's rows -> weighted sum in one launch) against the pooling of
+    models/layers/salsa.py:25-55 in fp64 on ragged clouds: long and short clouds, a cloud of one row, query counts that are
+    not multiples of 16 / 64, both channel widths; tolerance of the three-term bf16 split (scores to ~1e-4 absolute).  Also
+    against the launches it replaces, and a slice of a wider token matrix as destination."""
+    g = torch.Generator().manual_seed(11)
+    for C, k, sizes in ((256, 148, [2130, 1977, 1, 33, 2500, 640, 31, 2048]), (256, 36, [65, 70, 3, 64]),
+                        (256, 72, [446, 500, 17]), (128, 20, [900, 5, 300])):
+        n = sum(sizes)
+        x = torch.randn(n, C, generator=g) * 1.3 + 0.2
+        q = torch.randn(k, C, generator=g)
+        off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+        scale = C ** -0.5
+        want = torch.empty(len(sizes), k, C, dtype=torch.float64)
+        for b in range(len(sizes)):
+            xb = x[off[b]:off[b + 1]].double()
+            want[b] = torch.softmax(q.double() @ xb.t() * scale, dim=-1) @ xb
+        xd, qd, od = x.to(DEV), q.to(DEV), off.to(DEV)
+        got = ops.attn_pool(xd, od, qd, len(sizes), scale)
+        assert got.shape == (len(sizes), k, C)
+        err = (got.cpu().double() - want).abs().max().item()
+        assert err < 6e-4, (C, k, err)
+        # the launches it replaces (fp32 GEMM, segment softmax, padded batched GEMM)
+        sc = torch.mm(xd, qd.t())
+        ops.segment_softmax_(sc, od, len(sizes), scale)
+        nmax = max(sizes)
+        old = torch.bmm(ops.pad_rows(sc, od, len(sizes), nmax).transpose(1, 2), ops.pad_rows(xd, od, len(sizes), nmax)) \
+            if k % 4 == 0 else None
+        if old is not None:
+            assert (got - old).abs().max().item() < 6e-4
+        # into a slice of a wider (B, K, C) matrix
+        wide = torch.full((len(sizes), k + 24, C), 7.0, device=DEV)
+        ops.attn_pool(xd, od, qd, len(sizes), scale, out=wide[:, 8:8 + k])
+        assert torch.equal(wide[:, 8:8 + k], got) and bool((wide[:, :8] == 7.0).all()) and bool((wide[:, 8 + k:] == 7.0).all())
+        # one workgroup per (cloud, query group) -- no workspace -- gives the same result up to the order of the sums
+        lib = _native.load()
+        one = torch.empty_like(got)
+        assert lib.hfl_attn_pool(one.data_ptr(), one.stride(0), xd.data_ptr(), od.data_ptr(), qd.data_ptr(), len(sizes), k, C, n,
+                                 float(scale), None, 0, None) == 0
+        torch.cuda.synchronize()
+        assert (one - got).abs().max().item() < 2e-5
+
+
 def test_layer_norm_relu_f32_and_split2():
     """hfl_layer_norm_relu (norm -> ReLU behind every stem convolution, octformer_layers.py:80-98, in one pass): the fp32 form
     equals relu(LayerNorm) of the two-launch form bit for bit, the split2 form equals split2 of it bit for bit."""

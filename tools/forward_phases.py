@@ -23,15 +23,17 @@ def short(name):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    heads = [i for i, r in enumerate(rows) if 'segment_softmax' in r['Kernel_Name']]
-    end = heads[-1]
-    start = heads[-4] + 1
-    fwd = rows[start:end + 1]
-    # skip trailing kernels of the previous forward's head (mixer etc.): the forward starts at the first tap_count / token_meta / gather
-    for i, r in enumerate(fwd):
-        if any(k in r['Kernel_Name'] for k in ('tap_count', 'gather_kernel', 'token_meta', 'pad_index')):
-            fwd = fwd[i:]
-            break
+    # a forward starts with the per-batch tap tables (tap_count_kernel, > 1 ms after the previous one) and runs up to the next
+    # forward's start: the last COMPLETE forward of the trace
+    starts, last = [], -10 ** 18
+    for i, r in enumerate(rows):
+        if 'tap_count_kernel' in r['Kernel_Name']:
+            t = int(r['Start_Timestamp'])
+            if t - last > 1000000:
+                starts.append(i)
+            last = t
+    fwd = rows[starts[-2]:starts[-1]]
+    # (kernels of the previous forward's head may still trail on other queues: drop what ends before the first table kernel)
     t0 = int(fwd[0]['Start_Timestamp'])
     t1 = max(int(r['End_Timestamp']) for r in fwd)
     print('last forward: %d kernels, %.3f ms wall' % (len(fwd), (t1 - t0) / 1e6))
@@ -56,7 +58,7 @@ def main():
         cands = [int(r['Start_Timestamp']) for r in fwd if 'cpe_fwd_kernel<64>' in r['Kernel_Name'] and prev < int(r['Start_Timestamp']) < t]
         marks.append(('H-OSA iteration %d' % i, min(cands) if cands else t))
         prev = t
-    t_head = first(lambda n: 'segment_softmax' in n)
+    t_head = first(lambda n: 'attn_pool_kernel' in n or 'segment_softmax' in n)
     marks.append(('pooling head', t_head))
     marks.append(('end', t1))
     main_q = collections.Counter(r['Queue_Id'] for r in fwd).most_common(1)[0][0]

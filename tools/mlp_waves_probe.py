@@ -21,17 +21,25 @@ def main():
         b1, b2 = (torch.randn(4 * C, generator=g) * 0.1).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
         gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
         mpack = ops.mlp_fused_pack(w1, w2)
+        wq = (torch.randn(3 * C, C, generator=g) * 0.06).to(dev)
+        bq = (torch.randn(3 * C, generator=g) * 0.1).to(dev)
+        qpack = ops.qkv_fused_pack(wq)
         out = torch.empty_like(x)
+        qout = torch.empty((rows, 3 * C), dtype=torch.float32, device=dev)
         res = {}
         for nw in (8, 4, 8, 4):
             lib.hfl_set_variant(b'mlp_waves', nw)
+            lib.hfl_set_variant(b'qkv_waves', nw)
             tm = timeit(lambda: ops.ln_mlp_fused(x, gamma, beta, 1e-5, mpack, b1, b2, out=out))
-            res.setdefault(nw, []).append((tm, out.clone()))
+            tq = timeit(lambda: ops.ln_qkv_fused(x, gamma, beta, 1e-5, qpack, bq, 0.36, out=qout)) if rows >= 4096 else 0.0
+            res.setdefault(nw, []).append((tm, out.clone(), tq, qout.clone()))
         same = torch.equal(res[8][0][1].view(torch.int32), res[4][0][1].view(torch.int32))
+        same_q = torch.equal(res[8][0][3].view(torch.int32), res[4][0][3].view(torch.int32))
         flop = 16.0 * rows * C * C * 3
-        print('rows %6d C %3d | 8 waves %s us (%.0f TF/s bf16)   4 waves %s us (%.0f TF/s)   bits equal %s'
+        print('rows %6d C %3d | mlp 8 waves %s us (%.0f TF/s bf16)   4 waves %s us (%.0f TF/s)   bits equal %s | qkv 8 waves %s  4 waves %s  bits equal %s'
               % (rows, C, ['%.1f' % r[0] for r in res[8]], flop / min(r[0] for r in res[8]) / 1e6,
-                 ['%.1f' % r[0] for r in res[4]], flop / min(r[0] for r in res[4]) / 1e6, same), flush=True)
+                 ['%.1f' % r[0] for r in res[4]], flop / min(r[0] for r in res[4]) / 1e6, same,
+                 ['%.1f' % r[2] for r in res[8]], ['%.1f' % r[2] for r in res[4]], same_q), flush=True)
     lib.hfl_set_variant(b'reset', 0)
 
 
