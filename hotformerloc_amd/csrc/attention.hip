@@ -1501,6 +1501,8 @@ void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
 void hfl_internal_set_mlp_ring_pf(int v);
 void hfl_internal_set_mlp_waves(int v);
+void hfl_internal_set_mlp_lag(int v);
+void hfl_internal_set_mlp_dbg(int v);
 void hfl_internal_set_qkv_waves(int v);
 void hfl_internal_set_qkv_ring_pf(int v);
 void hfl_internal_set_mlp_tail_split(int v);
@@ -1564,6 +1566,8 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
     hfl_internal_set_mlp_ring_pf(3);
     hfl_internal_set_mlp_waves(8);
+    hfl_internal_set_mlp_lag(0);
+    hfl_internal_set_mlp_dbg(0);
     hfl_internal_set_qkv_waves(8);
     hfl_internal_set_qkv_ring_pf(3);
     hfl_internal_set_mlp_tail_split(1);
@@ -1593,6 +1597,10 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_qkv_tail_split(value);
   } else if (is("qkv_waves")) {
     hfl_internal_set_qkv_waves(value);
+  } else if (is("mlp_dbg")) {
+    hfl_internal_set_mlp_dbg(value);
+  } else if (is("mlp_lag")) {
+    hfl_internal_set_mlp_lag(value);
   } else if (is("mlp_waves")) {
     hfl_internal_set_mlp_waves(value);
   } else if (is("ring_pf")) {

@@ -20,7 +20,7 @@
 //         B = columns of X by ds_read_b64_tr_b16 from the same LDS image
 //   * arithmetic as everywhere on the default path: every fp32 operand as bf16 (hi, lo), three MFMAs per product
 //     (v_mfma_f32_16x16x32_bf16), fp32 accumulation, softmax in fp32 (exp2 domain).
-//   * S > 1 row chunks per cloud (so that ~one workgroup per CU exists): each writes (m, l, unnormalised O); a second kernel
+//   * S > 1 row chunks per cloud (so that ~two workgroups per CU exist): each writes (m, l, unnormalised O); a second kernel
 //     merges them in fixed order (bitwise reproducible, no atomics).
 #include "hfl_common.h"
 #include "x3_math.h"
@@ -312,7 +312,7 @@ struct PoolPlan {
 static PoolPlan pool_plan(int batch, int n_queries, int64_t n_rows, int cus) {
   PoolPlan pl;
   pl.G = (n_queries + kPoolWaves * 16 - 1) / (kPoolWaves * 16);
-  int s = cus / (batch * pl.G > 0 ? batch * pl.G : 1);
+  int s = 2 * cus / (batch * pl.G > 0 ? batch * pl.G : 1);     // two workgroups per CU (4 waves, 64 KB of LDS each)
   const int64_t avg = batch > 0 ? n_rows / batch : 0;
   while (s > 1 && avg / s < 96) --s;           // at least three 32-row steps per chunk
   pl.S = s < 1 ? 1 : (s > 16 ? 16 : s);

@@ -76,11 +76,16 @@ struct MlpFusedParams {
 static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
 static int g_mlp_stagger_groups = 8;
 static int g_mlp_ring_pf = 3;      // probe knob 'ring_pf': stages of the weight stream in flight ahead of the consumed one (2 | 3)
+static int g_mlp_dbg = 0;          // probe knob 'mlp_dbg': timing ablations (see the kernel), 0 = off
+static int g_mlp_lag = 0;          // probe knob 'mlp_lag': the second wave of every SIMD one stage behind the first
 static int g_mlp_waves = 8;        // probe knob 'mlp_waves': waves per workgroup (8: one 16-row tile each at C = 256; 4: two each)
 
-template <int C, int NT, int PF, int NW>
+// DBG (probe knob 'mlp_dbg', timing ablations only -- results are wrong): 1 GELU -> identity, 2 no bias / GELU / split at all,
+// 4 no refill of the weight ring, 8 no barrier at the stage boundaries
+template <int C, int NT, int PF, int NW, int LAG, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
 ln_mlp_fused_kernel(const MlpFusedParams p) {
+  static_assert(LAG == 0 || (PF == 2 && NW == 8), "the late half keeps a stage one step longer: two stages ahead, not three");
   static_assert(PF == 2 || PF == 3, "stages in flight ahead of the one being consumed");
   static_assert(NW == 8 || NW == 4, "waves per workgroup: two per SIMD with 256 registers each, or one with 512");
   constexpr int NTHR = NW * 64;
@@ -120,6 +125,11 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
 
   // ---- stage stream: stage n of a pass lives at pack + n * STAGE_B; wave w copies bytes [w, w+1) * DPW KiB of it
   const uint32_t lane_off = (uint32_t)lane * 16u;
+  // LAG: waves NW/2 .. NW-1 (the second wave of every SIMD) run one stage behind the first half.  Stages alternate GEMM1 +
+  // GELU (VALU between the MFMAs) and GEMM2 (MFMAs only): in lock-step both waves of a SIMD are in the same kind of stage
+  // and the GELU's vector instructions queue behind the MFMA issue of BOTH (PMC: VALU under a running MFMA 4 % of the MFMA
+  // time); one stage apart, one wave's GELU fills the issue gaps of the other's GEMM2.
+  const bool lagw = LAG != 0 && wave >= NW / 2;
   uint32_t seq = 0;                         // stages acquired so far (all passes): slot = seq % NSLOT
   // A pass over the hidden chunks [c0, c0 + nch) (all of them except in the tail) consumes the stages A_c0, A_c0+1, B_c0, ...,
   // A_last, B_last-1, B_last: in the pack's stage order (A0, A1, B0, A2, B1, ...) that is index 2 c0 - 1 (0 for c0 = 0), then
@@ -145,24 +155,30 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   // stage n (dma_piece).  Two stages in flight, four slots.
   int dma_n = 0;                            // stage whose pieces the current stage body issues (NST: none)
   uint32_t dma_slot = 0;
+  const unsigned char* dma_src = p.pack;    // this lane's source of piece 0 of that stage, and the wave's LDS destination
+  unsigned char* dma_dst = smem;
   auto acquire = [&](int n) -> const unsigned char* {
     // stages issued after stage n so far: n + 1 .. n + PF - 1 (those that exist); this wave's pieces of them may stay in flight
     if (n + PF - 1 < nst) HFL_WAIT_VM((PF - 1) * DPW);
     else if (n + 1 < nst) HFL_WAIT_VM((PF - 2) * DPW > 0 ? (PF - 2) * DPW : 0);
     else HFL_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(DBG & 8)) __builtin_amdgcn_s_barrier();
     dma_n = n + PF;
     dma_slot = (seq + PF) % NSLOT;
-    const unsigned char* st = smem + (seq % NSLOT) * STAGE_B;
+    // the refill's addresses once per stage: its pieces differ in the instruction's immediate offset only (which advances
+    // the global and the LDS address alike) -- per piece this was a stage-index select, a 64-bit multiply-add and an M0 write
+    dma_src = p.pack + (int64_t)sidx(dma_n < nst ? dma_n : 0) * STAGE_B + wave * (DPW * 1024) + lane_off;
+    dma_dst = smem + dma_slot * STAGE_B + wave * (DPW * 1024);
+    const unsigned char* st = smem + ((seq - (lagw ? 1u : 0u)) % NSLOT) * STAGE_B;   // (late half: the stage before)
     ++seq;
     return st;
   };
-  auto dma_piece = [&](int i) {
+  auto dma_piece = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (DBG & 4) return;
     if (dma_n < nst)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(p.pack + (int64_t)sidx(dma_n) * STAGE_B + wave * (DPW * 1024) +
-                                                          i * 1024 + lane_off),
-          (__attribute__((address_space(3))) void*)(smem + dma_slot * STAGE_B + wave * (DPW * 1024) + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)dma_src,
+                                       (__attribute__((address_space(3))) void*)dma_dst, 16, i * 1024, 0);
   };
   constexpr int PPH = DPW / 2;              // pieces per half stage
 
@@ -276,10 +292,16 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     auto gelu_pair = [&](int pidx, f32x4 (&hp)[2][NT], int chunk) {
       const int t = pidx >> 2, d = pidx & 3;
       const int i = d >> 1, r0 = 2 * (d & 1);
-      const float2 b = *reinterpret_cast<const float2*>(b1s + (c0 + chunk) * 32 + i * 16 + fq * 4 + r0);
+      if constexpr (DBG & 2) {
+        gh[t][d] = __float_as_uint(hp[i][t][r0]);
+        gl[t][d] = __float_as_uint(hp[i][t][r0 + 1]);
+        return;
+      }
+      (void)chunk;                  // (the bias is in the accumulators already: gemm1_half)
       // SCALAR f32 math on purpose (and -fno-slp-vectorize for this file): beside MFMAs a v_pk_*_f32 costs ~12 extra
       // cycles of the matrix pipe each (MI355X_MICROARCH.md, cycle constants), a plain VALU op hides in the MFMA's shadow
-      const float g0 = x3_gelu(hp[i][t][r0] + b.x), g1 = x3_gelu(hp[i][t][r0 + 1] + b.y);
+      const float g0 = (DBG & 1) ? hp[i][t][r0] : x3_gelu(hp[i][t][r0]);
+      const float g1 = (DBG & 1) ? hp[i][t][r0 + 1] : x3_gelu(hp[i][t][r0 + 1]);
       uint32_t hi, lo;
       x3_split_pair_scalar(g0, g1, hi, lo);
       gh[t][d] = hi;
@@ -289,10 +311,16 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     auto gemm1_half = [&](const unsigned char* st, auto hfc, f32x4 (&h)[2][NT], f32x4 (&hp)[2][NT], int prev_chunk, bool with_gelu) {
       constexpr int hf = decltype(hfc)::value;
       if (hf == 0) {
+        // the accumulators start from the fc1 bias (lane: hidden 16 i + 4 fq .. + 3 of the chunk): read here, in front of the
+        // first fragment read and waited for with it -- as a ds_read inside the GELU (rounds 3-4) its lgkmcnt(0) also waited
+        // for the fragment prefetch issued just before, i.e. it serialised every k-step's LDS round trip with its MFMAs
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          const f32x4 bi = (DBG & 2) ? (f32x4){0.f, 0.f, 0.f, 0.f}
+                                     : *reinterpret_cast<const f32x4*>(b1s + (c0 + prev_chunk + (with_gelu ? 1 : 0)) * 32 + i * 16 + fq * 4);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) h[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < NT; ++t) h[i][t] = bi;
+        }
       }
       // fragments of k-step kk + 1 are requested before the MFMAs of k-step kk (two register sets): the LDS round trip
       // (~200 cycles) would otherwise be exposed in front of every 6 NT MFMAs
@@ -325,7 +353,8 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
             if (ks % (KS / (4 * NT)) == 0) gelu_pair(ks / (KS / (4 * NT)), hp, prev_chunk);
           }
         }
-        if constexpr ((kk + 1) % ((KS / 2) / PPH) == 0) dma_piece(hf * PPH + (kk + 1) / ((KS / 2) / PPH) - 1);
+        if constexpr ((kk + 1) % ((KS / 2) / PPH) == 0)
+          dma_piece(std::integral_constant<int, hf * PPH + (kk + 1) / ((KS / 2) / PPH) - 1>{});
         if constexpr (kk + 1 < KS / 2)
           HFL_LDS_WAIT4_AFTER(wf[(kk + 1) & 1][0], wf[(kk + 1) & 1][1], wf[(kk + 1) & 1][2], wf[(kk + 1) & 1][3], h[1][NT - 1]);
       });
@@ -357,7 +386,8 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
             oacc[i0 + u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ss & 1][2 * u], __builtin_bit_cast(bf16x8, gh[t]), oacc[i0 + u][t], 0, 0, 0);
           }
         }
-        if constexpr ((ss + 1) % ((FT / 4) / PPH) == 0) dma_piece(hf * PPH + (ss + 1) / ((FT / 4) / PPH) - 1);
+        if constexpr ((ss + 1) % ((FT / 4) / PPH) == 0)
+          dma_piece(std::integral_constant<int, hf * PPH + (ss + 1) / ((FT / 4) / PPH) - 1>{});
         if constexpr (ss + 1 < FT / 4)
           HFL_LDS_WAIT4_AFTER(wf[(ss + 1) & 1][0], wf[(ss + 1) & 1][1], wf[(ss + 1) & 1][2], wf[(ss + 1) & 1][3],
                               oacc[hf * (FT / 2) + 2 * ss + 1][NT - 1]);
@@ -368,27 +398,39 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
     // (waves without a row tile in this pass still carry their share of the weight stream)
     int n = 0;
     const unsigned char* st = acquire(n++);
-    auto idle_pieces = [&]() {
-#pragma unroll
-      for (int i = 0; i < DPW; ++i) dma_piece(i);
+    auto idle_pieces = [&]() { hfl_static_for(std::make_integer_sequence<int, DPW>{}, [&](auto ic) { dma_piece(ic); }); };
+    // step boundaries: the early half crosses one AFTER each stage body (the next stage), the late half BEFORE it (step 0 of
+    // the late half is empty; its last stage landed at the previous boundary) -- the same number of barriers for both
+    if (lagw) idle_pieces();
+    auto enter = [&]() {
+      if (lagw) {
+        if (n < nst) {
+          st = acquire(n++);
+        } else {
+          st = smem + ((seq - 1u) % NSLOT) * STAGE_B;
+          dma_n = nst;
+        }
+      }
     };
     auto stage1 = [&](f32x4 (&h)[2][NT], f32x4 (&hp)[2][NT], int prev_chunk, bool with_gelu) {
+      enter();
       if (active) {
         gemm1_half(st, std::integral_constant<int, 0>{}, h, hp, prev_chunk, with_gelu);
         gemm1_half(st, std::integral_constant<int, 1>{}, h, hp, prev_chunk, with_gelu);
       } else {
         idle_pieces();
       }
-      st = acquire(n++);
+      if (!lagw) st = acquire(n++);
     };
     auto stage2 = [&](bool more) {
+      enter();
       if (active) {
         gemm2_half(st, std::integral_constant<int, 0>{});
         gemm2_half(st, std::integral_constant<int, 1>{});
       } else {
         idle_pieces();
       }
-      if (more) st = acquire(n++);
+      if (!lagw && more) st = acquire(n++);
     };
     stage1(hA, hB, 0, false);                                             // A0
 #pragma unroll 1
@@ -522,6 +564,8 @@ extern "C" {
 
 void hfl_internal_set_mlp_ring_pf(int v) { g_mlp_ring_pf = v == 2 ? 2 : 3; }
 void hfl_internal_set_mlp_waves(int v) { g_mlp_waves = v == 4 ? 4 : 8; }
+void hfl_internal_set_mlp_lag(int v) { g_mlp_lag = v ? 1 : 0; }
+void hfl_internal_set_mlp_dbg(int v) { g_mlp_dbg = v; }
 
 void hfl_internal_set_mlp_stagger(int v) {
   g_mlp_stagger = v & 0xFF;
@@ -654,19 +698,37 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   p.ticket = (g_mlp_dynamic && n_units > grid) ? ticket_slot() : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
-#define HFL_MLP_LAUNCH(CC, NT, PF, NW)                                                                          \
+#define HFL_MLP_LAUNCH(CC, NT, PF, NW, LAG)                                                                     \
   {                                                                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT, PF, NW>),      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT, PF, NW, LAG>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
     if (e != hipSuccess) return (int)e;                                                                         \
-    ln_mlp_fused_kernel<CC, NT, PF, NW><<<grid, NW * 64, lds, s>>>(p);                                          \
+    ln_mlp_fused_kernel<CC, NT, PF, NW, LAG><<<grid, NW * 64, lds, s>>>(p);                                     \
   }
-  if (g_mlp_waves == 4) {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 2, 3, 4) else HFL_MLP_LAUNCH(128, 4, 3, 4)
+  if (g_mlp_dbg && channels == 256) {
+#define HFL_MLP_DBG(D)                                                                                          \
+  {                                                                                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<256, 1, 3, 8, 0, D>),           \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+    ln_mlp_fused_kernel<256, 1, 3, 8, 0, D><<<grid, 512, lds, s>>>(p);                                          \
+  }
+    switch (g_mlp_dbg) {
+      case 1: HFL_MLP_DBG(1) break;
+      case 3: HFL_MLP_DBG(3) break;
+      case 4: HFL_MLP_DBG(4) break;
+      case 7: HFL_MLP_DBG(7) break;
+      case 8: HFL_MLP_DBG(8) break;
+      default: HFL_MLP_DBG(15) break;
+    }
+#undef HFL_MLP_DBG
+  } else if (g_mlp_waves == 4) {
+    if (channels == 256) HFL_MLP_LAUNCH(256, 2, 3, 4, 0) else HFL_MLP_LAUNCH(128, 4, 3, 4, 0)
+  } else if (g_mlp_lag) {
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2, 8, 1) else HFL_MLP_LAUNCH(128, 2, 2, 8, 1)
   } else if (g_mlp_ring_pf == 3) {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3, 8) else HFL_MLP_LAUNCH(128, 2, 3, 8)
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3, 8, 0) else HFL_MLP_LAUNCH(128, 2, 3, 8, 0)
   } else {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2, 8) else HFL_MLP_LAUNCH(128, 2, 2, 8)
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2, 8, 0) else HFL_MLP_LAUNCH(128, 2, 2, 8, 0)
   }
 #undef HFL_MLP_LAUNCH
   if (tp.parts > 0) {

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+out=gpurun_out
+python -c "from hotformerloc_amd import _native; _native.load(); print('library ok')" || exit 1
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q > $out/r04_ab_tests.log 2>&1; tail -4 $out/r04_ab_tests.log
+timeout 900 python -m pytest tests/test_gpu_model.py -x -q > $out/r04_ab_tests2.log 2>&1; tail -4 $out/r04_ab_tests2.log
+run() { # label, env...
+  label=$1; shift
+  env "$@" python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s' % '$label', j['value'], j['ms_per_step'], j['host_issue']['ms_per_step_issue'])"
+}
+for i in 1 2 3; do
+  run "default" A=1
+  run "ring 2 ahead" HFL_VARIANTS=ring_pf=2
+done > $out/r04_ab_ab.log 2>&1
+cat $out/r04_ab_ab.log
