@@ -874,8 +874,9 @@ def attn_pool(x: torch.Tensor, row_off: torch.Tensor, query: torch.Tensor, batch
     lib = _native.load()
     nb = lib.hfl_attn_pool_workspace(batch, k, c, x.shape[0])
     ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=x.device)
-    check(lib.hfl_attn_pool(out.data_ptr(), out.stride(0), x.data_ptr(), row_off.data_ptr(), query.data_ptr(), batch, k, c,
-                            x.shape[0], float(scale), ws.data_ptr(), int(nb), _stream()), 'hfl_attn_pool')
+    with _timed('hfl_attn_pool', x.numel() * 4 + out.numel() * 4, 4 * x.shape[0] * k * c):
+        check(lib.hfl_attn_pool(out.data_ptr(), out.stride(0), x.data_ptr(), row_off.data_ptr(), query.data_ptr(), batch, k, c,
+                                x.shape[0], float(scale), ws.data_ptr(), int(nb), _stream()), 'hfl_attn_pool')
     return out
 
 
