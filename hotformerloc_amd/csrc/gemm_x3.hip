@@ -86,6 +86,21 @@ __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][M
   const bool n_ok = EPI != 0 || nbase < N;          // EPI 0 takes N = 64: the upper half of the tile is W's zero padding
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias != nullptr && n_ok) b = *reinterpret_cast<const float4*>(p.bias + nbase);
+  // EPI 0: every residual value of the tile is requested here, before the first store.  `residual` may be `out` (the block's
+  // in-place x += proj(...)), so the compiler keeps a load behind every earlier store: in the loop below that was 8 MT / 2
+  // dependent round trips per wave (load, wait, add, store, next load ...) -- ~10 us per tile, the whole duration of the
+  // step's many one-round launches.  An element is read and written by the same lane only, so the order does not matter.
+  float4 rs[EPI == 0 ? MT / 2 : 1][EPI == 0 ? 8 : 1];
+  if (EPI == 0) {
+#pragma unroll
+    for (int h = 0; h < MT / 2; ++h)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int64_t m = m_tile + h * 32 + it * 4 + fq;
+        rs[h][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual != nullptr && m < m_end && n_ok) rs[h][it] = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+      }
+  }
 #pragma unroll
   for (int h = 0; h < MT / 2; ++h) {
 #pragma unroll
@@ -108,8 +123,8 @@ __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][M
           v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
         }
         if (p.residual != nullptr) {
-          const float4 rs = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
-          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+          const float4 r4 = rs[EPI == 0 ? h : 0][EPI == 0 ? it : 0];
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
         // non-temporal: the output is not re-read by this kernel, and letting it allocate in L2 evicts the operand
         // tiles the co-resident workgroups are re-reading (measured: 160 -> 106 us for the depth-4 fc1 shape)
