@@ -390,7 +390,7 @@ def main():
                 'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup}
 
     extras = world == 1 and not args.train and not args.no_extras
-    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = fused_roof = None
+    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = fused_roof = mlp_roof = None
     with (torch.enable_grad() if args.train else torch.inference_mode()):
         # ---- the headline: W warm-ups, K timed steps, nothing instrumented inside the timed region
         elapsed = timed(step, args.steps, args.warmup, tag='value')
@@ -449,6 +449,12 @@ def main():
                     rec, iso_sizes = native_attention_timing(step, args.steps)
                     kern_iso = {ATTN: rec}
                     fused_roof = native_fused_timing(step, args.steps)
+                    # the fused MLP launches (the step's largest kernel group) alone, same one-stream schedule
+                    with ops.KernelTimer(only=['hfl_ln_mlp_fused']) as t_mlp:
+                        for _ in range(args.steps):
+                            step()
+                        torch.cuda.synchronize()
+                    mlp_roof = rowtile_roofline(t_mlp.by_size('hfl_ln_mlp_fused'), t_mlp.summary().get('hfl_ln_mlp_fused'))
                     set_pyramid_streams(True)
             elif not args.no_streams:
                 set_pyramid_streams(False)
@@ -527,6 +533,8 @@ def main():
             line['roofline_fp32'] = roof32
         if fused_roof:
             line['roofline_fused'] = fused_roof
+        if mlp_roof:
+            line['roofline_mlp'] = mlp_roof
         if per_rank is not None:
             line['per_rank_ms_per_step'] = {'min': min(per_rank), 'max': max(per_rank), 'ranks': per_rank}
         if allgather_ms is not None:
@@ -670,7 +678,53 @@ def native_fused_timing(step, steps):
                     'frac_of_8TBps': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
                     'note': 'x in + split2 out = 8 B per (row, channel) + 8 B of metadata per token; the two launches it '
                             'replaces move 24 B per (row, channel)'},
+            'mfma_busy_pmc': pmc_mfma_busy('r04_fused_counters.txt'),
             'timing': 'HIP event pair around every launch, recorded by the library, serialised schedule, after the timed region'}
+
+
+def rowtile_roofline(groups, total):
+    """MFMA roofline of the fused LN2 -> fc1 -> GELU -> fc2 -> residual launches of the step (hfl_ln_mlp_fused): per launch size
+    (ops.KernelTimer.by_size: algorithmic bytes = 8 B per (row, channel)) and over all of them.  FLOP issued = 3 bf16 MFMA
+    terms per product of the 16 M C^2 useful ones."""
+    if not total or not groups:
+        return None
+    n, ms, nbytes, flops, _ = total
+    issued = 3.0 * flops
+    by = []
+    for b, c, t in groups:
+        # flops of a launch of b algorithmic bytes: rows x C = b / 8; C from the step's two widths is not recoverable from b
+        # alone, so the per-size rows report time and rows x channels only
+        by.append({'rows_x_channels': int(b // 8), 'launches': c, 'avg_launch_us': round(t / c * 1e3, 2)})
+    return {'kernel': 'hfl_ln_mlp_fused', 'what': 'LayerNorm -> fc1 -> GELU -> fc2 -> residual in ONE kernel, the M x 4C hidden '
+            'activation never in HBM; every launch of the step (depth-4 blocks, depth-5 blocks, relay-token blocks)',
+            'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_F16_PEAK_TFLOPS, 'achieved': round(issued / (ms * 1e-3) / 1e12, 1),
+            'frac': round(issued / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            'useful_tflops_fp32_equivalent': round(flops / (ms * 1e-3) / 1e12, 2), 'launches': n,
+            'avg_launch_us': round(ms / n * 1e3, 2), 'by_launch_size': by,
+            'mfma_busy_pmc': pmc_mfma_busy('r04_mlp_counters.txt'),
+            'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
+
+
+def pmc_mfma_busy(name):
+    """MFMA-pipe busy fraction of a kernel from its committed SQ counter survey (profiles/<name>, written by
+    tools/pmc_survey2.sh in separate --pmc passes): SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x kernel cycles), the kernel's
+    cycles taken as GRBM_GUI_ACTIVE / 8 XCDs of the same survey.  None when the survey is not in the tree."""
+    path = os.path.join(ROOT, 'profiles', name)
+    if not os.path.exists(path):
+        return None
+    vals = {}
+    for ln in open(path):
+        f = ln.split()
+        if len(f) >= 2 and f[0].isupper():
+            try:
+                vals[f[0]] = float(f[1])
+            except ValueError:
+                pass
+    busy, gui = vals.get('SQ_VALU_MFMA_BUSY_CYCLES'), vals.get('GRBM_GUI_ACTIVE')
+    if not busy or not gui:
+        return None
+    return {'frac': round(busy / (4 * 256 * gui / 8.0), 4), 'source': 'profiles/' + name,
+            'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), rocprofv3 --pmc survey of the kernel alone'}
 
 
 def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32, serialised):
@@ -709,7 +763,8 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
                      'engine': 'v_mfma_f32_16x16x32_f16' if f16 else 'v_mfma_f32_16x16x4_f32',
                      'frac_issued_of_peak_used': round(useful_tf * (3.5 if f16 else 1.0) /
                                                        (MFMA_F16_PEAK_TFLOPS if f16 else mfma_peak_f32), 4),
-                     'useful_over_f32_peak': round(useful_tf / MFMA_F32_PEAK_TFLOPS, 4)},
+                     'useful_over_f32_peak': round(useful_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                     'mfma_busy_pmc': pmc_mfma_busy('r04_attn_counters.txt') if f16 else None},
             'timing': ('HIP event pair around every launch (recorded by the library on the launch stream for the fp16 kernel, '
                        'by ops.KernelTimer for the fp32 one) over %d steps re-run right after the timed region, never inside '
                        'it, with the step\'s launch schedule on ONE stream; the kernel trace of that schedule is '
