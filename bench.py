@@ -28,8 +28,9 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
   e2e            a FRESH octree per step from device-resident points: device build + neighbour tables + forward
   train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process
   oxford         BASELINE config 5's per-rank workload (Oxford cfg, B = 64, octree depth 9), in a child process
-  pinned_host    the headline step with the process pinned to 1/8 of the host's logical CPUs (what one of 8 ranks sharing a
-                 host gets), in a child process; every leg's `host_issue` = host time to queue the K steps vs their wall time
+  unpinned_host  the headline step with the CPU affinity left alone, in a child process (the headline itself runs on its rank's
+                 eighth of the host's logical CPUs: --pin-cores); every leg's `host_issue` = host time to queue the K steps vs
+                 their wall time
 and then, outside any timed value: the `roofline` legs (HIP events per launch: the fp16 window kernel, `roofline_fused` for the
 one-kernel LayerNorm -> qkv -> attention launch of the OctFormer stage, `roofline_fp32` for the fp32 leg) and the `cpu_baseline`
 (the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol) whose descriptors are also the
@@ -96,12 +97,13 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='only the headline timed region (no other legs)')
     ap.add_argument('--no-train-leg', action='store_true', help='skip the config-3 child process')
     ap.add_argument('--no-oxford-leg', action='store_true', help="skip the config-5 per-rank workload's child process")
-    ap.add_argument('--no-pinned-leg', action='store_true', help='skip the host-contention child process')
+    ap.add_argument('--no-pinned-leg', action='store_true', help='skip the unpinned-host child process')
     ap.add_argument('--dry-launch', action='store_true',
                     help='--gpus N without a launcher: print the child command this process would start, and exit')
-    ap.add_argument('--pin-cores', type=int, default=0,
-                    help='restrict this process to the first N logical CPUs before anything else runs (what one of 8 ranks '
-                         'sharing a host gets) and report host issue time per step in `host_issue`')
+    ap.add_argument('--pin-cores', type=int, default=-1,
+                    help='restrict this process to N logical CPUs before anything else runs: -1 (default) = 1/8 of the host\'s, '
+                         'the slice of this rank (LOCAL_RANK) -- the share one of 8 ranks on a node has, which is also how a '
+                         'deployment pins one process per GPU; 0 = leave the affinity alone (the `unpinned_host` leg)')
     ap.add_argument('--master-port', type=int, default=None, help='self-launch: rendezvous port (default: a free one)')
     ap.add_argument('--train-leg-steps', type=int, default=5)
     ap.add_argument('--train-leg-warmup', type=int, default=3)
@@ -248,11 +250,39 @@ def rank_report(dist, elapsed, steps, device):
     return per_rank, float(t.item())
 
 
+def pin_host(args):
+    """One process per GPU, each on its own slice of the host's logical CPUs (args.pin_cores; -1: an eighth, by LOCAL_RANK).
+    The launching parent of --gpus N pins nothing (its children do).  Measured on the 256-CPU bench box: 2874-2936 clouds/s
+    with the scheduler free to move the Python thread and the HIP runtime's helpers, 2938-2960 pinned (alternating runs,
+    profiles/r04_ad_ab_host_pinning.log)."""
+    args.host_affinity = 'not set'
+    if not hasattr(os, 'sched_setaffinity'):
+        return
+    if args.pin_cores == 0:
+        # a child leg of a pinned parent inherits its mask: back to what the parent started with
+        orig = os.environ.get('HFL_BENCH_AFFINITY0')
+        if orig:
+            try:
+                os.sched_setaffinity(0, {int(c) for c in orig.split(',')})
+            except (OSError, ValueError):
+                pass
+        return
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return
+    allowed = sorted(os.sched_getaffinity(0))
+    os.environ.setdefault('HFL_BENCH_AFFINITY0', ','.join(str(c) for c in allowed))
+    n = args.pin_cores if args.pin_cores > 0 else max(1, (os.cpu_count() or len(allowed)) // 8)
+    n = min(n, len(allowed))
+    slot = int(os.environ.get('LOCAL_RANK', '0')) if args.pin_cores < 0 else 0
+    first = slot * n if (slot + 1) * n <= len(allowed) else 0
+    os.sched_setaffinity(0, set(allowed[first:first + n]))
+    os.environ['OMP_NUM_THREADS'] = str(n)
+    args.host_affinity = '%d of %d logical CPUs (slice %d)' % (n, os.cpu_count() or len(allowed), slot)
+
+
 def main():
     args = parse()
-    if args.pin_cores > 0 and hasattr(os, 'sched_setaffinity'):
-        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:args.pin_cores]))
-        os.environ['OMP_NUM_THREADS'] = str(args.pin_cores)
+    pin_host(args)
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
     if args.dry_launch:
@@ -524,7 +554,7 @@ def main():
                                        if args.multistaged else ('forward+backward, stochastic depth %s' % ('off' if args.no_drop_path else 'on (drop_path = %.2f, as the config trains)' % params.drop_path))) if args.train else 'forward-only',
                                       plan_txt),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
-                       'cu_partition': cu_partition_txt(),
+                       'cu_partition': cu_partition_txt(), 'host_affinity': getattr(args, 'host_affinity', 'not set'),
                        'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
                                      ('rccl all_gather at world size 1' if collective else 'none')},
             'roofline': roof,
@@ -567,17 +597,16 @@ def main():
                                        'per-rank workload of batch 512 on 8 GPUs; reference cfg config/config_oxford.txt:21)',
                                        keys=('host_issue',))
             log('oxford leg:', line['oxford'])
-        if extras and not args.no_pinned_leg and args.config == 'wild-places':
-            # eight ranks share one host at N = 8: the headline workload again with this process restricted to 1/8 of
-            # the host's logical CPUs (8 concurrent issuing processes cannot be run on a 1-GPU box)
-            pin = max(1, (os.cpu_count() or 8) // 8)
-            log('host-contention leg (pinned to %d logical CPUs; child process) ...' % pin)
-            line['pinned_host'] = child_leg(['--pin-cores', str(pin), '--steps', str(args.steps), '--warmup', str(args.warmup),
-                                             '--gemm', args.gemm],
-                                            'child process: the headline step with the process pinned to %d of the host\'s %d '
-                                            'logical CPUs (1/8: the share of one of 8 ranks)' % (pin, os.cpu_count() or 0),
-                                            keys=('host_issue',))
-            log('pinned leg:', line['pinned_host'])
+        if extras and not args.no_pinned_leg and args.config == 'wild-places' and args.pin_cores != 0:
+            # the headline is measured with the process on its rank's slice of the host's CPUs (pin_host); the same step with the
+            # affinity left alone, for contrast
+            log('unpinned-host leg (child process) ...')
+            line['unpinned_host'] = child_leg(['--pin-cores', '0', '--steps', str(args.steps), '--warmup', str(args.warmup),
+                                               '--no-extras', '--no-cpu-baseline'],
+                                              'child process: the headline step with the CPU affinity left alone (all %d '
+                                              'logical CPUs; the headline runs on %s)' % (os.cpu_count() or 0, args.host_affinity),
+                                              keys=('host_issue',))
+            log('unpinned leg:', line['unpinned_host'])
         if world == 1 and not args.no_cpu_baseline and not args.train:
             line['cpu_baseline'], want = cpu_baseline(params, depth, args)
             line['gpu_over_cpu'] = round(line['value'] / line['cpu_baseline']['value'], 1)

@@ -134,6 +134,17 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (phase == 1) return HFL_OK;
   // ---- phase 2 (or the whole block) = phase 3 (the relay rows up to their qkv) + the window attention + phase 4 (the rest);
   // 3 and 4 exist so that the attention of several blocks can go out as one launch in between (hfl_block_attention_x3_multi)
+  // (phases 2 / 3 with the fused LN1 -> qkv launch available: the relay rows' qkv reads them where they are and goes out FIRST
+  // -- the window attention waits for it, the copy of the rows into the block's buffer is only needed by proj's residual --
+  // as one launch with the output features split over the workgroups instead of copy, LayerNorm, GEMM: three dependent small
+  // launches of the finest level's critical chain per iteration)
+  const bool relay_fused = (phase == 2 || phase == 3) && rows > nt && w->qkv_pack != nullptr;
+  if (relay_fused) {
+    const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
+    rc = hfl_ln_qkv_fused(qkv + nt * 3 * C, src, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale,
+                          rows - nt, (int)C, stream);
+    if (rc != HFL_OK) return rc;
+  }
   if (phase != 4 && rows > nt) {
     const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
     hipError_t e = hipMemcpyAsync(x0 + nt * C, src, (size_t)(rows - nt) * C * 4, hipMemcpyDeviceToDevice,
@@ -149,7 +160,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
                             w->rpe_table, desc, stream);
     if (rc != HFL_OK) return rc;
   }
-  if (phase != 4 && !fused_attn) {
+  if (phase != 4 && !fused_attn && !relay_fused) {
     // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phases 2, 3)
     const int64_t r0 = phase != 0 ? nt : 0, nr = rows - r0;
     if (nr > 0) {

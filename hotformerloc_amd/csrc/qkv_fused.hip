@@ -446,7 +446,7 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
   int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
   if (g_qkv_reserve > 0 && cus - g_qkv_reserve >= 64 && p.n_tiles > (int64_t)cus * (channels == 256 ? 8 : 16)) cus -= g_qkv_reserve;
-  const int grid = p.n_tiles < cus ? p.n_tiles : cus;
+  int grid = p.n_tiles < cus ? p.n_tiles : cus;
   // (C = 256 with 8 waves x 2 tiles spills; probe knob 'qkv_waves' = 4: one wave per SIMD with 512 registers, 2 [4] tiles each)
   const int waves = g_qkv_waves, nt = (channels == 256 ? 1 : 2) * (8 / waves);
   p.stagger = p.n_tiles > (int64_t)grid * waves * nt ? 1 : 0;          // only when a workgroup walks several passes
@@ -457,13 +457,16 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
     const int tpp = waves * nt, nst_all = 3 * channels / 32;
     const int64_t full = p.n_tiles / ((int64_t)cus * tpp);
     const int64_t rem = p.n_tiles - full * cus * tpp;
-    if (g_qkv_tail_split && full >= 1 && rem > 0) {
+    // (full == 0: fewer rows than one round -- the relay rows of a block, 44 .. 1.4 k of them: their few row sets would each
+    // stream all of W on one CU; with the output features split the launch takes two stages per workgroup)
+    if (g_qkv_tail_split && rem > 0) {
       const int sets = (int)hfl_cdiv(rem, tpp);
       int parts = 1;
       for (int c = 2; c <= cus / sets && c <= nst_all / 2; ++c)
         if (nst_all % c == 0 && (nst_all / c) % 2 == 0) parts = c;      // parts | stages, an even number of stages each
       if (parts >= 2) {
         p.full_passes = (int)full; p.tail_tile0 = (int)(full * cus * tpp); p.tail_sets = sets; p.tail_parts = parts;
+        if (full == 0) grid = sets * parts;
       }
     }
   }

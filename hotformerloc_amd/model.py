@@ -774,9 +774,8 @@ class OctreeAttention(nn.Module):
                 # LayerNorm + the qkv GEMM
                 qkv = torch.empty((x.shape[0], 3 * x.shape[1]), dtype=torch.float32, device=x.device)
                 ops.ln_qkv_fused(x[:nt], norm1.weight, norm1.bias, norm1.eps, qpack, self.qkv.bias, qs, out=qkv[:nt])
-                if x.shape[0] > nt:
-                    ops.linear_x3_qkv(ops.layer_norm_split2(x[nt:], norm1.weight, norm1.bias, norm1.eps), _w2(self.qkv),
-                                      self.qkv.bias, qs, out=qkv[nt:])
+                if x.shape[0] > nt:          # the relay rows: the same launch, output features split over the workgroups
+                    ops.ln_qkv_fused(x[nt:], norm1.weight, norm1.bias, norm1.eps, qpack, self.qkv.bias, qs, out=qkv[nt:])
                 return self.core(qkv, plan, depth, out_split=2, qkv_f16=True)
             a2 = ops.layer_norm_split2(x, norm1.weight, norm1.bias, norm1.eps)
             if f16:
