@@ -167,6 +167,11 @@ SIGNATURES = {
     'hfl_ln_mlp_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                          c_void_p]),
     'hfl_ln_mlp_fused_workspace': (c_int64, [c_int64, c_int]),
+    'hfl_mlp_fused_pack_bytes_h': (c_int64, [c_int, c_int]),
+    'hfl_mlp_fused_pack_h': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'hfl_ln_mlp_fused_workspace_h': (c_int64, [c_int64, c_int, c_int]),
+    'hfl_ln_mlp_fused_h': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                   c_int, c_void_p, c_int64, c_void_p]),
     'hfl_ln_mlp_fused_ws': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                             c_void_p, c_int64, c_void_p]),
     'hfl_attn_fused_ok': (c_int, [c_void_p, c_int, c_int]),

@@ -1502,6 +1502,7 @@ void hfl_internal_set_mlp_stagger(int v);
 void hfl_internal_set_mlp_ring_pf(int v);
 void hfl_internal_set_mlp_waves(int v);
 void hfl_internal_set_mlp_lag(int v);
+void hfl_internal_set_round_launches(int v);
 void hfl_internal_set_mlp_dbg(int v);
 void hfl_internal_set_qkv_waves(int v);
 void hfl_internal_set_qkv_ring_pf(int v);
@@ -1567,6 +1568,7 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_ring_pf(3);
     hfl_internal_set_mlp_waves(8);
     hfl_internal_set_mlp_lag(0);
+    hfl_internal_set_round_launches(0);
     hfl_internal_set_mlp_dbg(0);
     hfl_internal_set_qkv_waves(8);
     hfl_internal_set_qkv_ring_pf(3);
@@ -1599,6 +1601,8 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_qkv_waves(value);
   } else if (is("mlp_dbg")) {
     hfl_internal_set_mlp_dbg(value);
+  } else if (is("round_launches")) {
+    hfl_internal_set_round_launches(value);
   } else if (is("mlp_lag")) {
     hfl_internal_set_mlp_lag(value);
   } else if (is("mlp_waves")) {

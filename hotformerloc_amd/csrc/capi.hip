@@ -9,9 +9,51 @@ namespace {
 std::mutex g_stream_mu;
 std::vector<std::pair<void*, int>> g_stream_cus;       // streams made by hfl_stream_create_cu_mask -> CUs in their mask
 int g_cu_reserve = 0;                                  // probe knob 'cu_reserve'
+int g_round_launches = 0;                              // probe knob 'round_launches' (measured: -1 % of the step, off)
 }  // namespace
 
 extern "C" {
+
+// The chip-filling row-tile launches of a block inside the multi-stream H-OSA schedule (fused LN1 -> qkv of the token rows,
+// fused MLP) as one launch per ROUND of the grid (cus x rows per pass) instead of one persistent launch over all rounds.
+// While such a kernel runs nothing else fits on any CU (8 waves x 256 VGPRs, 135-150 KB of LDS): the relay-token block's
+// launches, on their high-priority stream, waited for its last workgroup -- the relay tokens' fused MLP took 105 us beside the
+// finest level's qkv launch against 21 alone (kernel trace), and the finest level then waited ~58 us per iteration for the
+// relay rows.  At a launch boundary every CU frees at once and the queue arbiter serves the higher-priority stream first.
+// The rows of a round are whole passes (no tail), only the last launch has left-over rows: the same work, cut in time.
+// Measured (profiles/r04_ag_ab_round_launches.log): the relay tokens' MLP drops to 63 us, but its reduce then starves beside
+// the second round (61 us), every round pays its own ramp (depth-4 MLP 184 + 139 us against 276) and the step loses 1 %:
+// 2789-2802 clouds/s against 2820-2829.  Off; `round_launches` = 1 switches it on.
+void hfl_internal_set_round_launches(int v) { g_round_launches = v ? 1 : 0; }
+int hfl_internal_stream_cus(void* stream);
+
+static int qkv_by_rounds(void* qkv_out, const float* x, const hfl_block_weights* w, int64_t n_rows, int64_t C, int split,
+                         hfl_stream_t stream) {
+  const int64_t round = (int64_t)hfl_internal_stream_cus(stream) * (C == 256 ? 128 : 256);
+  int64_t r0 = 0;
+  while (split && g_round_launches && n_rows - r0 >= 2 * round) {      // (the last launch keeps at least one whole round)
+    int rc = hfl_ln_qkv_fused(static_cast<float*>(qkv_out) + r0 * 3 * C, x + r0 * C, w->norm1_gamma, w->norm1_beta, w->eps,
+                              w->qkv_pack, w->qkv_b, w->q_scale, round, (int)C, stream);
+    if (rc != HFL_OK) return rc;
+    r0 += round;
+  }
+  return hfl_ln_qkv_fused(static_cast<float*>(qkv_out) + r0 * 3 * C, x + r0 * C, w->norm1_gamma, w->norm1_beta, w->eps,
+                          w->qkv_pack, w->qkv_b, w->q_scale, n_rows - r0, (int)C, stream);
+}
+
+static int mlp_by_rounds(float* out, const float* x, const hfl_block_weights* w, int64_t n_rows, int64_t C, void* ws,
+                         int64_t ws_bytes, int split, hfl_stream_t stream) {
+  const int64_t round = (int64_t)hfl_internal_stream_cus(stream) * (C == 256 ? 128 : 256);
+  int64_t r0 = 0;
+  while (split && g_round_launches && n_rows - r0 >= 2 * round) {
+    int rc = hfl_ln_mlp_fused_ws(out + r0 * C, x + r0 * C, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b,
+                                 round, (int)C, ws, ws_bytes, stream);
+    if (rc != HFL_OK) return rc;
+    r0 += round;
+  }
+  return hfl_ln_mlp_fused_ws(out + r0 * C, x + r0 * C, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b,
+                             n_rows - r0, (int)C, ws, ws_bytes, stream);
+}
 
 // CUs a launch sizes its persistent grid for.  `cu_reserve` CUs are left out on purpose: the chip-filling kernels of the
 // finest pyramid level occupy a CU completely (8 waves x 256 VGPRs, 135-150 KB of LDS), so while one of them runs no launch
@@ -107,8 +149,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
     rc = hfl_linear_x3(x1 + r0 * C, o2 + r0 * 2 * C, w->proj_w, w->proj_b, x0 + r0 * C, nr, (int)C, (int)C, 0, stream);
     if (rc != HFL_OK) return rc;
     if (phase == 6 && w->mlp_pack != nullptr)
-      return hfl_ln_mlp_fused_ws(io->out + r0 * C, x1 + r0 * C, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b,
-                                 w->fc2_b, nr, (int)C, a + 12 * unit, mlp_ws_bound(rows, C), stream);
+      return mlp_by_rounds(io->out + r0 * C, x1 + r0 * C, w, nr, C, a + 12 * unit, mlp_ws_bound(rows, C), 1, stream);
     if (w->fc1_w == nullptr || w->fc2_w == nullptr) return HFL_EINVAL;
     rc = hfl_layer_norm_split2(h2 + r0 * 2 * C, x1 + r0 * C, w->norm2_gamma, w->norm2_beta, nr, C, w->eps, stream);
     if (rc != HFL_OK) return rc;
@@ -122,7 +163,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
     if (rc != HFL_OK) return rc;
     if (phase == 1) {           // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
       if (w->qkv_pack != nullptr) {
-        rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
+        rc = qkv_by_rounds(qkv, x0, w, nt, C, 1, stream);
       } else {
         rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, nt, C, w->eps, stream);
         if (rc != HFL_OK) return rc;
@@ -180,8 +221,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
     // (workspace of the left-over rows' partial sums: behind the twelve units, sized by hfl_block_forward_x3_arena)
-    return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
-                               a + 12 * unit, mlp_ws_bound(rows, C), stream);
+    return mlp_by_rounds(io->out, x1, w, rows, C, a + 12 * unit, mlp_ws_bound(rows, C), phase != 0, stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);

@@ -82,7 +82,7 @@ static int g_mlp_waves = 8;        // probe knob 'mlp_waves': waves per workgrou
 
 // DBG (probe knob 'mlp_dbg', timing ablations only -- results are wrong): 1 GELU -> identity, 2 no bias / GELU / split at all,
 // 4 no refill of the weight ring, 8 no barrier at the stage boundaries
-template <int C, int NT, int PF, int NW, int LAG, int DBG = 0>
+template <int C, int NT, int PF, int NW, int LAG, int DBG = 0, int HID = 4 * C>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1)
 ln_mlp_fused_kernel(const MlpFusedParams p) {
   static_assert(LAG == 0 || (PF == 2 && NW == 8), "the late half keeps a stage one step longer: two stages ahead, not three");
@@ -91,7 +91,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   constexpr int NTHR = NW * 64;
   constexpr int KS = C / 32;               // k-steps of GEMM1
   constexpr int FT = C / 16;               // 16-feature tiles of the output
-  constexpr int NCH = C / 8;               // chunks of 32 hidden features (hidden = 4 C)
+  constexpr int NCH = HID / 32;            // chunks of 32 hidden features (hidden = 4 C in the transformer blocks, C in the Mixer)
   constexpr int STAGE_B = C * 128;         // bytes of one stage: C rows x 128 B
   constexpr int NSLOT = 4;
   constexpr int DPW = STAGE_B / 1024 / NW; // LDS-DMA instructions per wave and stage
@@ -99,7 +99,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
   constexpr int TPP = NW * NT;             // 16-row tiles per pass
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   float* b1s = reinterpret_cast<float*>(smem + NSLOT * STAGE_B);       // (4C) fc1 bias | (C) gamma | (C) beta | (C) fc2 bias
-  float* gms = b1s + 4 * C;
+  float* gms = b1s + HID;
   float* bts = gms + C;
   float* b2s = bts + C;
 
@@ -115,7 +115,7 @@ ln_mlp_fused_kernel(const MlpFusedParams p) {
 
   // small vectors live in LDS for the whole kernel: read per use with ds_read (a global load per use would be a dependent
   // L2 round trip each -- the register file has no room to hold them)
-  for (int i = tid; i < C; i += NTHR) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+  for (int i = tid; i < HID / 4; i += NTHR) reinterpret_cast<float4*>(b1s)[i] = reinterpret_cast<const float4*>(p.b1)[i];
   for (int i = tid; i < C / 4; i += NTHR) {
     reinterpret_cast<float4*>(gms)[i] = reinterpret_cast<const float4*>(p.gamma)[i];
     reinterpret_cast<float4*>(bts)[i] = reinterpret_cast<const float4*>(p.beta)[i];
@@ -516,8 +516,8 @@ mlp_tail_reduce_kernel(float* __restrict__ out, const float* __restrict__ x, con
 //   perm: position 8 q + e  <->  hidden offset 16 (e >> 2) + 4 q + (e & 3)   (the accumulator layout of GEMM1 read as a
 //   B fragment of GEMM2).  16-B slot t of a row is stored at slot t ^ ((row >> 1) & 7).
 __global__ void __launch_bounds__(256)
-mlp_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w1, const float* __restrict__ w2, int C) {
-  const int nch = C / 8;
+mlp_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w1, const float* __restrict__ w2, int C, int hidden) {
+  const int nch = hidden / 32;
   const int64_t cells = (int64_t)2 * nch * C * 8;                 // 16-B slots of the pack
   for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (int64_t)gridDim.x * blockDim.x) {
     const int slot = (int)(cell & 7);
@@ -538,7 +538,7 @@ mlp_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w1, 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = src[e];
     } else {
-      const float* src = w2 + (int64_t)r * (4 * C) + 32 * j;
+      const float* src = w2 + (int64_t)r * hidden + 32 * j;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = src[16 * (e >> 2) + 4 * q + (e & 3)];
     }
@@ -572,17 +572,25 @@ void hfl_internal_set_mlp_stagger(int v) {
   g_mlp_stagger_groups = (v >> 8) > 0 ? (v >> 8) : 2;
 }
 
-int64_t hfl_mlp_fused_pack_bytes(int channels) {
-  if (channels != 128 && channels != 256) return 0;
-  return (int64_t)2 * (channels / 8) * channels * 128;
+static bool mlp_shape_ok(int channels, int hidden) {
+  return (channels == 128 || channels == 256) && (hidden == 4 * channels || (channels == 256 && hidden == 256));
 }
 
-int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channels, hfl_stream_t stream) {
-  if (pack == nullptr || w1 == nullptr || w2 == nullptr || hfl_mlp_fused_pack_bytes(channels) == 0) return HFL_EINVAL;
-  const int64_t cells = hfl_mlp_fused_pack_bytes(channels) / 16;
+int64_t hfl_mlp_fused_pack_bytes_h(int channels, int hidden) {
+  if (!mlp_shape_ok(channels, hidden)) return 0;
+  return (int64_t)2 * (hidden / 32) * channels * 128;
+}
+int64_t hfl_mlp_fused_pack_bytes(int channels) { return hfl_mlp_fused_pack_bytes_h(channels, 4 * channels); }
+
+int hfl_mlp_fused_pack_h(void* pack, const float* w1, const float* w2, int channels, int hidden, hfl_stream_t stream) {
+  if (pack == nullptr || w1 == nullptr || w2 == nullptr || hfl_mlp_fused_pack_bytes_h(channels, hidden) == 0) return HFL_EINVAL;
+  const int64_t cells = hfl_mlp_fused_pack_bytes_h(channels, hidden) / 16;
   mlp_pack_kernel<<<(unsigned)hfl_cdiv(cells, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      static_cast<unsigned char*>(pack), w1, w2, channels);
+      static_cast<unsigned char*>(pack), w1, w2, channels, hidden);
   HFL_RETURN_LAST_ERROR();
+}
+int hfl_mlp_fused_pack(void* pack, const float* w1, const float* w2, int channels, hfl_stream_t stream) {
+  return hfl_mlp_fused_pack_h(pack, w1, w2, channels, 4 * channels, stream);
 }
 
 // Tail plan of a launch over n_rows: {full passes per workgroup, first tail tile, sets, parts}; parts == 0: no tail split
@@ -611,10 +619,10 @@ unsigned int* hfl_internal_ticket_slot() {
   return base + (size_t)(next++ % kTicketSlots) * 32;
 }
 static unsigned int* ticket_slot() { return hfl_internal_ticket_slot(); }
-static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus) {
+static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus, int hidden) {
   MlpTailPlan t{0, 0, 0, 0};
   const int64_t n_tiles = hfl_cdiv(n_rows, 16);
-  const int tpp = channels == 256 ? 8 : 16, nch = channels / 8;
+  const int tpp = channels == 256 ? 8 : 16, nch = hidden / 32;
   if (!g_mlp_tail_split) return t;
   // (full == 0: fewer rows than one round -- relay tokens, the coarse pyramid levels.  Their few row sets would leave most of
   // the chip idle while every workgroup streams all of W1 and W2; split over the hidden dimension the same launch fills it.)
@@ -640,19 +648,26 @@ static int64_t mlp_tail_bytes(const MlpTailPlan& t, int64_t n_rows, int channels
 /* Workspace of hfl_ln_mlp_fused_ws for this shape (0: none needed): enough for a launch on the whole chip or on any
  * CU-masked stream of this library (hfl_stream_create_cu_mask: 8 .. all CUs in steps of 8) -- the plan depends on the CUs the
  * launch's stream can use; parts x left-over rows never exceeds one round, cus x rows per pass. */
-extern "C" int64_t hfl_ln_mlp_fused_workspace(int64_t n_rows, int channels) {
-  if (n_rows <= 0 || (channels != 128 && channels != 256)) return 0;
+extern "C" int64_t hfl_ln_mlp_fused_workspace_h(int64_t n_rows, int channels, int hidden) {
+  if (n_rows <= 0 || !mlp_shape_ok(channels, hidden)) return 0;
   int64_t need = 0;
   for (int cus = 8; cus <= hfl_num_cus(); cus += 8) {
-    const int64_t b = mlp_tail_bytes(mlp_tail_plan(n_rows, channels, cus), n_rows, channels);
+    const int64_t b = mlp_tail_bytes(mlp_tail_plan(n_rows, channels, cus, hidden), n_rows, channels);
     if (b > need) need = b;
   }
   return need;
 }
 
+extern "C" int64_t hfl_ln_mlp_fused_workspace(int64_t n_rows, int channels) {
+  return hfl_ln_mlp_fused_workspace_h(n_rows, channels, 4 * channels);
+}
+
 extern "C" int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                         const float* b1, const float* b2, int64_t n_rows, int channels, void* workspace,
                         int64_t workspace_bytes, hfl_stream_t stream);
+extern "C" int hfl_ln_mlp_fused_h(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                       const float* b1, const float* b2, int64_t n_rows, int channels, int hidden, void* workspace,
+                       int64_t workspace_bytes, hfl_stream_t stream);
 
 int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* b1, const float* b2, int64_t n_rows, int channels, hfl_stream_t stream) {
@@ -662,10 +677,17 @@ int hfl_ln_mlp_fused(float* out, const float* x, const float* gamma, const float
 int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                         const float* b1, const float* b2, int64_t n_rows, int channels, void* workspace,
                         int64_t workspace_bytes, hfl_stream_t stream) {
+  return hfl_ln_mlp_fused_h(out, x, gamma, beta, eps, pack, b1, b2, n_rows, channels, 4 * channels, workspace, workspace_bytes,
+                            stream);
+}
+
+int hfl_ln_mlp_fused_h(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                       const float* b1, const float* b2, int64_t n_rows, int channels, int hidden, void* workspace,
+                       int64_t workspace_bytes, hfl_stream_t stream) {
   if (out == nullptr || x == nullptr || gamma == nullptr || beta == nullptr || pack == nullptr || b1 == nullptr ||
       b2 == nullptr || n_rows < 0)
     return HFL_EINVAL;
-  if (channels != 128 && channels != 256) return HFL_EINVAL;
+  if (!mlp_shape_ok(channels, hidden)) return HFL_EINVAL;
   if (out == x) return HFL_EINVAL;                       // rows are re-read for the residual after other rows were written
   if (n_rows == 0) return HFL_OK;
   if (hfl_cdiv(n_rows, 16) > 0x7fffffffLL) return HFL_ECAPACITY;
@@ -681,7 +703,7 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   p.stagger_groups = g_mlp_stagger_groups;
   int grid = p.n_tiles < cus ? p.n_tiles : cus;
   p.full_passes = 0; p.tail_tile0 = 0; p.tail_sets = 0; p.tail_parts = 0; p.part = nullptr;
-  MlpTailPlan tp = mlp_tail_plan(n_rows, channels, cus);
+  MlpTailPlan tp = mlp_tail_plan(n_rows, channels, cus, hidden);
   if (tp.parts > 0 && workspace != nullptr && workspace_bytes >= mlp_tail_bytes(tp, n_rows, channels)) {
     p.full_passes = tp.full; p.tail_tile0 = tp.tile0; p.tail_sets = tp.sets; p.tail_parts = tp.parts;
     p.part = static_cast<float*>(workspace);
@@ -697,7 +719,7 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
   // tickets only when a workgroup can get more than one unit (else the static deal is the same thing without the atomics)
   p.ticket = (g_mlp_dynamic && n_units > grid) ? ticket_slot() : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)4 * channels * 128 + (size_t)channels * 28;
+  const size_t lds = (size_t)4 * channels * 128 + (size_t)(hidden + 3 * channels) * 4;
 #define HFL_MLP_LAUNCH(CC, NT, PF, NW, LAG)                                                                     \
   {                                                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<CC, NT, PF, NW, LAG>), \
@@ -705,7 +727,12 @@ int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const fl
     if (e != hipSuccess) return (int)e;                                                                         \
     ln_mlp_fused_kernel<CC, NT, PF, NW, LAG><<<grid, NW * 64, lds, s>>>(p);                                     \
   }
-  if (g_mlp_dbg && channels == 256) {
+  if (hidden != 4 * channels) {               // the Mixer's layers: hidden = C = 256
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<256, 1, 3, 8, 0, 0, 256>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    ln_mlp_fused_kernel<256, 1, 3, 8, 0, 0, 256><<<grid, 512, lds, s>>>(p);
+  } else if (g_mlp_dbg && channels == 256) {
 #define HFL_MLP_DBG(D)                                                                                          \
   {                                                                                                             \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_mlp_fused_kernel<256, 1, 3, 8, 0, D>),           \

@@ -1649,6 +1649,23 @@ class FeatureMixerLayer(nn.Module):
         return x + self.mix(x)
 
 
+_MIXER_FUSED = os.environ.get('HFL_MIXER_FUSED', '1') != '0'
+
+
+def _mixer_pack(fc1: nn.Linear, fc2: nn.Linear):
+    """`ops.mlp_fused_pack` image of a Mixer layer's two Linears, cached per parameter pair like `_mlp_pack`."""
+    w1, w2 = fc1.weight, fc2.weight
+    key = ('mixer', id(w1), id(w2))
+    hit = _W3_CACHE.get(key)
+    stamp = (w1._version, w2._version, w1.data_ptr(), w2.data_ptr())
+    if hit is None or hit[0]() is not w1 or hit[1]() is not w2 or hit[2] != stamp:
+        if hit is None or hit[0]() is not w1:
+            weakref.finalize(w1, _W3_CACHE.pop, key, None)
+        hit = (weakref.ref(w1), weakref.ref(w2), stamp, ops.mlp_fused_pack(w1, w2))
+        _W3_CACHE[key] = hit
+    return hit[3]
+
+
 def _mixer_layer_fits(m) -> bool:
     ln, fc1, act, fc2 = m.mix
     return (isinstance(ln, nn.LayerNorm) and isinstance(act, nn.GELU) and fc1.in_features % 128 == 0
@@ -1673,6 +1690,10 @@ class Mixer(nn.Module):
             x2 = x.reshape(b * k, c)
             for m in self.mix:
                 ln, fc1, _, fc2 = m.mix
+                if _MIXER_FUSED and _GEMM_MODE == 'x3' and ops.mlp_fused_shape_ok(c, fc1.out_features):
+                    # the whole layer as the block MLP's launch (hidden = C): one launch (+ the hidden split's reduce) for three
+                    x2 = ops.ln_mlp_fused(x2.contiguous(), ln.weight, ln.bias, ln.eps, _mixer_pack(fc1, fc2), fc1.bias, fc2.bias)
+                    continue
                 h2 = ops.layer_norm_split2(x2, ln.weight, ln.bias, ln.eps)
                 g2 = ops.linear_x3(h2, _w2(fc1), bias=fc1.bias, gelu_split_out=True)
                 x2 = ops.linear_x3(g2, _w2(fc2), bias=fc2.bias, residual=x2)

@@ -502,40 +502,48 @@ def mlp_fused_ok(channels: int) -> bool:
     return int(_native.load().hfl_mlp_fused_pack_bytes(int(channels))) > 0
 
 
+def mlp_fused_shape_ok(channels: int, hidden: int) -> bool:
+    return int(_native.load().hfl_mlp_fused_pack_bytes_h(int(channels), int(hidden))) > 0
+
+
 def mlp_fused_pack(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
-    """Weight image of `ln_mlp_fused` from the fp32 Linear weights fc1 (4C, C) and fc2 (C, 4C) (hfl_mlp_fused_pack): the
-    (hi, lo) bf16 split of both, cut into the 32-hidden-feature stages the kernel streams through LDS.  Once per parameter."""
+    """Weight image of `ln_mlp_fused` from the fp32 Linear weights fc1 (H, C) and fc2 (C, H) (hfl_mlp_fused_pack_h): the
+    (hi, lo) bf16 split of both, cut into the 32-hidden-feature stages the kernel streams through LDS.  Once per parameter.
+    H = 4C (C = 128, 256: transformer blocks) or H = C = 256 (Mixer layers)."""
     _dev(w1, w2)
     w1, w2 = _f32c(w1.detach()), _f32c(w2.detach())
-    c = w1.shape[1]
-    assert tuple(w1.shape) == (4 * c, c) and tuple(w2.shape) == (c, 4 * c)
+    h, c = w1.shape
+    assert tuple(w2.shape) == (c, h)
     lib = _native.load()
-    n = int(lib.hfl_mlp_fused_pack_bytes(c))
+    n = int(lib.hfl_mlp_fused_pack_bytes_h(c, h))
     if n <= 0:
-        raise _native.NativeLibraryError('hfl_mlp_fused_pack: unsupported channel count %d' % c)
+        raise _native.NativeLibraryError('hfl_mlp_fused_pack: unsupported shape C = %d, hidden = %d' % (c, h))
     pack = torch.empty(n, dtype=torch.uint8, device=w1.device)
-    check(lib.hfl_mlp_fused_pack(pack.data_ptr(), w1.data_ptr(), w2.data_ptr(), c, _stream()), 'hfl_mlp_fused_pack')
+    check(lib.hfl_mlp_fused_pack_h(pack.data_ptr(), w1.data_ptr(), w2.data_ptr(), c, h, _stream()), 'hfl_mlp_fused_pack_h')
     return pack
 
 
 def ln_mlp_fused(x, gamma, beta, eps: float, pack, b1, b2, out=None):
-    """out = x + fc2(gelu(fc1(LN(x)) + b1)) + b2 in ONE launch (hfl_ln_mlp_fused); `pack` from `mlp_fused_pack`."""
+    """out = x + fc2(gelu(fc1(LN(x)) + b1)) + b2 in ONE launch (hfl_ln_mlp_fused_h); `pack` from `mlp_fused_pack`; the hidden
+    width is the length of b1."""
     _dev(x, gamma, beta, pack, b1, b2)
     x = _f32c(x)
     m, c = x.shape
+    h = b1.numel()
     if out is None:
         out = torch.empty_like(x)
     else:
         assert out.shape == x.shape and out.dtype == torch.float32 and out.is_contiguous()
     assert out.data_ptr() != x.data_ptr(), 'the residual rows are re-read: cannot run in place'
-    # algorithmic bytes: read x, write out (the LayerNorm input doubles as the residual); 2 * 2 * M * C * 4C flop
+    # algorithmic bytes: read x, write out (the LayerNorm input doubles as the residual); 2 * 2 * M * C * H flop
     lib = _native.load()
-    ws_bytes = int(lib.hfl_ln_mlp_fused_workspace(m, c))      # partial sums of the rows left over after the last whole round
+    assert pack.numel() == int(lib.hfl_mlp_fused_pack_bytes_h(c, h)), 'pack does not belong to this (C, hidden)'
+    ws_bytes = int(lib.hfl_ln_mlp_fused_workspace_h(m, c, h))   # partial sums of the rows left over after the last whole round
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes > 0 else None
-    with _timed('hfl_ln_mlp_fused', m * c * 8, 16 * m * c * c):
-        check(lib.hfl_ln_mlp_fused_ws(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
-                                      float(eps), pack.data_ptr(), _f32c(b1).data_ptr(), _f32c(b2).data_ptr(), m, c,
-                                      ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), 'hfl_ln_mlp_fused_ws')
+    with _timed('hfl_ln_mlp_fused', m * c * 8, 4 * m * c * h):
+        check(lib.hfl_ln_mlp_fused_h(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                     float(eps), pack.data_ptr(), _f32c(b1).data_ptr(), _f32c(b2).data_ptr(), m, c, h,
+                                     ws.data_ptr() if ws is not None else None, ws_bytes, _stream()), 'hfl_ln_mlp_fused_h')
     return out
 
 

@@ -462,6 +462,15 @@ int64_t hfl_ln_mlp_fused_workspace(int64_t n_rows, int channels);
 int hfl_ln_mlp_fused_ws(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                         const float* b1, const float* b2, int64_t n_rows, int channels, void* workspace,
                         int64_t workspace_bytes, hfl_stream_t stream);
+/*     The same launches for a hidden width other than 4C: `hidden` = rows of w1 = columns of w2.  Supported: 4C (C = 128,
+ *     256: the transformer blocks, identical to the entry points above) and C = hidden = 256 (the Mixer layers of the pooling
+ *     head, models/layers/salsa.py:58-75: LayerNorm -> Linear -> GELU -> Linear -> residual with mlp_ratio 1). */
+int64_t hfl_mlp_fused_pack_bytes_h(int channels, int hidden);
+int hfl_mlp_fused_pack_h(void* pack, const float* w1, const float* w2, int channels, int hidden, hfl_stream_t stream);
+int64_t hfl_ln_mlp_fused_workspace_h(int64_t n_rows, int channels, int hidden);
+int hfl_ln_mlp_fused_h(float* out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
+                       const float* b1, const float* b2, int64_t n_rows, int channels, int hidden, void* workspace,
+                       int64_t workspace_bytes, hfl_stream_t stream);
 
 /* 9d. LayerNorm -> qkv projection as ONE launch, written as the fp16 (hi, lo) operand rows of the window kernel
  *     (= hfl_layer_norm_split2 + hfl_linear_x3_qkv: norm1 -> attention.qkv, models/octformer_backbone.py:70,

@@ -1001,6 +1001,34 @@ def test_ln_mlp_fused_matches_fp64_and_the_unfused_launches(C):
 
 
 @pytest.mark.gpu
+def test_ln_mlp_fused_mixer_shape_hidden_equals_channels():
+    """The same launch with hidden = C = 256 (hfl_ln_mlp_fused_h: a FeatureMixerLayer of the pooling head,
+    models/layers/salsa.py:58-75, mlp_ratio 1) against fp64 and the three launches it replaces; the bench's 8192 token rows
+    (hidden split over 4 workgroups per row set), ragged counts, and shapes the entry point must refuse."""
+    C = 256
+    g = torch.Generator().manual_seed(31)
+    w1 = (torch.randn(C, C, generator=g) * 0.06).to(DEV)
+    w2 = (torch.randn(C, C, generator=g) * 0.06).to(DEV)
+    b1 = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    b2 = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    assert ops.mlp_fused_shape_ok(256, 256) and ops.mlp_fused_shape_ok(256, 1024) and ops.mlp_fused_shape_ok(128, 512)
+    assert not ops.mlp_fused_shape_ok(128, 128) and not ops.mlp_fused_shape_ok(256, 512) and not ops.mlp_fused_shape_ok(64, 256)
+    pack = ops.mlp_fused_pack(w1, w2)
+    w1s, w2s = ops.split2_weight(w1), ops.split2_weight(w2)
+    for n in (1, 17, 300, 8192, 40001):
+        x = (torch.randn(n, C, generator=g) * 2).to(DEV)
+        got = ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2)
+        ref = _mlp_ref(x.cpu(), gamma.cpu(), beta.cpu(), 1e-5, w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu())
+        assert ((got.cpu().double() - ref).norm() / ref.norm()).item() < 1e-5, n
+        h2 = ops.layer_norm_split2(x, gamma, beta, 1e-5)
+        unf = ops.linear_x3(ops.linear_x3(h2, w1s, bias=b1, gelu_split_out=True), w2s, bias=b2, residual=x)
+        assert (got - unf).abs().max().item() <= 2e-5 * ref.abs().max().item(), n
+        assert torch.equal(got, ops.ln_mlp_fused(x, gamma, beta, 1e-5, pack, b1, b2))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('C,n', [(256, 68167), (256, 33000), (128, 70001)])
 def test_ln_mlp_fused_tail_split_equals_whole_passes(C, n):
     """Rows left over after the last whole round of passes (68167 rows at C = 256 are 2.08 rounds of the grid's 32768) are
