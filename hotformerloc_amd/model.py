@@ -1313,7 +1313,7 @@ class HOTFormerStage(nn.Module):
                 raise RuntimeError('relay-first schedule: a block of iteration %d lost its native call' % i)
             for j in order:                                              # token rows: CPE, LN1, qkv (finest level first)
                 d = depths[j]
-                if sts[j] is not main:
+                if sts[j] is not main and (i == 0 or _ITER_JOIN):          # (later iterations: the level's own stream order)
                     sts[j].wait_event(ev0)
                 with torch.cuda.stream(sts[j]):
                     calls[d].run(1)
@@ -1366,12 +1366,14 @@ class HOTFormerStage(nn.Module):
                         bufs[d] = self.hosa_blocks[j][i]._tail(bufs[d], plan, d)
                         rts[d] = self.up_projections[j][i](bufs[d][nts[j]:]) if proj else bufs[d][nts[j]:]
             keep.append(calls)
-            for j in range(nlev):
-                if sts[j] is not main:
-                    main.wait_stream(sts[j])
+            if _ITER_JOIN or i + 1 == self.num_blocks:
+                for j in range(nlev):
+                    if sts[j] is not main:
+                        main.wait_stream(sts[j])
             if i + 1 == self.num_blocks:
                 main.wait_stream(rs)
-            keep = keep[-2:]
+            # (three iterations' worth: a level stream may run a whole iteration behind the RTSA stream that reads its rows)
+            keep = keep if i == 0 else keep[-6:]
         del keep
         return {d: bufs[d][:nt] for d, nt in zip(depths, nts)}, rts
 
