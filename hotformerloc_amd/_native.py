@@ -90,6 +90,7 @@ SIGNATURES = {
     'hfl_tap_tiles': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'hfl_pad_index': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'hfl_pad_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    'hfl_mixer_tail': (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p]),
     'hfl_attn_pool_ok': (c_int, [c_int]),
     'hfl_attn_pool_workspace': (c_int64, [c_int, c_int, c_int, c_int64]),
     'hfl_attn_pool': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_float, c_void_p,

@@ -249,6 +249,8 @@ _ATTN_POOL = os.environ.get('HFL_ATTN_POOL', '1') != '0'
 _RELAY_FIRST = os.environ.get('HFL_RELAY_FIRST', '0') != '0'
 # join every pyramid stream at the end of every H-OSA iteration (the schedule of rounds 2-3); 0: only the true dependencies
 _ITER_JOIN = os.environ.get('HFL_ITER_JOIN', '0') != '0'
+# relay-token self-attention on a stream of its own (1) or on the finest level's, behind that level's CPE / LN1 / qkv (0)
+_RTSA_STREAM = os.environ.get('HFL_RTSA_STREAM', '1') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
 
 
@@ -1392,7 +1394,7 @@ class HOTFormerStage(nn.Module):
                 # once both are done -- the ~120 us chain of eight tiny RTSA launches leaves the critical path.
                 main = torch.cuda.current_stream()
                 side = [main] * (len(depths) - 1) if _SERIAL_STREAMS else (part[1] if part else self._side_streams(data.device))
-                rs = main if _SERIAL_STREAMS else (part[2] if part else self._rtsa_stream(data.device))
+                rs = main if (_SERIAL_STREAMS or not _RTSA_STREAM) else (part[2] if part else self._rtsa_stream(data.device))
                 small = [not (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) for j, d in enumerate(depths)]
                 sts = [side[j - 1] if small[j] else main for j in range(len(depths))]
                 # issue order = critical path first (the host runs only just ahead of the GPU here): the finest level's
@@ -1702,6 +1704,11 @@ class Mixer(nn.Module):
             x = x2.view(b, k, c)
         else:
             x = self.mix(x)
+        if (_MIXER_FUSED and _GEMM_MODE == 'x3' and x.is_cuda and not _grad_path() and x.dtype == torch.float32
+                and x.shape[-1] % 4 == 0 and self.row_proj.out_features <= 8 and self.channel_proj.bias is not None
+                and self.row_proj.bias is not None and x.shape[1] * self.row_proj.out_features <= 16000):
+            # channel_proj, row_proj and the flatten as one small launch (row_proj first: the maps commute)
+            return ops.mixer_tail(x, self.channel_proj.weight, self.channel_proj.bias, self.row_proj.weight, self.row_proj.bias)
         x = self.channel_proj(x.permute(0, 2, 1)).permute(0, 2, 1)
         return self.row_proj(x).flatten(1)
 

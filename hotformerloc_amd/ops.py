@@ -865,6 +865,21 @@ def pad_rows(x: torch.Tensor, row_off: torch.Tensor, batch: int, nmax: int):
     return out
 
 
+def mixer_tail(x: torch.Tensor, channel_w, channel_b, row_w, row_b):
+    """(B, k_out * out_d) = flatten(row_proj(channel_proj(x^T)^T)) of the Mixer aggregator in one launch (hfl_mixer_tail);
+    x (B, K, C), channel_w (k_out, K), row_w (out_d, C)."""
+    _dev(x, channel_w, channel_b, row_w, row_b)
+    x = _f32c(x)
+    b, k, c = x.shape
+    ko, d = channel_w.shape[0], row_w.shape[0]
+    assert tuple(channel_w.shape) == (ko, k) and tuple(row_w.shape) == (d, c)
+    out = torch.empty((b, ko * d), dtype=torch.float32, device=x.device)
+    check(_native.load().hfl_mixer_tail(out.data_ptr(), x.data_ptr(), _f32c(channel_w).data_ptr(), _f32c(channel_b).data_ptr(),
+                                        _f32c(row_w).data_ptr(), _f32c(row_b).data_ptr(), b, k, c, ko, d, _stream()),
+          'hfl_mixer_tail')
+    return out
+
+
 def attn_pool_ok(channels: int) -> bool:
     return bool(_native.load().hfl_attn_pool_ok(int(channels)))
 

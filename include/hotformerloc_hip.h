@@ -198,6 +198,12 @@ int hfl_pad_rows(float* out, const float* x, const int64_t* row_off, int batch, 
  * out + b * out_cloud_stride + q * C is row q of cloud b (so a level can write its slice of the concatenated token matrix).
  * Products as bf16 (hi, lo) splits with fp32 accumulation, softmax in fp32.  channels in {128, 256} (hfl_attn_pool_ok);
  * workspace: hfl_attn_pool_workspace bytes (without it a cloud's rows stay in one workgroup per 64 queries). */
+/* Tail of the Mixer aggregator, models/layers/salsa.py:104-111 (channel_proj over the token axis, row_proj over the channel
+ * axis, flatten) in one launch: out (batch, k_out * out_d), x (batch, k_tokens, channels), channel_w (k_out, k_tokens),
+ * row_w (out_d, channels); out_d <= 8.  row_proj is applied first (the two maps commute): same value up to fp32 summation
+ * order. */
+int hfl_mixer_tail(float* out, const float* x, const float* channel_w, const float* channel_b, const float* row_w,
+                   const float* row_b, int batch, int k_tokens, int channels, int k_out, int out_d, hfl_stream_t stream);
 int hfl_attn_pool_ok(int channels);
 int64_t hfl_attn_pool_workspace(int batch, int n_queries, int channels, int64_t n_rows);
 int hfl_attn_pool(float* out, int64_t out_cloud_stride, const float* x, const int64_t* row_off, const float* query, int batch,

@@ -574,6 +574,21 @@ def test_attn_pool_matches_fp64_pooling():
         assert (one - got).abs().max().item() < 2e-5
 
 
+def test_mixer_tail_matches_the_two_linears():
+    """hfl_mixer_tail (channel_proj over tokens, row_proj over channels, flatten: models/layers/salsa.py:104-111, with the two
+    maps exchanged) against the reference order in fp64."""
+    g = torch.Generator().manual_seed(3)
+    for b, k, c, ko, d in ((5, 256, 256, 64, 4), (3, 128, 128, 32, 8), (1, 77, 64, 19, 1)):
+        x = torch.randn(b, k, c, generator=g)
+        wc, bc = torch.randn(ko, k, generator=g) * 0.1, torch.randn(ko, generator=g)
+        wr, br = torch.randn(d, c, generator=g) * 0.1, torch.randn(d, generator=g)
+        y = torch.nn.functional.linear(x.double().permute(0, 2, 1), wc.double(), bc.double()).permute(0, 2, 1)
+        want = torch.nn.functional.linear(y, wr.double(), br.double()).flatten(1)
+        got = ops.mixer_tail(x.to(DEV), wc.to(DEV), bc.to(DEV), wr.to(DEV), br.to(DEV)).cpu().double()
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() < 2e-5 * want.abs().max().item(), (b, k, c)
+
+
 def test_layer_norm_relu_f32_and_split2():
     """hfl_layer_norm_relu (norm -> ReLU behind every stem convolution, octformer_layers.py:80-98, in one pass): the fp32 form
     equals relu(LayerNorm) of the two-launch form bit for bit, the split2 form equals split2 of it bit for bit."""
