@@ -249,6 +249,7 @@ _ATTN_POOL = os.environ.get('HFL_ATTN_POOL', '1') != '0'
 _RELAY_FIRST = os.environ.get('HFL_RELAY_FIRST', '0') != '0'
 # join every pyramid stream at the end of every H-OSA iteration (the schedule of rounds 2-3); 0: only the true dependencies
 _ITER_JOIN = os.environ.get('HFL_ITER_JOIN', '0') != '0'
+_PLAN_LATE = os.environ.get('HFL_PLAN_LATE', '1') != '0'           # window plan built after the stem has been issued
 # relay-token self-attention on a stream of its own (1) or on the finest level's, behind that level's CPE / LN1 / qkv (0)
 _RTSA_STREAM = os.environ.get('HFL_RTSA_STREAM', '1') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
@@ -1556,11 +1557,22 @@ class HOTFormerBase(nn.Module):
         # the plan depends on the octree only: built first, so that its host work hides the round trip of the tap counts
         # that `construct_all_neigh()` started (the stem convolutions below are the first to need them)
         top = depth - self.stem_down if self.downsample_input_embeddings else depth         # :707-708
-        plan = WindowPlan.for_octree(octree, self.patch_size, self.dilation, max_depth=top,
-                                     start_depth=top - self.num_stages + 1,
-                                     num_pyramid_levels=self.num_pyramid_levels,
-                                     num_octf_levels=self.num_octf_levels, adape_mode=self.ADaPE_mode)
-        data = self.patch_embed(data, octree, depth)
+
+        def make_plan():
+            return WindowPlan.for_octree(octree, self.patch_size, self.dilation, max_depth=top,
+                                         start_depth=top - self.num_stages + 1,
+                                         num_pyramid_levels=self.num_pyramid_levels,
+                                         num_octf_levels=self.num_octf_levels, adape_mode=self.ADaPE_mode)
+
+        if _PLAN_LATE and not _grad_path() and data.is_cuda:
+            # inference: the stem first (it only needs the tap lists, whose counts the host has to wait for anyway), THEN the
+            # plan: its ~0.25 ms of host work runs while the GPU executes the stem's 0.7 ms instead of in front of it with
+            # the GPU idle (kernel trace of a step's first millisecond, profiles/r04_phases_stem_head_end_of_round.log)
+            data = self.patch_embed(data, octree, depth)
+            plan = make_plan()
+        else:
+            plan = make_plan()
+            data = self.patch_embed(data, octree, depth)
         depth = top
         for i in range(self.num_octf_levels):
             data = self.octf_stage[i](data, plan, depth)
