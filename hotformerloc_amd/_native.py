@@ -7,7 +7,7 @@ this module raises.  Build it with `python -m hotformerloc_amd.build`
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libhotformerloc_hip.so')
@@ -64,6 +64,8 @@ SIGNATURES = {
     'hfl_version': (c_int, []),
     'hfl_stream_create_cu_mask': (c_int, [c_void_p, c_int, c_int]),
     'hfl_stream_destroy': (c_int, [c_void_p]),
+    'hfl_flag_set': (c_int, [c_void_p, c_uint32, c_void_p]),
+    'hfl_flag_wait': (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
     'hfl_arch': (c_char_p, []),
     'hfl_dwconv_forward_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                             c_int64, c_int, c_void_p]),

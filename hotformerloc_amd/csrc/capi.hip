@@ -105,6 +105,37 @@ int hfl_stream_destroy(hfl_stream_t stream) {
   return (int)hipStreamDestroy(static_cast<hipStream_t>(stream));
 }
 
+// ---- cross-stream ordering through a device flag instead of an event (probe; see tools/hop_latency.py).
+// hfl_flag_set: a one-lane kernel that stores `value` to *flag (release) -- stream order puts it behind everything queued
+// before it.  hfl_flag_wait: a one-lane kernel that polls *flag (acquire) until it is >= value, for at most `max_polls` polls
+// (bounded: a lost signal costs a late, wrong result that the parity tests catch, never a hung queue); the launches behind it
+// in its stream start when it exits.  The waiting side holds no CU resources to speak of (64 lanes, no LDS).
+namespace {
+__global__ void flag_set_kernel(unsigned int* flag, unsigned int value) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(const unsigned int* flag, unsigned int value, int max_polls) {
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < max_polls; ++i) {
+      if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+}  // namespace
+
+int hfl_flag_set(unsigned int* flag, unsigned int value, hfl_stream_t stream) {
+  if (flag == nullptr) return HFL_EINVAL;
+  flag_set_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(flag, value);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_flag_wait(const unsigned int* flag, unsigned int value, int max_polls, hfl_stream_t stream) {
+  if (flag == nullptr || max_polls <= 0) return HFL_EINVAL;
+  flag_wait_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(flag, value, max_polls);
+  HFL_RETURN_LAST_ERROR();
+}
+
 int hfl_version(void) { return 100; }   // 1.00
 
 const char* hfl_arch(void) { return "gfx950"; }

@@ -250,6 +250,25 @@ _RELAY_FIRST = os.environ.get('HFL_RELAY_FIRST', '0') != '0'
 # join every pyramid stream at the end of every H-OSA iteration (the schedule of rounds 2-3); 0: only the true dependencies
 _ITER_JOIN = os.environ.get('HFL_ITER_JOIN', '0') != '0'
 _PLAN_LATE = os.environ.get('HFL_PLAN_LATE', '1') != '0'           # window plan built after the stem has been issued
+# dependencies between the pyramid streams and the relay-token stream through device flags (hfl_flag_set / hfl_flag_wait)
+# instead of events: 3.4 us of GPU time per link against 13.7 (tools/hop_latency.py)
+_FLAG_HOPS = os.environ.get('HFL_FLAG_HOPS', '0') != '0'
+_HOP_FLAGS = {}
+_HOP_SEQ = [0]
+
+
+def _hop_flags(device):
+    """Device words of the flag hops (one 128-B line each), per device, zero-initialised once."""
+    key = (device.type, device.index)
+    t = _HOP_FLAGS.get(key)
+    if t is None:
+        t = _HOP_FLAGS[key] = torch.zeros(8 * 32, dtype=torch.int32, device=device)
+    return [t[32 * k:32 * k + 1] for k in range(8)]
+
+
+def _hop_next() -> int:
+    _HOP_SEQ[0] += 1
+    return _HOP_SEQ[0]
 # relay-token self-attention on a stream of its own (1) or on the finest level's, behind that level's CPE / LN1 / qkv (0)
 _RTSA_STREAM = os.environ.get('HFL_RTSA_STREAM', '1') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
@@ -1423,14 +1442,21 @@ class HOTFormerStage(nn.Module):
                             calls[d].run(1)
 
                 phase1(order[0])
+                flags = _hop_flags(data.device) if (_FLAG_HOPS and not _SERIAL_STREAMS and rs is not main) else None
                 if join:
                     rs.wait_event(ev0)
+                elif flags is not None:
+                    for fl, val in done:                   # (device-flag hops: ~3 us per link against ~14 for an event)
+                        ops.flag_wait(fl, val, rs)
                 else:
                     for ev in done:
                         rs.wait_event(ev)
                 with torch.cuda.stream(rs):
                     rt_all = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
                     ev_rt = rs.record_event()
+                    if flags is not None:
+                        rt_flag = (flags[0], _hop_next())
+                        ops.flag_set(rt_flag[0], rt_flag[1], rs)
                 for j in order[1:]:
                     phase1(j)
                 fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
@@ -1449,7 +1475,10 @@ class HOTFormerStage(nn.Module):
 
                 for j in order:
                     d = depths[j]
-                    sts[j].wait_event(ev_rt)
+                    if flags is not None:
+                        ops.flag_wait(rt_flag[0], rt_flag[1], sts[j])
+                    else:
+                        sts[j].wait_event(ev_rt)
                     with torch.cuda.stream(sts[j]):
                         if j in group:
                             calls[d].run(3, relay_in(j))                      # relay rows in, their LN1 / qkv
@@ -1477,6 +1506,12 @@ class HOTFormerStage(nn.Module):
                     for j in range(len(depths)):
                         if sts[j] is not main:
                             main.wait_stream(sts[j])
+                elif flags is not None:
+                    done = []
+                    for n, st in enumerate(dict.fromkeys(sts)):
+                        val = _hop_next()
+                        ops.flag_set(flags[1 + n], val, st)
+                        done.append((flags[1 + n], val))
                 else:
                     done = [st.record_event() for st in dict.fromkeys(sts)]
                 del calls, old, fresh, rt_all

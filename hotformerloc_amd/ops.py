@@ -880,6 +880,18 @@ def mixer_tail(x: torch.Tensor, channel_w, channel_b, row_w, row_b):
     return out
 
 
+def flag_set(flag: torch.Tensor, value: int, stream):
+    """Queue `*flag = value` (release) behind the work already in `stream` (hfl_flag_set)."""
+    check(_native.load().hfl_flag_set(flag.data_ptr(), int(value) & 0xffffffff, ctypes.c_void_p(stream.cuda_stream)),
+          'hfl_flag_set')
+
+
+def flag_wait(flag: torch.Tensor, value: int, stream, max_polls: int = 1 << 17):
+    """Queue a one-lane poll of `*flag >= value` (acquire, bounded) in front of what follows in `stream` (hfl_flag_wait)."""
+    check(_native.load().hfl_flag_wait(flag.data_ptr(), int(value) & 0xffffffff, int(max_polls),
+                                       ctypes.c_void_p(stream.cuda_stream)), 'hfl_flag_wait')
+
+
 def attn_pool_ok(channels: int) -> bool:
     return bool(_native.load().hfl_attn_pool_ok(int(channels)))
 

@@ -35,6 +35,13 @@ typedef void* hfl_stream_t; /* hipStream_t */
  * kernels and the coarse levels' / relay tokens' latency-bound launches side by side without competing for CUs. */
 int hfl_stream_create_cu_mask(hfl_stream_t* out, int first_bit, int n_bits);
 int hfl_stream_destroy(hfl_stream_t stream);
+/* Ordering between two streams through a device word instead of an event: hfl_flag_set queues a store of `value` to *flag
+ * (release) behind the work already in `stream`; hfl_flag_wait queues a one-lane kernel that polls *flag until it is >= value
+ * (acquire; at most max_polls polls of ~0.5 us, then it gives up and lets the stream go on) in front of the work that follows
+ * in its stream.  flag: 4 bytes of device memory, zero-initialised by the caller, values increasing.  (What the reference does
+ * with torch.cuda streams and `wait_stream`, models/hotformerloc_backbone.py:604-633, where the hop has to be short.) */
+int hfl_flag_set(unsigned int* flag, unsigned int value, hfl_stream_t stream);
+int hfl_flag_wait(const unsigned int* flag, unsigned int value, int max_polls, hfl_stream_t stream);
 
 #define HFL_OK 0
 #define HFL_EINVAL (-1)      /* unsupported shape / argument            */
