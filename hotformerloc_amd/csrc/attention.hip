@@ -1775,6 +1775,10 @@ int hfl_window_attention_fwd_ex(void* out, const float* qkv, const float* qkv_bi
 
 int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth, int f16_operand) {
   if (n_heads <= 0 || pos_bnd < 0) return 0;
+  if (f16_operand == 2) {                  // the fused attention kernels: three 1-D tables at every depth <= 7
+    if (depth < 1 || depth > 7) return 0;
+    return (int64_t)n_heads * (int64_t)((3 * (2 * ((1 << depth) - 1) + 1) + 3) & ~3);
+  }
   return (int64_t)n_heads * (int64_t)rpe_form_floats(depth, pos_bnd, f16_operand ? 1 : 0);
 }
 
@@ -1782,7 +1786,7 @@ int hfl_window_rpe_expand(float* out, const float* rpe_table, int n_heads, int p
                           hfl_stream_t stream) {
   const int64_t n = hfl_window_rpe_expand_size(n_heads, pos_bnd, depth, f16_operand);
   if (n <= 0 || out == nullptr || rpe_table == nullptr) return HFL_EINVAL;
-  if (rpe_form(depth, pos_bnd, f16_operand ? 1 : 0) == 1)
+  if (f16_operand != 2 && rpe_form(depth, pos_bnd, f16_operand ? 1 : 0) == 1)
     rpe_expand_kernel<<<(unsigned)hfl_cdiv(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
         out, rpe_table, n_heads, pos_bnd, (1 << depth) - 1);
   else

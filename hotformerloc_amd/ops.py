@@ -927,7 +927,7 @@ def rpe_expand(rpe_table, n_heads: int, pos_bnd: int, depth: int, f16: bool = Fa
     n = lib.hfl_window_rpe_expand_size(n_heads, pos_bnd, depth, int(f16))
     if n <= 0:
         return None
-    key = (id(rpe_table), depth, bool(f16))
+    key = (id(rpe_table), depth, int(f16))            # (f16 = 2: the fused attention kernels' three 1-D tables at every depth)
     hit = _RPE2_CACHE.get(key)
     # data_ptr / device: `module.to(...)` swaps `.data` without bumping the version counter
     if (hit is not None and hit[0]() is rpe_table and hit[1] == rpe_table._version and hit[3] == rpe_table.data_ptr()

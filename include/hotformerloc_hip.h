@@ -273,6 +273,7 @@ int hfl_window_attention_fwd_multi(int n, void* const* out, const float* const* 
  *   f16_operand = 1 (fp16 (hi, lo) qkv kernel, flag 0x100 of hfl_window_attention_fwd_ex): that form up to depth 4; from
  *     depth 5 (and whenever R > pos_bnd) three 1-D tables over the full coordinate range with the reference's clamp baked
  *     in (depth <= 7)
+ *   f16_operand = 2: the three 1-D tables at every depth <= 7 (what the fp16 kernel reads from depth 5 on, for any depth)
  * out holds hfl_window_rpe_expand_size() floats; rebuild it whenever rpe_table changes.  A table built for one consumer
  * must not be handed to the other. */
 int64_t hfl_window_rpe_expand_size(int n_heads, int pos_bnd, int depth, int f16_operand);

@@ -44,13 +44,41 @@ CASES = {
 }
 
 
+# The BASELINE.json workloads themselves, at their full sizes: clouds from `bench.py::bench_clouds` (the generator is part
+# of the product package, so the fixture stores its arguments, not 1.5 MB of points) and the bench's weight profile.
+#   case -> (cfg, octree depth, weight profile, make_clouds config id, batch, n_points, n_points_max or None)
+WORKLOAD_CASES = {
+    'wild_places_b32':       ('wild-places', 7, 'init', 2, 32, 4096, None),        # config 2 = the bench's timed batch
+    'cs_wild_places_b8_var': ('cs-wild-places', 7, 'init', 3, 8, 4096, 32768),     # config 3's generator, 8 clouds
+}
+
+
+def workload_clouds(coordinates, cid, batch, n_points, n_points_max):
+    """bench.py::bench_clouds for rank 0"""
+    if n_points_max:
+        clouds = []
+        for i in range(batch):
+            clouds += syn.make_clouds(cid, 1, n_points, coordinates, kind='forest' if i % 2 == 0 else 'ball',
+                                      n_points_max=n_points_max, first_index=i)
+        return clouds
+    return syn.make_clouds(cid, batch, n_points, coordinates)
+
+
 def build_case(case):
-    cfg, depth, cid, spec = CASES[case]
+    workload = case in WORKLOAD_CASES
+    if workload:
+        cfg, depth, profile, cid, batch, n_points, n_points_max = WORKLOAD_CASES[case]
+    else:
+        cfg, depth, cid, spec = CASES[case]
+        profile = 'stress'
     cfg_path = os.path.join(ref_import.REFERENCE_ROOT, 'models', 'hotformerloc_%s_cfg.txt' % cfg)
     model, params = ref_import.reference_model(cfg_path)
-    syn.fill_synthetic_weights(model, 'stress')
+    syn.fill_synthetic_weights(model, profile)
     clouds = []
-    for i, (n, kind) in enumerate(spec):
+    if workload:
+        clouds = workload_clouds(params.coordinates, cid, batch, n_points, n_points_max)
+    else:
+      for i, (n, kind) in enumerate(spec):
         seed = 1000 * cid + i
         pc = syn.unit_ball_cloud(seed, n) if kind == 'ball' else syn.forest_cloud(seed, n)
         if params.coordinates == 'cylindrical':
@@ -79,9 +107,15 @@ def build_case(case):
 
     out = dict(cfg=np.array(cfg), octree_depth=np.array(depth),
                n_points=np.array([c.shape[0] for c in clouds], dtype=np.int64),
-               points=np.concatenate(clouds, 0).astype(np.float32),
                descriptors=y.numpy().astype(np.float32),
                nnum_nempty=octree.nnum_nempty.numpy())
+    if workload:      # the generator's arguments + a checksum of the points it produced here
+        out['workload'] = np.array([cid, batch, n_points, n_points_max or 0], dtype=np.int64)
+        out['profile'] = np.array(profile)
+        out['points_sum'] = np.array([np.concatenate(clouds, 0).astype(np.float64).sum(),
+                                      (np.concatenate(clouds, 0).astype(np.float64) ** 2).sum()])
+    else:
+        out['points'] = np.concatenate(clouds, 0).astype(np.float32)
 
     def put(name, t):
         t = t.detach().double()
@@ -116,13 +150,13 @@ def main():
     if sys.argv[1:] == ['state_dicts']:
         dump_state_dicts(dst)
         return
-    for case in (sys.argv[1:] or CASES):
+    for case in (sys.argv[1:] or list(CASES) + list(WORKLOAD_CASES)):
         out = build_case(case)
         path = os.path.join(dst, 'model_%s.npz' % case)
         np.savez_compressed(path, **out)
         d = out['descriptors']
         print(case, out['n_points'].tolist(), 'nne', out['nnum_nempty'].tolist(),
-              'desc[0,:3]', d[0, :3], 'pairwise', np.round(d @ d.T, 3).tolist(),
+              'desc[0,:3]', d[0, :3], 'pairwise', np.round((d @ d.T)[:4, :4], 3).tolist(),
               '%.0f KB' % (os.path.getsize(path) / 1024))
 
 

@@ -101,6 +101,44 @@ def test_descriptors_match_reference_golden(golden_dir, case, gemm_mode):
     assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', ['wild_places_b32', 'cs_wild_places_b8_var'])
+@pytest.mark.parametrize('mode', ['x3', 'fp32'])
+def test_full_size_workloads_match_reference_golden(golden_dir, case, mode):
+    """BASELINE configs 2 and 3 at their real sizes against the REFERENCE's own output (oracle/gen_golden.py::WORKLOAD_CASES:
+    the reference model files run in the build container on the bench's batch -- 32 clouds x 4096 points, Wild-Places cfg,
+    the bench's 'init' weights -- and on 8 clouds of config 3's generator, 4.5 k .. 23 k points, CS-Wild-Places cfg):
+    descriptors within 1e-3 relative L2 per cloud, in the default split-bf16 mode and with fp32 Linear layers."""
+    g = load_case(golden_dir, case)
+    params, depth = load_config(g['cfg'])
+    set_gemm_mode(mode)
+    try:
+        model = _device_model(params, g['profile'])
+        octs = []
+        for pc in g['clouds']:
+            o = Octree(depth, 2)
+            o.build_octree(Points(torch.from_numpy(pc)))
+            octs.append(o)
+        octree = merge_octrees(octs).to('cuda')
+        octree.construct_all_neigh()
+        assert np.array_equal(octree.nnum_nempty.numpy(), g['nnum_nempty'])
+        y, cap = _run_with_capture(model, octree)
+    finally:
+        set_gemm_mode('x3')
+    y = y.cpu().numpy()
+    assert y.shape == g['descriptors'].shape and np.isfinite(y).all()
+    report = {'descriptor': float(_rel(y, g['descriptors']).max())}
+    for name in ('patch_embed', 'octf_out'):
+        head = g[name + '_head']
+        report[name] = _stage_err(cap[name][:head.shape[0]], head)
+    feats, rts = cap['hotf']
+    for d in feats:
+        head = g['feat_final_%d_head' % d]
+        report['feat_final_%d' % d] = _stage_err(feats[d][:head.shape[0]], head)
+    print(case, mode, report)
+    bad = {k: v for k, v in report.items() if not v <= REL_TOL}
+    assert not bad, (bad, report)
+
+
 _ORACLE_CACHE = {}
 
 

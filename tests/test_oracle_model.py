@@ -44,6 +44,20 @@ def test_oracle_matches_reference_golden(golden_dir, case):
             assert np.abs(val[:head.shape[0]].numpy() - head).max() < 2e-4
 
 
+def test_oracle_matches_reference_on_the_bench_workload(golden_dir):
+    """The batch `bench.py` times (32 clouds x 4096 points, Wild-Places cfg, 'init' weights): the oracle -- which the bench's
+    `parity` block and `cpu_baseline` run -- against the reference's own descriptors for that batch
+    (oracle/gen_golden.py::WORKLOAD_CASES)."""
+    g = load_case(golden_dir, 'wild_places_b32')
+    params, depth = load_config(g['cfg'])
+    octree = oracle_octree(g['clouds'], depth)
+    assert np.array_equal(octree.nnum_nempty.numpy(), g['nnum_nempty'])
+    y = hotformer_ref.forward(synthetic_state_dict(params, g['profile']), params, octree).numpy()
+    ref = g['descriptors']
+    rel = np.linalg.norm(y - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert rel.max() < 2e-5, rel
+
+
 def test_oracle_matches_reference_live():
     """Only where /root/reference exists (build container): rerun the reference."""
     from oracle import ref_import
