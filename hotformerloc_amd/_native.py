@@ -43,13 +43,15 @@ class RelayBlockWeights(ctypes.Structure):
     _fields_ = [('channels', c_int64), ('n_heads', c_int32), ('eps', c_float),
                 ('norm1_gamma', c_void_p), ('norm1_beta', c_void_p), ('norm2_gamma', c_void_p), ('norm2_beta', c_void_p),
                 ('qkv_w', c_void_p), ('proj_w', c_void_p), ('fc1_w', c_void_p), ('fc2_w', c_void_p),
-                ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p), ('mlp_pack', c_void_p)]
+                ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p), ('mlp_pack', c_void_p),
+                ('qkv_pack', c_void_p)]
 
 
 class RelayBlockIO(ctypes.Structure):
     """hfl_relay_block_io"""
     _fields_ = [('x_in', c_void_p), ('out', c_void_p), ('arena', c_void_p), ('seq_rows', c_void_p), ('seq_off', c_void_p),
-                ('n_rows', c_int64), ('batch', c_int32), ('max_seq_len', c_int32)]
+                ('n_rows', c_int64), ('batch', c_int32), ('max_seq_len', c_int32), ('orphan_rows', c_void_p),
+                ('n_orphans', c_int32)]
 
 
 class BlockIO(ctypes.Structure):
@@ -158,6 +160,7 @@ SIGNATURES = {
     'hfl_window_rpe_expand': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'hfl_relay_attention_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),
+    'hfl_relay_attention_f16_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     'hfl_relay_token_init': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                      c_int64, c_void_p]),
     'hfl_window_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int, c_void_p]),

@@ -105,6 +105,46 @@ def octree_gather(data, neigh):
     return OctreeGatherFn.apply(data, neigh)
 
 
+class TallMmFn(torch.autograd.Function):
+    """y = col @ w [+ bias] for a dense-gather octree convolution (model.OctreeConv's fallback: the first stem convolution,
+    3 input channels, and the 32 -> 64 stride-2 one -- `ocnn.nn.OctreeConv`'s octree2col + mm, models/layers/octformer_layers.py:
+    89-95) with the weight gradient as a split-K product.  Autograd's dW = col^T dy is a (27 Cin, Cout) = (81, 32) or (256, 64)
+    output contracted over 0.66-0.87 M rows: the BLAS library runs it on the three to eight workgroups its output tiles give
+    (5.5 and 4.6 ms of the 160 ms config-3 step, tools/train_ops_profile.py).  Here the rows are cut into chunks that one
+    batched GEMM contracts side by side and a small sum over the chunks finishes (fp32, fixed order)."""
+
+    CHUNK = 4096
+
+    @staticmethod
+    def forward(ctx, col, w, bias):
+        ctx.save_for_backward(col, w)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, col, w) if bias is not None else torch.mm(col, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dcol = dy.mm(w.t()) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            n, rows = col.shape[0], TallMmFn.CHUNK
+            s = n // rows
+            if s >= 2:
+                n0 = s * rows
+                dw = torch.bmm(col[:n0].view(s, rows, -1).transpose(1, 2), dy[:n0].view(s, rows, -1)).sum(0)
+                if n0 < n:
+                    dw = dw.addmm_(col[n0:].t(), dy[n0:])
+            else:
+                dw = col.t().mm(dy)
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dcol, dw, db
+
+
+def tall_mm(col, w, bias=None):
+    return TallMmFn.apply(col, w, bias)
+
+
 class LiveTapConvFn(torch.autograd.Function):
     """Octree convolution over its LIVE (row, tap) pairs (model.OctreeConv._forward_live_taps) with its gradients in the
     same form: the output gradient is gathered pair-major, every tap is two small GEMMs (dg_k = dpart_k W_k^T,

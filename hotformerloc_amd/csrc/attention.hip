@@ -1490,6 +1490,104 @@ relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
   }
 }
 
+
+// The same attention on the fp16 (hi, lo) operand rows hfl_ln_qkv_fused writes (per row [Q | K | V] regions of C * 4 bytes, per
+// head 64 B = [16 hi | 16 lo] fp16, queries pre-multiplied by scale * log2 e), writing the proj GEMM's bf16 split2 operand
+// directly: with LayerNorm -> qkv as one launch in front and no split pass behind, the relay-token block's attention branch is
+// three launches instead of six (LayerNorm, qkv GEMM, memset, attention, split2, proj).  fp32 MFMA as above, exp2-domain
+// softmax.  Block `batch` of the grid writes zeros to the rows that belong to no sequence (the relay tokens of pure padding
+// windows, `orphan_rows`), which the memset did before.
+__global__ void __launch_bounds__(256)
+relay_attn_f16_kernel(unsigned char* __restrict__ out2, const unsigned char* __restrict__ qkv,
+                      const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ seq_off,
+                      const int32_t* __restrict__ orphan_rows, int n_orphans, int batch, int H) {
+  const int b = blockIdx.x;
+  const int C = H * 16;
+  if (b >= batch) {
+    const int per_row = C * 4 / 16;                       // 16-B cells of an output row
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n_orphans * per_row; i += gridDim.y * blockDim.x)
+      *reinterpret_cast<uint4*>(out2 + (size_t)orphan_rows[i / per_row] * (size_t)(C * 4) + (size_t)(i % per_row) * 16) =
+          make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const int r0 = seq_off[b];
+  const int R = seq_off[b + 1] - r0;
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15, g = lane >> 4;
+  const int ntile = (R + 15) / 16;
+  const int wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const size_t row_b = (size_t)C * 12;                    // bytes of an operand row: 3 regions of C * 4
+  auto ld4 = [&](const unsigned char* p) -> float4 {      // dims 4 g .. 4 g + 3 of a head's 64 B at p: hi + lo
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + 8 * g), lo = *reinterpret_cast<const uint2*>(p + 32 + 8 * g);
+    auto h = [](unsigned int w, int k) -> float {
+      return (float)__builtin_bit_cast(_Float16, (unsigned short)(k ? w >> 16 : w & 0xFFFFu));
+    };
+    return make_float4(h(hi.x, 0) + h(lo.x, 0), h(hi.x, 1) + h(lo.x, 1), h(hi.y, 0) + h(lo.y, 0), h(hi.y, 1) + h(lo.y, 1));
+  };
+  for (int item = blockIdx.y * nwave + wave; item < H * ntile; item += gridDim.y * nwave) {
+    const int h = item / ntile, qt = item % ntile;
+    const int qi = qt * 16 + c;
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qi < R) qf = ld4(qkv + (size_t)seq_rows[r0 + qi] * row_b + h * 64);
+    float m = kDeadValue, l = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      float inv = 0.f;
+      if (pass == 1) {
+        float m2 = fmaxf(m, __shfl_xor(m, 16, 64));
+        m2 = fmaxf(m2, __shfl_xor(m2, 32, 64));
+        float l2 = l * __builtin_amdgcn_exp2f(m - m2);
+        l2 += __shfl_xor(l2, 16, 64);
+        l2 += __shfl_xor(l2, 32, 64);
+        m = m2;
+        inv = 1.0f / l2;
+      }
+      for (int kt = 0; kt < ntile; ++kt) {
+        const int kj = kt * 16 + c;
+        float4 kf = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kj < R) kf = ld4(qkv + (size_t)seq_rows[r0 + kj] * row_b + (size_t)C * 4 + h * 64);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = kt * 16 + 4 * g + r;
+          const float v = kk < R ? acc[r] : kDeadValue;
+          if (pass == 0) {
+            const float mn = fmaxf(m, v);
+            l = l * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(v - mn);
+            m = mn;
+          } else {
+            const float pv = __builtin_amdgcn_exp2f(v - m) * inv;
+            float vv = 0.f;
+            if (kk < R) {
+              const unsigned char* vp = qkv + (size_t)seq_rows[r0 + kk] * row_b + (size_t)C * 8 + h * 64 + c * 2;
+              vv = (float)__builtin_bit_cast(_Float16, *reinterpret_cast<const unsigned short*>(vp)) +
+                   (float)__builtin_bit_cast(_Float16, *reinterpret_cast<const unsigned short*>(vp + 32));
+            }
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vv, o, 0, 0, 0);
+          }
+        }
+      }
+      if (pass == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int oq = qt * 16 + 4 * g + r;
+          if (oq < R) {
+            const uint32_t hb = x3_bf16_rne(o[r]);
+            const uint32_t lb = x3_bf16_rne(o[r] - __uint_as_float(hb << 16));
+            unsigned char* op = out2 + (size_t)seq_rows[r0 + oq] * (size_t)(C * 4) + (h >> 1) * 128 + (h & 1) * 32 + c * 2;
+            *reinterpret_cast<unsigned short*>(op) = (unsigned short)hb;
+            *reinterpret_cast<unsigned short*>(op + 64) = (unsigned short)lb;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1804,6 +1902,19 @@ int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_row
   dim3 grid((unsigned)batch, (unsigned)(items > 4 ? (items + 3) / 4 : 1));
   relay_attn_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(out, qkv, seq_rows, seq_off,
                                                                         n_heads, scale);
+  HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_relay_attention_f16_fwd(void* out_split2, const void* qkv_f16, const int32_t* seq_rows, const int32_t* seq_off, int batch,
+                                int n_heads, int max_seq_len, const int32_t* orphan_rows, int n_orphans, hfl_stream_t stream) {
+  if (out_split2 == nullptr || qkv_f16 == nullptr || seq_rows == nullptr || seq_off == nullptr || batch <= 0 || n_heads <= 0 ||
+      max_seq_len < 0 || n_orphans < 0 || (n_orphans > 0 && orphan_rows == nullptr))
+    return HFL_EINVAL;
+  const int items = n_heads * ((max_seq_len + 15) / 16);
+  dim3 grid((unsigned)batch + (n_orphans > 0 ? 1u : 0u), (unsigned)(items > 4 ? (items + 3) / 4 : 1));
+  relay_attn_f16_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<unsigned char*>(out_split2), static_cast<const unsigned char*>(qkv_f16), seq_rows, seq_off, orphan_rows,
+      n_orphans, batch, n_heads);
   HFL_RETURN_LAST_ERROR();
 }
 

@@ -304,16 +304,27 @@ int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay
   float* x1 = reinterpret_cast<float*>(a + 6 * unit);
   uint16_t* h2 = reinterpret_cast<uint16_t*>(a + 7 * unit);
   uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
-  int rc = hfl_layer_norm_split2(a2, io->x_in, w->norm1_gamma, w->norm1_beta, rows, C, w->eps, stream);
-  if (rc != HFL_OK) return rc;
-  rc = hfl_linear_x3(qkv, a2, w->qkv_w, w->qkv_b, nullptr, rows, (int)C, (int)(3 * C), 0, stream);
-  if (rc != HFL_OK) return rc;
-  hipError_t e = hipMemsetAsync(att, 0, unit, static_cast<hipStream_t>(stream));      // rows in no sequence -> 0
-  if (e != hipSuccess) return (int)e;
-  rc = hfl_relay_attention_fwd(att, qkv, io->seq_rows, io->seq_off, io->batch, w->n_heads, 0.25f, io->max_seq_len, stream);
-  if (rc != HFL_OK) return rc;
-  rc = hfl_split2(o2, att, rows, C, stream);
-  if (rc != HFL_OK) return rc;
+  int rc;
+  if (w->qkv_pack != nullptr) {
+    // LN1 -> qkv as one launch into the fp16 (hi, lo) operand rows, the attention from them straight into proj's operand
+    rc = hfl_ln_qkv_fused(qkv, io->x_in, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b,
+                          0.25f * 1.4426950408889634f, rows, (int)C, stream);
+    if (rc != HFL_OK) return rc;
+    rc = hfl_relay_attention_f16_fwd(o2, qkv, io->seq_rows, io->seq_off, io->batch, w->n_heads, io->max_seq_len, io->orphan_rows,
+                                     io->n_orphans, stream);
+    if (rc != HFL_OK) return rc;
+  } else {
+    rc = hfl_layer_norm_split2(a2, io->x_in, w->norm1_gamma, w->norm1_beta, rows, C, w->eps, stream);
+    if (rc != HFL_OK) return rc;
+    rc = hfl_linear_x3(qkv, a2, w->qkv_w, w->qkv_b, nullptr, rows, (int)C, (int)(3 * C), 0, stream);
+    if (rc != HFL_OK) return rc;
+    hipError_t e = hipMemsetAsync(att, 0, unit, static_cast<hipStream_t>(stream));      // rows in no sequence -> 0
+    if (e != hipSuccess) return (int)e;
+    rc = hfl_relay_attention_fwd(att, qkv, io->seq_rows, io->seq_off, io->batch, w->n_heads, 0.25f, io->max_seq_len, stream);
+    if (rc != HFL_OK) return rc;
+    rc = hfl_split2(o2, att, rows, C, stream);
+    if (rc != HFL_OK) return rc;
+  }
   rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, io->x_in, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // LN2 -> fc1 -> GELU -> fc2 -> residual in one launch, hidden dimension split over the chip

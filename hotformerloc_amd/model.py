@@ -232,6 +232,11 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
 _QKV_FUSED_MIN_ROWS = int(os.environ.get('HFL_QKV_FUSED_MIN_ROWS', '24576'))
 _RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
+# relay-token block: LN1 -> qkv as ONE launch (csrc/qkv_fused.hip, output features split over the chip for the ~2 k rows) and
+# the ragged attention reading its fp16 (hi, lo) rows and writing attention.proj's split2 operand itself
+# (hfl_relay_attention_f16_fwd): LayerNorm, qkv GEMM, memset, attention, split2 -> two launches.  The block is a chain of tiny
+# launches on the cycle every H-OSA iteration waits for.
+_RTSA_SLIM = os.environ.get('HFL_RTSA_SLIM', '1') != '0'
 # LN1 -> qkv -> window attention of the blocks without relay tokens (OctFormer stage) as one launch (csrc/attn_fused.hip)
 _ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
 # attentional pooling of the head as one launch per level (csrc/attn_pool.hip) instead of GEMM + segment softmax + two
@@ -511,6 +516,8 @@ class OctreeConv(nn.Module):
         neigh = octree.get_neigh(depth, self.kernel, self.stride, nempty=True)
         col = ag.octree_gather(data, neigh) if _grad_path(data) else ops.octree_gather(data, neigh)
         w = self.weights.reshape(self.kdim * self.in_channels, self.out_channels)
+        if torch.is_grad_enabled() and (col.requires_grad or self.weights.requires_grad):
+            return ag.tall_mm(col, w, self.bias)          # (weight gradient contracted over the rows as a split-K product)
         if self.bias is not None:
             return torch.addmm(self.bias, col, w)
         return torch.mm(col, w)
@@ -1097,9 +1104,12 @@ class RelayTokenTransformerBlock(nn.Module):
             # three launches alone, and inside the step the relay tokens' fc2 -- K = 1024 over 28 workgroups -- took 120 us:
             # 2361 -> 2417 clouds/s, three alternating runs each)
             mpack = _mlp_pack(mlp, _MLP_FUSED_MIN_ROWS) if (_RTSA_MLP_FUSED and att.dim in (128, 256)) else None
-            keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2), mpack)
+            # (LN1 -> qkv as one launch and the attention writing proj's operand: six launches -> three, see _RTSA_SLIM)
+            qpack = _qkv_pack(att, _QKV_FUSED_MIN_ROWS) if _RTSA_SLIM else None
+            keep = (_w2(att.qkv), _w2(att.proj), _w2(mlp.fc1), _w2(mlp.fc2), mpack, qpack)
             w = RelayBlockWeights(channels=att.dim, n_heads=att.num_heads, eps=self.norm1.eps,
                                   mlp_pack=None if mpack is None else mpack.data_ptr(),
+                                  qkv_pack=None if qpack is None else qpack.data_ptr(),
                                   norm1_gamma=self.norm1.weight.data_ptr(), norm1_beta=self.norm1.bias.data_ptr(),
                                   norm2_gamma=self.norm2.weight.data_ptr(), norm2_beta=self.norm2.bias.data_ptr(),
                                   qkv_w=keep[0].data_ptr(), proj_w=keep[1].data_ptr(), fc1_w=keep[2].data_ptr(),
@@ -1115,11 +1125,18 @@ class RelayTokenTransformerBlock(nn.Module):
                 static = self._native_static(rt.device)          # the same nine launches from ONE native call
                 if static is not None:
                     return ops.relay_block_forward_x3(static[0], static[1], rt, plan.seq_rows, plan.seq_off, plan.B,
-                                                      plan.max_seq_len)
+                                                      plan.max_seq_len, plan.orphan_rows)
             att = self.rt_attention
-            a2 = ops.layer_norm_split2(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            qkv = ops.linear_x3(a2, _w2(att.qkv), bias=att.qkv.bias)
-            o2 = ops.split2(ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, att.num_heads, plan.max_seq_len))
+            qpack = _qkv_pack(att, _QKV_FUSED_MIN_ROWS) if _RTSA_SLIM else None
+            if qpack is not None:
+                qkv = ops.ln_qkv_fused(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps, qpack, att.qkv.bias,
+                                       0.25 * 1.4426950408889634)
+                o2 = ops.relay_attention_f16(qkv, plan.seq_rows, plan.seq_off, plan.B, att.num_heads, plan.max_seq_len,
+                                             plan.orphan_rows)
+            else:
+                a2 = ops.layer_norm_split2(rt, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+                qkv = ops.linear_x3(a2, _w2(att.qkv), bias=att.qkv.bias)
+                o2 = ops.split2(ops.relay_attention(qkv, plan.seq_rows, plan.seq_off, plan.B, att.num_heads, plan.max_seq_len))
             return _block_tail_x3(rt, o2, att, self.norm2, self.mlp, fused_any_rows=_RTSA_MLP_FUSED and att.dim in (128, 256))
         if self.use_layer_scale or (self.training and self.drop_path.drop_prob > 0.0):
             bid = plan.relay_cloud()

@@ -596,15 +596,17 @@ def block_attention_multi(calls):
     check(lib.hfl_block_attention_x3_multi(n, ws, ios, ds, _stream()), 'hfl_block_attention_x3_multi')
 
 
-def relay_block_forward_x3(weights, keep_alive, rt, seq_rows, seq_off, batch: int, max_seq_len: int):
+def relay_block_forward_x3(weights, keep_alive, rt, seq_rows, seq_off, batch: int, max_seq_len: int, orphan_rows=None):
     """The relay-token transformer block (RTSA) of the inference path in ONE native call (hfl_relay_block_forward_x3)."""
-    _dev(rt, seq_rows, seq_off)
+    _dev(rt, seq_rows, seq_off, orphan_rows)
     rows, c = rt.shape
     lib = _native.load()
     out = torch.empty((rows, c), dtype=torch.float32, device=rt.device)
     arena = torch.empty(int(lib.hfl_relay_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=rt.device)
     io = _native.RelayBlockIO(x_in=rt.data_ptr(), out=out.data_ptr(), arena=arena.data_ptr(), seq_rows=seq_rows.data_ptr(),
-                              seq_off=seq_off.data_ptr(), n_rows=rows, batch=batch, max_seq_len=max_seq_len)
+                              seq_off=seq_off.data_ptr(), n_rows=rows, batch=batch, max_seq_len=max_seq_len,
+                              orphan_rows=None if orphan_rows is None or orphan_rows.numel() == 0 else orphan_rows.data_ptr(),
+                              n_orphans=0 if orphan_rows is None else orphan_rows.numel())
     check(lib.hfl_relay_block_forward_x3(ctypes.byref(weights), ctypes.byref(io), _stream()), 'hfl_relay_block_forward_x3')
     return out
 
@@ -1024,6 +1026,23 @@ def window_attention_multi(problems, out_split: int = 2):
                                              _native.ptr_array([ctypes.addressof(d) for d in descs]),
                                              out_split | 0x100, _stream()), 'hfl_window_attention_fwd_multi')
     return outs
+
+
+def relay_attention_f16(qkv_f16, seq_rows, seq_off, batch: int, n_heads: int, max_seq_len: int, orphan_rows=None):
+    """Ragged relay-token self-attention on the fp16 (hi, lo) operand rows of `ln_qkv_fused` (q pre-scaled by 16^-0.5 log2 e)
+    -> (rows, 2C) bf16 split2, the operand of attention.proj; rows of no sequence (`orphan_rows`) come out zero
+    (hfl_relay_attention_f16_fwd)."""
+    _dev(qkv_f16, seq_rows, seq_off, orphan_rows)
+    rows, c3 = qkv_f16.shape
+    c = c3 // 3
+    assert qkv_f16.dtype == torch.float32 and qkv_f16.is_contiguous() and c == n_heads * 16
+    out = torch.empty((rows, 2 * c), dtype=torch.bfloat16, device=qkv_f16.device)
+    n_orph = 0 if orphan_rows is None else orphan_rows.numel()
+    check(_native.load().hfl_relay_attention_f16_fwd(out.data_ptr(), qkv_f16.data_ptr(), seq_rows.data_ptr(), seq_off.data_ptr(),
+                                                     batch, n_heads, max_seq_len,
+                                                     orphan_rows.data_ptr() if n_orph else None, n_orph, _stream()),
+          'hfl_relay_attention_f16_fwd')
+    return out
 
 
 def relay_attention(qkv, seq_rows, seq_off, batch: int, n_heads: int, max_seq_len: int):

@@ -79,6 +79,12 @@ def window_layout(batch_nne: np.ndarray, patch_size: int, dilation: int, max_dep
         seq_off.append(len(seq_rows))
     out['seq_rows'] = np.asarray(seq_rows, dtype=np.int32)
     out['seq_off'] = np.asarray(seq_off, dtype=np.int32)
+    # rows of the relay-token matrix that no cloud lists: the relay tokens of the pure padding windows at the end of every depth
+    orphans = []
+    for d in pyramid_depths:
+        W, npad = out['n_windows'][d], out['n_pad_windows'][d]
+        orphans.extend(range(out['rt_offset'][d] + W - npad, out['rt_offset'][d] + W))
+    out['orphan_rows'] = np.asarray(orphans, dtype=np.int32)
     out['rt_counts'] = rt_counts
     return out
 
@@ -107,8 +113,9 @@ class WindowPlan:
         dev = self.device
         self.meta = {d: ops.token_meta(octree.nkeys[d], d) for d in range(start_depth, max_depth + 1)}
         # the small host-built index arrays travel in two copies (int32 | int64), not one blocking pageable copy each
-        i32 = torch.from_numpy(np.concatenate([lay['seq_rows'], lay['seq_off']])).to(dev, non_blocking=True)
-        self.seq_rows, self.seq_off = i32[:lay['seq_rows'].size], i32[lay['seq_rows'].size:]
+        i32 = torch.from_numpy(np.concatenate([lay['seq_rows'], lay['seq_off'], lay['orphan_rows']])).to(dev, non_blocking=True)
+        n1, n2 = lay['seq_rows'].size, lay['seq_rows'].size + lay['seq_off'].size
+        self.seq_rows, self.seq_off, self.orphan_rows = i32[:n1], i32[n1:n2], i32[n2:]
         self.max_seq_len = int(np.diff(lay['seq_off']).max()) if self.B > 0 else 0
         # per-cloud row offsets of the token stream (attentional pooling segments) and the padded gather index of the
         # pooling head (built on the device: hfl_pad_index)

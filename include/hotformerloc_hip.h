@@ -319,6 +319,11 @@ int hfl_set_variant(const char* key, int value);
 int hfl_relay_attention_fwd(float* out, const float* qkv, const int32_t* seq_rows,
                             const int32_t* seq_off, int batch, int n_heads, float scale,
                             int max_seq_len, hfl_stream_t stream);
+/* The same attention on the fp16 (hi, lo) operand rows hfl_ln_qkv_fused writes (queries pre-multiplied by 16^-0.5 * log2 e),
+ * writing attention.proj's bf16 split2 operand (rows, 2C) directly; `orphan_rows` (n_orphans of them, may be 0): rows of no
+ * sequence, written as zeros (models/hotformerloc_backbone.py:83-119 on the padded sequences gives those rows no consumer). */
+int hfl_relay_attention_f16_fwd(void* out_split2, const void* qkv_f16, const int32_t* seq_rows, const int32_t* seq_off, int batch,
+                                int n_heads, int max_seq_len, const int32_t* orphan_rows, int n_orphans, hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 6. Relay-token initialisation and window statistics
@@ -603,6 +608,10 @@ typedef struct hfl_relay_block_weights {
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
   const void* mlp_pack;                                /* hfl_mlp_fused_pack image of (fc1, fc2) or NULL: when set (C = 128 / 256) the MLP
                                                           branch is ONE launch (hfl_ln_mlp_fused_ws) and fc1_w / fc2_w are not read */
+  const void* qkv_pack;                                /* hfl_qkv_fused_pack image of qkv_w or NULL: when set, LN1 -> qkv is ONE launch
+                                                          (hfl_ln_qkv_fused) and the attention reads its fp16 (hi, lo) rows and
+                                                          writes proj's split2 operand itself (hfl_relay_attention_f16_fwd): three
+                                                          launches up to proj's input instead of six */
 } hfl_relay_block_weights;
 typedef struct hfl_relay_block_io {
   const float* x_in;
@@ -612,6 +621,9 @@ typedef struct hfl_relay_block_io {
   const int32_t* seq_off;
   int64_t n_rows;
   int32_t batch, max_seq_len;
+  const int32_t* orphan_rows;                          /* rows that belong to no sequence (relay tokens of pure padding windows):
+                                                          their attention output is zero; read when qkv_pack is set */
+  int32_t n_orphans;
 } hfl_relay_block_io;
 int64_t hfl_relay_block_forward_x3_arena(int64_t n_rows, int64_t channels);
 int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay_block_io* io, hfl_stream_t stream);

@@ -496,6 +496,17 @@ def test_relay_attention_init_and_stats(cfg, sizes, depth):
     listed = np.zeros(got.shape[0], bool)
     listed[lay['seq_rows']] = True
     assert torch.all(got[~torch.from_numpy(listed)] == 0)
+    # the same attention on the fp16 (hi, lo) operand rows, writing the proj GEMM's split2 operand (hfl_relay_attention_f16_fwd:
+    # the inference path's relay-token block): equal to the fp32-operand kernel to the operand's 22 bits; rows of no sequence
+    # -- exactly `orphan_rows` -- come out zero
+    assert np.array_equal(np.sort(lay['orphan_rows']), np.flatnonzero(~listed))
+    x_all = torch.cat([rts[d] for d in depths]).to(DEV)
+    packed = _pack_qkv_f16(x_all, H, 0.25 * 1.4426950408889634)
+    o2 = ops.relay_attention_f16(packed, plan.seq_rows, plan.seq_off, B, H, plan.max_seq_len, plan.orphan_rows)
+    v = o2.float().view(o2.shape[0], C // 32, 2, 32)
+    val = (v[:, :, 0] + v[:, :, 1]).reshape(o2.shape[0], C).cpu()
+    assert (val - got).abs().max().item() < 3e-5 * max(got.abs().max().item(), 1.0)
+    assert torch.all(val[~torch.from_numpy(listed)] == 0)
 
 
 def test_segment_softmax():

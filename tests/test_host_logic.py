@@ -192,3 +192,32 @@ def test_split_weight_cache_releases_with_the_parameter():
     del lin, w2, w3
     gc.collect()
     assert len(M._W3_CACHE) == before
+
+
+def test_tall_mm_split_k_weight_gradient_equals_autograd():
+    """autograd.TallMmFn (the dense-gather convolutions' col @ w with a split-K weight gradient, ocnn's octree2col + mm
+    of models/layers/octformer_layers.py:89-95): outputs and all three gradients equal plain autograd, for row counts below one
+    chunk, whole chunks, and chunks plus a remainder; with and without bias."""
+    import torch
+    from hotformerloc_amd.autograd import TallMmFn, tall_mm
+    old, TallMmFn.CHUNK = TallMmFn.CHUNK, 64
+    try:
+        g = torch.Generator().manual_seed(0)
+        for n in (10, 128, 1000):
+            col = torch.randn(n, 81, generator=g, requires_grad=True, dtype=torch.float64)
+            w = torch.randn(81, 32, generator=g, requires_grad=True, dtype=torch.float64)
+            b = torch.randn(32, generator=g, requires_grad=True, dtype=torch.float64)
+            dy = torch.randn(n, 32, generator=g, dtype=torch.float64)
+            for bias in (None, b):
+                y = tall_mm(col, w, bias)
+                y.backward(dy)
+                got = (col.grad.clone(), w.grad.clone(), None if bias is None else b.grad.clone())
+                col.grad = w.grad = b.grad = None
+                y2 = (col @ w) + (0 if bias is None else bias)
+                y2.backward(dy)
+                assert torch.allclose(y, y2) and torch.allclose(got[0], col.grad) and torch.allclose(got[1], w.grad)
+                if bias is not None:
+                    assert torch.allclose(got[2], b.grad)
+                col.grad = w.grad = b.grad = None
+    finally:
+        TallMmFn.CHUNK = old
