@@ -79,10 +79,6 @@ def parse():
     ap.add_argument('--resident-plan', action='store_true',
                     help='headline step keeps the window plan / tap tables cached on the octree (round-2 behaviour)')
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
-    ap.add_argument('--cu-partition', type=int, default=None,
-                    help='CUs of the finest pyramid level\'s CU-masked stream inside the H-OSA iterations (multiple of 8; the '
-                         'coarse levels and the relay-token attention share the rest; 0 = plain streams).  Default: the '
-                         'package\'s (HFL_CU_PARTITION, 192)')
     ap.add_argument('--serial-streams', action='store_true',
                     help="the step's own launch schedule on ONE stream (what the roofline leg times: a kernel trace of this "
                          'run shows every kernel alone; profiles/*_serial_*)')
@@ -295,9 +291,6 @@ def main():
     from hotformerloc_amd.model import set_gemm_mode, set_pyramid_streams
     set_gemm_mode(args.gemm)
     set_pyramid_streams('serial' if args.serial_streams else not args.no_streams)
-    if args.cu_partition is not None:
-        from hotformerloc_amd.model import set_cu_partition
-        set_cu_partition(args.cu_partition)
     if args.no_train_x3:
         from hotformerloc_amd.model import set_train_x3
         set_train_x3(False)
@@ -554,7 +547,7 @@ def main():
                                        if args.multistaged else ('forward+backward, stochastic depth %s' % ('off' if args.no_drop_path else 'on (drop_path = %.2f, as the config trains)' % params.drop_path))) if args.train else 'forward-only',
                                       plan_txt),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
-                       'cu_partition': cu_partition_txt(), 'host_affinity': getattr(args, 'host_affinity', 'not set'),
+                       'host_affinity': getattr(args, 'host_affinity', 'not set'),
                        'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
                                      ('rccl all_gather at world size 1' if collective else 'none')},
             'roofline': roof,
@@ -620,13 +613,6 @@ def main():
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
-
-
-def cu_partition_txt():
-    from hotformerloc_amd import model as M
-    big = M._CU_PARTITION
-    return ('H-OSA iterations: finest pyramid level on a %d-CU masked stream, coarse levels + relay-token attention on the '
-            'other CUs' % big) if big > 0 else 'none (plain streams)'
 
 
 def bench_clouds(syn, params, args, rank):

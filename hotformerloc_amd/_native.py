@@ -64,10 +64,6 @@ class BlockIO(ctypes.Structure):
 # name -> (restype, argtypes): every symbol include/hotformerloc_hip.h declares
 SIGNATURES = {
     'hfl_version': (c_int, []),
-    'hfl_stream_create_cu_mask': (c_int, [c_void_p, c_int, c_int]),
-    'hfl_stream_destroy': (c_int, [c_void_p]),
-    'hfl_flag_set': (c_int, [c_void_p, c_uint32, c_void_p]),
-    'hfl_flag_wait': (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
     'hfl_arch': (c_char_p, []),
     'hfl_dwconv_forward_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                             c_int64, c_int, c_void_p]),

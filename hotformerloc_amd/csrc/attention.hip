@@ -1597,21 +1597,12 @@ extern "C" void hfl_internal_set_cpe_chunk(int rows);
 void hfl_internal_set_x3_dbg(int v);
 void hfl_internal_set_window_bwd(int v);
 void hfl_internal_set_mlp_stagger(int v);
-void hfl_internal_set_mlp_ring_pf(int v);
-void hfl_internal_set_mlp_waves(int v);
-void hfl_internal_set_mlp_lag(int v);
-void hfl_internal_set_round_launches(int v);
+#ifdef HFL_PROBES
 void hfl_internal_set_mlp_dbg(int v);
-void hfl_internal_set_qkv_waves(int v);
-void hfl_internal_set_qkv_ring_pf(int v);
+#endif
 void hfl_internal_set_mlp_tail_split(int v);
 void hfl_internal_set_mlp_dynamic(int v);
-void hfl_internal_set_cu_reserve(int v);
-void hfl_internal_set_x3_ring(int v);
 void hfl_internal_set_attn_fused_split(int v);
-extern "C" void hfl_internal_set_mlp_reserve(int v);
-void hfl_internal_set_qkv_reserve(int v);
-void hfl_internal_set_qkv_dynamic(int v);
 void hfl_internal_set_qkv_tail_split(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
 int hfl_internal_rpe_form(int depth, int bnd, int f16) { return rpe_form(depth, bnd, f16); }     // (csrc/attn_fused.hip)
@@ -1663,51 +1654,23 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_x3_dbg(0x100);
     hfl_internal_set_cpe_chunk(0);
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
-    hfl_internal_set_mlp_ring_pf(3);
-    hfl_internal_set_mlp_waves(8);
-    hfl_internal_set_mlp_lag(0);
-    hfl_internal_set_round_launches(0);
+#ifdef HFL_PROBES
     hfl_internal_set_mlp_dbg(0);
-    hfl_internal_set_qkv_waves(8);
-    hfl_internal_set_qkv_ring_pf(3);
+#endif
     hfl_internal_set_mlp_tail_split(1);
     hfl_internal_set_qkv_tail_split(1);
     hfl_internal_set_mlp_dynamic(1);
-    hfl_internal_set_qkv_dynamic(1);
-    hfl_internal_set_cu_reserve(0);
-    hfl_internal_set_x3_ring(0);
-    hfl_internal_set_mlp_reserve(0);
-    hfl_internal_set_qkv_reserve(0);
-  } else if (is("mlp_reserve")) {
-    hfl_internal_set_mlp_reserve(value);
-  } else if (is("qkv_reserve")) {
-    hfl_internal_set_qkv_reserve(value);
-    hfl_internal_set_attn_fused_split(1);
   } else if (is("attn_fused_split")) {
     hfl_internal_set_attn_fused_split(value);
-  } else if (is("x3_ring")) {
-    hfl_internal_set_x3_ring(value);
-  } else if (is("cu_reserve")) {
-    hfl_internal_set_cu_reserve(value);
   } else if (is("dynamic_units")) {
     hfl_internal_set_mlp_dynamic(value);
-    hfl_internal_set_qkv_dynamic(value);
   } else if (is("tail_split")) {
     hfl_internal_set_mlp_tail_split(value);
     hfl_internal_set_qkv_tail_split(value);
-  } else if (is("qkv_waves")) {
-    hfl_internal_set_qkv_waves(value);
+#ifdef HFL_PROBES
   } else if (is("mlp_dbg")) {
     hfl_internal_set_mlp_dbg(value);
-  } else if (is("round_launches")) {
-    hfl_internal_set_round_launches(value);
-  } else if (is("mlp_lag")) {
-    hfl_internal_set_mlp_lag(value);
-  } else if (is("mlp_waves")) {
-    hfl_internal_set_mlp_waves(value);
-  } else if (is("ring_pf")) {
-    hfl_internal_set_mlp_ring_pf(value);
-    hfl_internal_set_qkv_ring_pf(value);
+#endif
   } else if (is("mlp_stagger")) {
     hfl_internal_set_mlp_stagger(value);
   } else if (is("window_attention")) {

@@ -1,139 +1,13 @@
 // Library identification entry points of libhotformerloc_hip.so.
 #include "hfl_common.h"
 
-#include <mutex>
-#include <utility>
-#include <vector>
-
-namespace {
-std::mutex g_stream_mu;
-std::vector<std::pair<void*, int>> g_stream_cus;       // streams made by hfl_stream_create_cu_mask -> CUs in their mask
-int g_cu_reserve = 0;                                  // probe knob 'cu_reserve'
-int g_round_launches = 0;                              // probe knob 'round_launches' (measured: -1 % of the step, off)
-}  // namespace
 
 extern "C" {
 
-// The chip-filling row-tile launches of a block inside the multi-stream H-OSA schedule (fused LN1 -> qkv of the token rows,
-// fused MLP) as one launch per ROUND of the grid (cus x rows per pass) instead of one persistent launch over all rounds.
-// While such a kernel runs nothing else fits on any CU (8 waves x 256 VGPRs, 135-150 KB of LDS): the relay-token block's
-// launches, on their high-priority stream, waited for its last workgroup -- the relay tokens' fused MLP took 105 us beside the
-// finest level's qkv launch against 21 alone (kernel trace), and the finest level then waited ~58 us per iteration for the
-// relay rows.  At a launch boundary every CU frees at once and the queue arbiter serves the higher-priority stream first.
-// The rows of a round are whole passes (no tail), only the last launch has left-over rows: the same work, cut in time.
-// Measured (profiles/r04_ag_ab_round_launches.log): the relay tokens' MLP drops to 63 us, but its reduce then starves beside
-// the second round (61 us), every round pays its own ramp (depth-4 MLP 184 + 139 us against 276) and the step loses 1 %:
-// 2789-2802 clouds/s against 2820-2829.  Off; `round_launches` = 1 switches it on.
-void hfl_internal_set_round_launches(int v) { g_round_launches = v ? 1 : 0; }
-int hfl_internal_stream_cus(void* stream);
-
-static int qkv_by_rounds(void* qkv_out, const float* x, const hfl_block_weights* w, int64_t n_rows, int64_t C, int split,
-                         hfl_stream_t stream) {
-  const int64_t round = (int64_t)hfl_internal_stream_cus(stream) * (C == 256 ? 128 : 256);
-  int64_t r0 = 0;
-  while (split && g_round_launches && n_rows - r0 >= 2 * round) {      // (the last launch keeps at least one whole round)
-    int rc = hfl_ln_qkv_fused(static_cast<float*>(qkv_out) + r0 * 3 * C, x + r0 * C, w->norm1_gamma, w->norm1_beta, w->eps,
-                              w->qkv_pack, w->qkv_b, w->q_scale, round, (int)C, stream);
-    if (rc != HFL_OK) return rc;
-    r0 += round;
-  }
-  return hfl_ln_qkv_fused(static_cast<float*>(qkv_out) + r0 * 3 * C, x + r0 * C, w->norm1_gamma, w->norm1_beta, w->eps,
-                          w->qkv_pack, w->qkv_b, w->q_scale, n_rows - r0, (int)C, stream);
-}
-
-static int mlp_by_rounds(float* out, const float* x, const hfl_block_weights* w, int64_t n_rows, int64_t C, void* ws,
-                         int64_t ws_bytes, int split, hfl_stream_t stream) {
-  const int64_t round = (int64_t)hfl_internal_stream_cus(stream) * (C == 256 ? 128 : 256);
-  int64_t r0 = 0;
-  while (split && g_round_launches && n_rows - r0 >= 2 * round) {
-    int rc = hfl_ln_mlp_fused_ws(out + r0 * C, x + r0 * C, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b,
-                                 round, (int)C, ws, ws_bytes, stream);
-    if (rc != HFL_OK) return rc;
-    r0 += round;
-  }
-  return hfl_ln_mlp_fused_ws(out + r0 * C, x + r0 * C, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b,
-                             n_rows - r0, (int)C, ws, ws_bytes, stream);
-}
-
-// CUs a launch sizes its persistent grid for.  `cu_reserve` CUs are left out on purpose: the chip-filling kernels of the
-// finest pyramid level occupy a CU completely (8 waves x 256 VGPRs, 135-150 KB of LDS), so while one of them runs no launch
-// of another stream -- the coarse levels' and the relay tokens' short kernels -- finds a free slot anywhere; with a few CUs
-// never claimed by the persistent grids those chains keep moving.
-void hfl_internal_set_cu_reserve(int v) { g_cu_reserve = v < 0 ? 0 : v; }
-
+// CUs a launch sizes its persistent grid for (every launcher asks through hfl_stream_cus): the device's.
 int hfl_internal_stream_cus(void* stream) {
-  int n = hfl_num_cus();
-  if (stream != nullptr) {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (auto& e : g_stream_cus)
-      if (e.first == stream) n = e.second;
-  }
-  return n - g_cu_reserve >= 8 ? n - g_cu_reserve : n;
-}
-
-// A HIP stream whose kernels run on a subset of the chip's CUs: mask bits [first_bit, first_bit + n_bits).  On gfx950 bit i
-// of a CU mask is CU (i / 8) of XCD (i % 8) (tools/micro/cu_mask_census.hip), so a run of 8 k consecutive bits is k CUs of
-// every XCD -- an even slice of every L2.  Streams with disjoint masks do not compete for CUs: persistent kernels of one do
-// not wait for, or starve, the launches of the other.
-int hfl_stream_create_cu_mask(hfl_stream_t* out, int first_bit, int n_bits) {
-  const int total = hfl_num_cus();
-  if (out == nullptr || first_bit < 0 || n_bits < 8 || first_bit % 8 != 0 || n_bits % 8 != 0 || first_bit + n_bits > total)
-    return HFL_EINVAL;
-  std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
-  for (int b = first_bit; b < first_bit + n_bits; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
-  hipStream_t s = nullptr;
-  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
-  if (e != hipSuccess) return (int)e;
-  {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    g_stream_cus.emplace_back(static_cast<void*>(s), n_bits);
-  }
-  *out = static_cast<hfl_stream_t>(s);
-  return HFL_OK;
-}
-
-int hfl_stream_destroy(hfl_stream_t stream) {
-  if (stream == nullptr) return HFL_EINVAL;
-  {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (size_t i = 0; i < g_stream_cus.size(); ++i)
-      if (g_stream_cus[i].first == stream) {
-        g_stream_cus.erase(g_stream_cus.begin() + (long)i);
-        break;
-      }
-  }
-  return (int)hipStreamDestroy(static_cast<hipStream_t>(stream));
-}
-
-// ---- cross-stream ordering through a device flag instead of an event (probe; see tools/hop_latency.py).
-// hfl_flag_set: a one-lane kernel that stores `value` to *flag (release) -- stream order puts it behind everything queued
-// before it.  hfl_flag_wait: a one-lane kernel that polls *flag (acquire) until it is >= value, for at most `max_polls` polls
-// (bounded: a lost signal costs a late, wrong result that the parity tests catch, never a hung queue); the launches behind it
-// in its stream start when it exits.  The waiting side holds no CU resources to speak of (64 lanes, no LDS).
-namespace {
-__global__ void flag_set_kernel(unsigned int* flag, unsigned int value) {
-  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__global__ void flag_wait_kernel(const unsigned int* flag, unsigned int value, int max_polls) {
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < max_polls; ++i) {
-      if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= value) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-}
-}  // namespace
-
-int hfl_flag_set(unsigned int* flag, unsigned int value, hfl_stream_t stream) {
-  if (flag == nullptr) return HFL_EINVAL;
-  flag_set_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(flag, value);
-  HFL_RETURN_LAST_ERROR();
-}
-
-int hfl_flag_wait(const unsigned int* flag, unsigned int value, int max_polls, hfl_stream_t stream) {
-  if (flag == nullptr || max_polls <= 0) return HFL_EINVAL;
-  flag_wait_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(flag, value, max_polls);
-  HFL_RETURN_LAST_ERROR();
+  (void)stream;
+  return hfl_num_cus();
 }
 
 int hfl_version(void) { return 100; }   // 1.00
@@ -170,31 +44,14 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
   int rc;
   const int phase = io->phase;
-  if (phase < 0 || phase > 6) return HFL_EINVAL;
-  if (phase == 5 || phase == 6) {
-    // proj + residual and the MLP branch of the RELAY rows (5) or of the TOKEN rows (6) alone: per-row operators, so the relay
-    // rows -- all the next iteration's relay-token self-attention waits for -- can go first, as three small launches, and that
-    // self-attention then runs beside the token rows' proj / MLP instead of after them
-    const int64_t r0 = phase == 5 ? nt : 0, nr = phase == 5 ? rows - nt : nt;
-    if (nr == 0) return HFL_OK;
-    rc = hfl_linear_x3(x1 + r0 * C, o2 + r0 * 2 * C, w->proj_w, w->proj_b, x0 + r0 * C, nr, (int)C, (int)C, 0, stream);
-    if (rc != HFL_OK) return rc;
-    if (phase == 6 && w->mlp_pack != nullptr)
-      return mlp_by_rounds(io->out + r0 * C, x1 + r0 * C, w, nr, C, a + 12 * unit, mlp_ws_bound(rows, C), 1, stream);
-    if (w->fc1_w == nullptr || w->fc2_w == nullptr) return HFL_EINVAL;
-    rc = hfl_layer_norm_split2(h2 + r0 * 2 * C, x1 + r0 * C, w->norm2_gamma, w->norm2_beta, nr, C, w->eps, stream);
-    if (rc != HFL_OK) return rc;
-    rc = hfl_linear_x3(g2 + r0 * 8 * C, h2 + r0 * 2 * C, w->fc1_w, w->fc1_b, nullptr, nr, (int)C, (int)(4 * C), 1, stream);
-    if (rc != HFL_OK) return rc;
-    return hfl_linear_x3(io->out + r0 * C, g2 + r0 * 8 * C, w->fc2_w, w->fc2_b, x1 + r0 * C, nr, (int)(4 * C), (int)C, 0, stream);
-  }
+  if (phase < 0 || phase > 4) return HFL_EINVAL;
   // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention)
   if (phase <= 1 && nt > 0) {
     rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
     if (rc != HFL_OK) return rc;
     if (phase == 1) {           // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
       if (w->qkv_pack != nullptr) {
-        rc = qkv_by_rounds(qkv, x0, w, nt, C, 1, stream);
+        rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
       } else {
         rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, nt, C, w->eps, stream);
         if (rc != HFL_OK) return rc;
@@ -252,7 +109,8 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
     // (workspace of the left-over rows' partial sums: behind the twelve units, sized by hfl_block_forward_x3_arena)
-    return mlp_by_rounds(io->out, x1, w, rows, C, a + 12 * unit, mlp_ws_bound(rows, C), phase != 0, stream);
+    return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,
+                               a + 12 * unit, mlp_ws_bound(rows, C), stream);
   rc = hfl_layer_norm_split2(h2, x1, w->norm2_gamma, w->norm2_beta, rows, C, w->eps, stream);
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);

@@ -64,7 +64,6 @@ struct X3Params {
 };
 
 static int g_x3_dbg = 0;
-static int g_x3_ring = 0;   // probe knob 'x3_ring': the NS-stage ring kernel for launches of at most one workgroup per CU.
                             // Off: alone it halves the time of the relay tokens' K = 1024 GEMM, inside the step it loses 3 %
                             // (2361 -> 2442 clouds/s without it): its 128 KB of LDS need a nearly empty CU, the one-stage kernel's
                             // 32 KB slip in beside the finest level's workgroups
@@ -305,116 +304,6 @@ gemm_x3_kernel(const X3Params p) {
   x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
 }
 
-// The same tile on a RING of NS stages for launches that put at most one workgroup on a CU (relay tokens, the coarsest
-// pyramid level: 2 k rows, 15-100 workgroups).  With one stage and nobody co-resident to cover it, every k-step is a full
-// L2 -> LDS round trip (~3.7 us: the relay tokens' fc2, K = 1024, took 120 us for 1.9 k rows); with NS - 1 stages in
-// flight the round trips overlap.  Protocol of csrc/mlp_fused.hip: at the barrier of step kt every wave has left step kt - 1,
-// so that slot takes stage kt + NS - 1; one counted vmcnt per step (this wave's own pieces of the younger stages may stay in
-// flight), fragment reads in inline asm (hipcc would wait vmcnt(0) in front of every LDS read it sees while a DMA is in
-// flight).
-template <int EPI, int NS>
-__global__ void __launch_bounds__(256, 1)
-gemm_x3_ring_kernel(const X3Params p) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];     // NS stages: x tile | w tile each
-  constexpr int MT = 4;
-  constexpr int BM = 32 * MT;
-  constexpr int XTILE_B = BM * 128;
-  constexpr int STAGE_B = XTILE_B + XT * 128;
-  constexpr int DPS = MT + 4;                                                 // DMA instructions per wave and stage
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wm = wave & 1;
-  int64_t wg = blockIdx.x;
-  {
-    const int64_t q = p.n_wg >> 3, r = p.n_wg & 7;
-    const int64_t xcd = wg & 7, loc = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int64_t m0 = (wg / p.tiles_n) * BM;
-  const int n0 = (int)(wg % p.tiles_n) * XT;
-  const int nk = p.K >> 5;
-  const int64_t row_b = (int64_t)p.K * 4;
-  const int64_t m_end = p.M;
-  const int srow = lane >> 3, sslot = lane & 7;
-  const unsigned char* xbase = reinterpret_cast<const unsigned char*>(p.x) + m0 * row_b;
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * row_b;
-  const int rows_valid = (int)((m_end - m0) < BM ? (m_end - m0) : BM);
-  uint32_t xoff[MT], woff[4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int row = wave * (8 * MT) + i * 8 + srow;
-    const int t = sslot ^ ((row >> 1) & 7);
-    const int xr = row < rows_valid ? row : rows_valid - 1;
-    xoff[i] = (uint32_t)xr * (uint32_t)row_b + t * 16;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + srow;
-    woff[i] = (uint32_t)row * (uint32_t)row_b + (sslot ^ ((row >> 1) & 7)) * 16;
-  }
-  auto stage = [&](int kt) {
-    unsigned char* dst = smem + (kt % NS) * STAGE_B;
-    const unsigned char* xk = xbase + (int64_t)kt * 128;
-    const unsigned char* wk = wbase + (int64_t)kt * 128;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xk + xoff[i]),
-                                       (__attribute__((address_space(3))) void*)(dst + (wave * (8 * MT) + i * 8) * 128), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wk + woff[i]),
-                                       (__attribute__((address_space(3))) void*)(dst + XTILE_B + (wave * 32 + i * 8) * 128), 16, 0,
-                                       0);
-  };
-  const int frow = lane & 15, fq = lane >> 4;
-  const int rn0 = wn * 64 + frow, rm0 = wm * (16 * MT) + frow;
-  const int offw_hi = XTILE_B + rn0 * 128 + ((fq ^ ((rn0 >> 1) & 7)) << 4), offw_lo = offw_hi ^ 64;
-  const int offx_hi = rm0 * 128 + ((fq ^ ((rm0 >> 1) & 7)) << 4), offx_lo = offx_hi ^ 64;
-
-  f32x4 acc[4][MT];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) stage(s);
-  const uint32_t sbase = (uint32_t)(uintptr_t)smem;
-#pragma unroll 1
-  for (int kt = 0; kt < nk; ++kt) {
-    // stages issued after stage kt so far: kt + 1 .. kt + NS - 2 (those that exist)
-    const int ahead = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
-    if (NS >= 4 && ahead >= 2) HFL_WAIT_VM(2 * DPS);
-    else if (NS >= 3 && ahead >= 1) HFL_WAIT_VM(DPS);
-    else HFL_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
-    if (kt + NS - 1 < nk) stage(kt + NS - 1);
-    const uint32_t st = sbase + (uint32_t)((kt % NS) * STAGE_B);
-    const uint32_t awh = st + (uint32_t)offw_hi, awl = st + (uint32_t)offw_lo;
-    const uint32_t axh = st + (uint32_t)offx_hi, axl = st + (uint32_t)offx_lo;
-    bf16x8 wh[4], wl[4], xh[MT], xl[MT];
-    HFL_LDS_READ4_FIRST(wh[0], wl[0], wh[1], wl[1], awh, awl, 0, 2048);
-    HFL_LDS_READ4_FIRST(wh[2], wl[2], wh[3], wl[3], awh, awl, 4096, 6144);
-    HFL_LDS_READ4_FIRST(xh[0], xl[0], xh[1], xl[1], axh, axl, 0, 2048);
-    HFL_LDS_READ4_FIRST(xh[2], xl[2], xh[3], xl[3], axh, axl, 4096, 6144);
-    HFL_LDS_WAIT4(wh[0], wl[0], wh[1], wl[1]);
-    HFL_LDS_WAIT4(wh[2], wl[2], wh[3], wl[3]);
-    HFL_LDS_WAIT4(xh[0], xl[0], xh[1], xl[1]);
-    HFL_LDS_WAIT4(xh[2], xl[2], xh[3], xl[3]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], acc[i][j], 0, 0, 0);
-      }
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);      // (the compiler's wait-count pass: vmcnt(0) was waited in the last step)
-  __syncthreads();                         // every wave has left the last stage: the epilogue reuses the LDS
-  x3_epilogue<EPI, MT>(p, acc, smem + wave * 8192, m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
-}
 
 // fp32 (rows, C) [* row_scale[row]] -> split2 (rows, C/32, 2, 32) bf16
 __global__ void __launch_bounds__(256)
@@ -444,8 +333,6 @@ split2_kernel(uint16_t* __restrict__ out, const float* __restrict__ x, const flo
 }  // namespace
 
 extern "C" {
-
-void hfl_internal_set_x3_ring(int v) { g_x3_ring = v == 1 ? 4 : v; }      // stages of the ring kernel (2..4), 0 = off
 
 void hfl_internal_set_x3_dbg(int v) {
   if (v >= 0x200) return;                   // (knobs of removed tile variants)
@@ -544,23 +431,6 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
   const size_t lds = (size_t)(128 + XT) * 128 + (size_t)(g_x3_dbg & 0xFF) * 1024;   // (+ probe: extra KiB to cut occupancy)
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (g_x3_ring >= 2 && tiles == nullptr && row_scale == nullptr && (epi == 0 || epi == 1 || epi == 2) && in_features >= 256 &&
-      p.n_wg <= hfl_stream_cus(s)) {
-#define HFL_X3_RING(E, NSV)                                                                              \
-  {                                                                                                      \
-    const size_t ldsr = (size_t)(NSV) * (128 + XT) * 128;                                                \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_ring_kernel<E, NSV>),       \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);           \
-    if (e != hipSuccess) return (int)e;                                                                  \
-    gemm_x3_ring_kernel<E, NSV><<<(unsigned)p.n_wg, 256, ldsr, s>>>(p);                                  \
-  }
-#define HFL_X3_RING_E(NSV) \
-  if (epi == 2) HFL_X3_RING(2, NSV) else if (epi == 1) HFL_X3_RING(1, NSV) else HFL_X3_RING(0, NSV)
-    if (g_x3_ring == 2) { HFL_X3_RING_E(2) } else if (g_x3_ring == 3) { HFL_X3_RING_E(3) } else { HFL_X3_RING_E(4) }
-#undef HFL_X3_RING_E
-#undef HFL_X3_RING
-    HFL_RETURN_LAST_ERROR();
-  }
 #define HFL_X3_LAUNCH(E, M)                                                                              \
   {                                                                                                      \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x3_kernel<E, M>),              \

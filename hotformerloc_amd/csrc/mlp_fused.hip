@@ -75,10 +75,9 @@ struct MlpFusedParams {
 
 static int g_mlp_stagger = 1;      // probe knob 'mlp_stagger': naps per group step | groups << 8
 static int g_mlp_stagger_groups = 8;
-static int g_mlp_ring_pf = 3;      // probe knob 'ring_pf': stages of the weight stream in flight ahead of the consumed one (2 | 3)
+#ifdef HFL_PROBES
 static int g_mlp_dbg = 0;          // probe knob 'mlp_dbg': timing ablations (see the kernel), 0 = off
-static int g_mlp_lag = 0;          // probe knob 'mlp_lag': the second wave of every SIMD one stage behind the first
-static int g_mlp_waves = 8;        // probe knob 'mlp_waves': waves per workgroup (8: one 16-row tile each at C = 256; 4: two each)
+#endif
 
 // DBG (probe knob 'mlp_dbg', timing ablations only -- results are wrong): 1 GELU -> identity, 2 no bias / GELU / split at all,
 // 4 no refill of the weight ring, 8 no barrier at the stage boundaries
@@ -562,10 +561,9 @@ static int grid_guess(int n_tiles, int cus) { return n_tiles < cus ? n_tiles : c
 
 extern "C" {
 
-void hfl_internal_set_mlp_ring_pf(int v) { g_mlp_ring_pf = v == 2 ? 2 : 3; }
-void hfl_internal_set_mlp_waves(int v) { g_mlp_waves = v == 4 ? 4 : 8; }
-void hfl_internal_set_mlp_lag(int v) { g_mlp_lag = v ? 1 : 0; }
-void hfl_internal_set_mlp_dbg(int v) { g_mlp_dbg = v; }
+#ifdef HFL_PROBES
+void hfl_internal_set_mlp_dbg(int v) { g_mlp_dbg = v; }      // timing ablations (tools/mlp_ablate.py), probe builds only
+#endif
 
 void hfl_internal_set_mlp_stagger(int v) {
   g_mlp_stagger = v & 0xFF;
@@ -600,23 +598,27 @@ struct MlpTailPlan {
 };
 static int g_mlp_tail_split = 1;   // probe knob 'mlp_tail_split'
 static int g_mlp_dynamic = 1;      // probe knob 'mlp_dynamic': work units by atomic ticket (0: static, strided by workgroup)
-static int g_mlp_reserve = 0;      // probe knob 'mlp_reserve': CUs a chip-filling launch leaves to the other streams
 
-// Ticket slots (two counters each, one 128-B line per slot), zero-initialised once; launches take them round-robin and the
-// last workgroup of a launch leaves its slot zeroed, so a slot is clean again long before it comes round (64 launches later).
-constexpr int kTicketSlots = 64;
+// Ticket slots (two counters each, one 128-B line per slot), one table per DEVICE, zero-initialised once; a device's launches
+// take its slots round-robin and the last workgroup of a launch leaves its slot zeroed.  A slot comes round again 256 ticketed
+// launches later on its device; the launches of one forward that take tickets (multi-round row-tile launches) are a few
+// dozen, so two live launches never share a slot unless more than 256 of them are in flight on one device at once.
+constexpr int kTicketSlots = 256;
+constexpr int kTicketDevices = 16;
 unsigned int* hfl_internal_ticket_slot() {
   static std::mutex mu;
-  static unsigned int* base = nullptr;
-  static unsigned int next = 0;
+  static unsigned int* base[kTicketDevices] = {};
+  static unsigned int next[kTicketDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kTicketDevices) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
-  if (base == nullptr) {
+  if (base[dev] == nullptr) {
     unsigned int* b = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&b), (size_t)kTicketSlots * 128) != hipSuccess) return nullptr;
     if (hipMemset(b, 0, (size_t)kTicketSlots * 128) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    base = b;
+    base[dev] = b;
   }
-  return base + (size_t)(next++ % kTicketSlots) * 32;
+  return base[dev] + (size_t)(next[dev]++ % kTicketSlots) * 32;
 }
 static unsigned int* ticket_slot() { return hfl_internal_ticket_slot(); }
 static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus, int hidden) {
@@ -639,7 +641,6 @@ static MlpTailPlan mlp_tail_plan(int64_t n_rows, int channels, int cus, int hidd
 
 extern "C" void hfl_internal_set_mlp_tail_split(int v) { g_mlp_tail_split = v ? 1 : 0; }
 extern "C" void hfl_internal_set_mlp_dynamic(int v) { g_mlp_dynamic = v ? 1 : 0; }
-extern "C" void hfl_internal_set_mlp_reserve(int v) { g_mlp_reserve = v < 0 ? 0 : v; }
 
 static int64_t mlp_tail_bytes(const MlpTailPlan& t, int64_t n_rows, int channels) {
   return t.parts == 0 ? 0 : (int64_t)t.parts * (n_rows - (int64_t)t.tile0 * 16) * channels * 4;
@@ -697,8 +698,6 @@ int hfl_ln_mlp_fused_h(float* out, const float* x, const float* gamma, const flo
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
   // stagger only launches in which a workgroup walks several passes (a single pass has nothing to alternate with)
   int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
-  // (a launch of several rounds: leave g_mlp_reserve CUs unclaimed, see hfl_internal_stream_cus)
-  if (g_mlp_reserve > 0 && cus - g_mlp_reserve >= 64 && p.n_tiles > (int64_t)cus * (channels == 256 ? 8 : 16)) cus -= g_mlp_reserve;
   p.stagger = p.n_tiles > (int64_t)grid_guess(p.n_tiles, cus) * 8 * (channels == 256 ? 1 : 2) ? g_mlp_stagger : 0;
   p.stagger_groups = g_mlp_stagger_groups;
   int grid = p.n_tiles < cus ? p.n_tiles : cus;
@@ -732,6 +731,7 @@ int hfl_ln_mlp_fused_h(float* out, const float* x, const float* gamma, const flo
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     ln_mlp_fused_kernel<256, 1, 3, 8, 0, 0, 256><<<grid, 512, lds, s>>>(p);
+#ifdef HFL_PROBES
   } else if (g_mlp_dbg && channels == 256) {
 #define HFL_MLP_DBG(D)                                                                                          \
   {                                                                                                             \
@@ -748,14 +748,12 @@ int hfl_ln_mlp_fused_h(float* out, const float* x, const float* gamma, const flo
       default: HFL_MLP_DBG(15) break;
     }
 #undef HFL_MLP_DBG
-  } else if (g_mlp_waves == 4) {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 2, 3, 4, 0) else HFL_MLP_LAUNCH(128, 4, 3, 4, 0)
-  } else if (g_mlp_lag) {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2, 8, 1) else HFL_MLP_LAUNCH(128, 2, 2, 8, 1)
-  } else if (g_mlp_ring_pf == 3) {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3, 8, 0) else HFL_MLP_LAUNCH(128, 2, 3, 8, 0)
+#endif
   } else {
-    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 2, 8, 0) else HFL_MLP_LAUNCH(128, 2, 2, 8, 0)
+    // 8 waves (two per SIMD, 256 registers each), three stages of the weight stream ahead of the consumed one: the measured
+    // best of the variants tried in rounds 3-4 (4 waves x 512 registers, two stages ahead, the second wave of a SIMD one stage
+    // late: profiles/r04_waves_probe.log, r04_mlp_lag_probe.log)
+    if (channels == 256) HFL_MLP_LAUNCH(256, 1, 3, 8, 0) else HFL_MLP_LAUNCH(128, 2, 3, 8, 0)
   }
 #undef HFL_MLP_LAUNCH
   if (tp.parts > 0) {

@@ -404,20 +404,11 @@ qkv_pack_kernel(unsigned char* __restrict__ pack, const float* __restrict__ w, i
 
 }  // namespace
 
-static int g_qkv_ring_pf = 3;
-static int g_qkv_waves = 8;       // probe knob 'qkv_waves' (8 | 4)
-static int g_qkv_tail_split = 1;    // probe knob 'qkv_tail_split'
+static int g_qkv_tail_split = 1;    // probe knob 'tail_split'
 
 extern "C" {
 
-void hfl_internal_set_qkv_ring_pf(int v) { g_qkv_ring_pf = v == 2 ? 2 : 3; }
-void hfl_internal_set_qkv_waves(int v) { g_qkv_waves = v == 4 ? 4 : 8; }
 void hfl_internal_set_qkv_tail_split(int v) { g_qkv_tail_split = v ? 1 : 0; }
-// (work units by atomic ticket as in csrc/mlp_fused.hip were tried here too: the unit decode in the pass loop pushed the C = 256
-// instance from 256 VGPRs / no scratch to 14 spilled dwords with reloads behind the stage barriers; the static deal stays)
-void hfl_internal_set_qkv_dynamic(int) {}
-static int g_qkv_reserve = 0;       // probe knob 'qkv_reserve': CUs a chip-filling launch leaves to the other streams
-void hfl_internal_set_qkv_reserve(int v) { g_qkv_reserve = v < 0 ? 0 : v; }
 
 int64_t hfl_qkv_fused_pack_bytes(int channels) {
   if (channels != 128 && channels != 256) return 0;
@@ -445,10 +436,9 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   p.pack = static_cast<const unsigned char*>(pack); p.bias = bias; p.M = n_rows; p.eps = eps; p.q_scale = q_scale;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
   int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
-  if (g_qkv_reserve > 0 && cus - g_qkv_reserve >= 64 && p.n_tiles > (int64_t)cus * (channels == 256 ? 8 : 16)) cus -= g_qkv_reserve;
   int grid = p.n_tiles < cus ? p.n_tiles : cus;
-  // (C = 256 with 8 waves x 2 tiles spills; probe knob 'qkv_waves' = 4: one wave per SIMD with 512 registers, 2 [4] tiles each)
-  const int waves = g_qkv_waves, nt = (channels == 256 ? 1 : 2) * (8 / waves);
+  // (8 waves, two per SIMD; C = 256: one 16-row tile per wave -- two spill; 4 waves x 512 registers lost, profiles/r04_waves_probe.log)
+  const int waves = 8, nt = channels == 256 ? 1 : 2;
   p.stagger = p.n_tiles > (int64_t)grid * waves * nt ? 1 : 0;          // only when a workgroup walks several passes
   p.stagger_groups = 8;
   p.full_passes = 0; p.tail_tile0 = 0; p.tail_sets = 0; p.tail_parts = 0;
@@ -479,13 +469,7 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
     if (e != hipSuccess) return (int)e;                                                                         \
     ln_qkv_fused_kernel<CC, NT, WW, PF><<<grid, WW * 64, lds, s>>>(p);                                          \
   }
-  if (waves == 4) {
-    if (channels == 256) HFL_QKV_LAUNCH(256, 2, 4, 3) else HFL_QKV_LAUNCH(128, 4, 4, 3)
-  } else if (g_qkv_ring_pf == 3) {
-    if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 3) else HFL_QKV_LAUNCH(128, 2, 8, 3)
-  } else {
-    if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 2) else HFL_QKV_LAUNCH(128, 2, 8, 2)
-  }
+  if (channels == 256) HFL_QKV_LAUNCH(256, 1, 8, 3) else HFL_QKV_LAUNCH(128, 2, 8, 3)
 #undef HFL_QKV_LAUNCH
   HFL_RETURN_LAST_ERROR();
 }

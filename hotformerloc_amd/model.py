@@ -100,14 +100,6 @@ _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: 
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
 _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
 _MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
-# CUs of the finest pyramid level's stream during the H-OSA iterations; the coarse levels and the relay-token self-attention
-# share the rest of the chip (CU-masked HIP streams, hfl_stream_create_cu_mask).  0 (default): plain streams, everybody
-# competes for every CU.  Why it exists: on plain streams the finest level's persistent kernels (one workgroup per CU, 135 KB of
-# LDS) and the coarse levels' launches block each other -- a depth-4 fused MLP launch took 410 us beside them against 258 us
-# alone, a depth-3 fc2 GEMM 245 us against 25.  Why it is off: measured, the partition removes the
-# interference but not the work -- on 192 CUs the finest level's kernels take 256/192 of their time alone, the relay-token
-# chain on the shared 64 CUs gets slower and stalls the finest level longer: 940 us per iteration either way.
-_CU_PARTITION = int(os.environ.get('HFL_CU_PARTITION', '0'))
 
 
 def set_train_split(enabled: bool):
@@ -129,32 +121,6 @@ def set_attention_f16(enabled: bool):
 
 
 _SERIAL_STREAMS = False
-
-
-def set_cu_partition(big_cus: int):
-    """CUs given to the finest pyramid level's stream inside the H-OSA iterations (multiple of 8; 0 = no partition)."""
-    global _CU_PARTITION
-    assert big_cus == 0 or (big_cus % 8 == 0 and 8 <= big_cus)
-    _CU_PARTITION = int(big_cus)
-
-
-_MASKED_STREAMS = {}     # (device index, first bit, bits, tag) -> torch.cuda.ExternalStream over a CU-masked HIP stream
-
-
-def _masked_stream(device, first_bit: int, n_bits: int, tag: str):
-    import ctypes
-    from . import _native
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (idx, first_bit, n_bits, tag)
-    st = _MASKED_STREAMS.get(key)
-    if st is None:
-        with torch.cuda.device(idx):
-            h = ctypes.c_void_p()
-            ops.check(_native.load().hfl_stream_create_cu_mask(ctypes.byref(h), first_bit, n_bits), 'hfl_stream_create_cu_mask')
-            st = torch.cuda.ExternalStream(h.value, device=torch.device('cuda', idx))
-        _MASKED_STREAMS[key] = st
-    return st
 
 
 def set_pyramid_streams(enabled):
@@ -242,38 +208,9 @@ _ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
 # attentional pooling of the head as one launch per level (csrc/attn_pool.hip) instead of GEMM + segment softmax + two
 # padding copies + batched GEMM
 _ATTN_POOL = os.environ.get('HFL_ATTN_POOL', '1') != '0'
-# H-OSA iterations, relay rows first: after the window attention every level runs proj + MLP of its RELAY rows (2 % of the
-# rows, three small launches) before those of its token rows, so that the next iteration's relay-token self-attention -- which
-# needs nothing else -- starts beside the token rows' proj / MLP instead of after the slowest level's.  Why: the kernel trace
-# of the step shows the iteration's cycle is [coarse levels' MLP launches, starved while the finest level's fused MLP holds
-# every CU] -> [relay-token self-attention, 8 launches] -> [finest level: relay qkv, attention, proj, MLP]; the finest
-# level's own CPE + qkv ride beside it for free.  Relay-first takes the first two links out of the cycle -- and measured, it
-# does not pay: 2505-2531 clouds/s with the relay tails on the levels' own streams, 2608-2617 with them on the RTSA stream,
-# against 2619-2690 without (same box, alternating runs): twelve more small launches per iteration compete with the finest
-# level's persistent kernels for the CUs the cycle's links were waiting on anyway.  Off by default.
-_RELAY_FIRST = os.environ.get('HFL_RELAY_FIRST', '0') != '0'
 # join every pyramid stream at the end of every H-OSA iteration (the schedule of rounds 2-3); 0: only the true dependencies
 _ITER_JOIN = os.environ.get('HFL_ITER_JOIN', '0') != '0'
 _PLAN_LATE = os.environ.get('HFL_PLAN_LATE', '1') != '0'           # window plan built after the stem has been issued
-# dependencies between the pyramid streams and the relay-token stream through device flags (hfl_flag_set / hfl_flag_wait)
-# instead of events: 3.4 us of GPU time per link against 13.7 (tools/hop_latency.py)
-_FLAG_HOPS = os.environ.get('HFL_FLAG_HOPS', '0') != '0'
-_HOP_FLAGS = {}
-_HOP_SEQ = [0]
-
-
-def _hop_flags(device):
-    """Device words of the flag hops (one 128-B line each), per device, zero-initialised once."""
-    key = (device.type, device.index)
-    t = _HOP_FLAGS.get(key)
-    if t is None:
-        t = _HOP_FLAGS[key] = torch.zeros(8 * 32, dtype=torch.int32, device=device)
-    return [t[32 * k:32 * k + 1] for k in range(8)]
-
-
-def _hop_next() -> int:
-    _HOP_SEQ[0] += 1
-    return _HOP_SEQ[0]
 # relay-token self-attention on a stream of its own (1) or on the finest level's, behind that level's CPE / LN1 / qkv (0)
 _RTSA_STREAM = os.environ.get('HFL_RTSA_STREAM', '1') != '0'
 _QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
@@ -388,9 +325,16 @@ def _checkpoint_block(blk, *args):
     snap = [(m, m._factors) for m in mods]
 
     def run(*a):
+        # the saved draws are visible during the block call only: the recomputation in the backward must not leave the previous
+        # step's factors armed on the modules (a submodule called on its own afterwards draws fresh ones)
+        prev = [(m, m._factors, m._calls) for m, _ in snap]
         for m, f in snap:
             m._factors, m._calls = f, 0
-        return blk(*a)
+        try:
+            return blk(*a)
+        finally:
+            for m, f, c in prev:
+                m._factors, m._calls = f, c
     return checkpoint(run, *args, use_reentrant=False)
 
 
@@ -614,8 +558,9 @@ class OctreeConvNormRelu(nn.Module):
         y = self.conv(data, octree, depth)
         if y.is_cuda and not _grad_path(y) and y.shape[-1] in ops._LN_CHANNELS:
             return ops.layer_norm_relu(y, self.norm.weight, self.norm.bias, self.norm.eps, split2=split2_out)
-        assert not split2_out
-        return F.relu_(_ln(y, self.norm))
+        y = F.relu_(_ln(y, self.norm))
+        # (a width the fused norm + ReLU kernel is not instantiated for, e.g. 192 of dim = 384: the split as its own pass)
+        return ops.split2(y) if split2_out else y
 
 
 class PatchEmbed(nn.Module):
@@ -913,12 +858,12 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     w.qkv_pack = None if qpack is None else qpack.data_ptr()
     w.fuse_attention = 1 if _ATTN_FUSED else 0
     pack = _mlp_pack(mlp, rows)
-    if pack is not None and not _RELAY_FIRST:
+    if pack is not None:
         w.mlp_pack, w.fc1_w, w.fc2_w = pack.data_ptr(), None, None
-    else:               # (the relay rows' tail of the relay-first schedule runs the two GEMM launches also beside a pack)
+    else:
         if keep[2] is None:
             keep[2], keep[3] = _w2(mlp.fc1), _w2(mlp.fc2)
-        w.mlp_pack, w.fc1_w, w.fc2_w = (None if pack is None else pack.data_ptr()), keep[2].data_ptr(), keep[3].data_ptr()
+        w.mlp_pack, w.fc1_w, w.fc2_w = None, keep[2].data_ptr(), keep[3].data_ptr()
     desc = WindowAttnDesc(n_tokens=nt, rt_row0=nt, n_windows=plan.n_windows[depth], patch_size=att.patch_size,
                           dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
                           batch_size=plan.B, scale=16 ** -0.5, depth=depth,
@@ -1242,18 +1187,6 @@ class HOTFormerStage(nn.Module):
             self._streams = [torch.cuda.Stream(device=device) for _ in range(self.num_pyramid_levels - 1)]
         return self._streams
 
-    def _partition(self, device):
-        """(finest level's stream, coarse levels' streams, RTSA stream) over disjoint CU masks, or None when the partition
-        is off / does not fit this device."""
-        big = _CU_PARTITION
-        total = torch.cuda.get_device_properties(device).multi_processor_count
-        if big <= 0 or big + 8 > total:
-            return None
-        rest = total - big
-        return (_masked_stream(device, 0, big, 'big'),
-                [_masked_stream(device, big, rest, 'side%d' % j) for j in range(self.num_pyramid_levels - 1)],
-                _masked_stream(device, big, rest, 'rtsa'))
-
     def _rtsa_stream(self, device):
         if self.__dict__.get('_rtsa_st') is None:
             # high priority: RTSA is a chain of eight tiny launches that must slip in between the chip-filling kernels of the
@@ -1304,123 +1237,9 @@ class HOTFormerStage(nn.Module):
             return out, (self.up_projections[j][i](out[nt:]) if proj else out[nt:])
 
         early = _EARLY_PHASE and _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda and not ckpt
-        # CU partition: the whole loop runs with the finest level's CU-masked stream as the "main" one (forked from the caller's
-        # stream here, joined after the last iteration); the coarse levels and RTSA get streams over the other CUs.
-        part = self._partition(data.device) if (early and not _SERIAL_STREAMS) else None
-        caller = torch.cuda.current_stream() if part is not None else None
-        if part is not None:
-            part[0].wait_stream(caller)
-        with (torch.cuda.stream(part[0]) if part is not None else contextlib.nullcontext()):
-            local, rts = self._iterations(data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa, part)
-        if part is not None:
-            caller.wait_stream(part[0])
-            for t in list(local.values()) + list(rts.values()):        # allocated on the masked stream, consumed by the caller's
-                t.record_stream(caller)
-        return local, rts
+        return self._iterations(data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa)
 
-    def _iterations_relay_first(self, data, plan, depths, bufs, rts, nts, proj, part):
-        """The early-phase schedule with the relay rows' block tail first (see _RELAY_FIRST); returns None when a block of
-        the first iteration is not eligible for the native executor (the caller then runs the plain early schedule)."""
-        main = torch.cuda.current_stream()
-        side = part[1] if part else self._side_streams(data.device)
-        rs = part[2] if part else self._rtsa_stream(data.device)
-        small = [not (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) for j, d in enumerate(depths)]
-        sts = [side[j - 1] if small[j] else main for j in range(len(depths))]
-        order = sorted(range(len(depths)), key=lambda j: -bufs[depths[j]].shape[0])
-        nlev = len(depths)
-
-        def rtsa(i, ready):
-            """RTSA of iteration i on its stream, behind the events `ready`; returns (rows of all levels, event)"""
-            for ev in ready:
-                rs.wait_event(ev)
-            with torch.cuda.stream(rs):
-                out = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
-                return out, rs.record_event()
-
-        rt_all, ev_rt = rtsa(0, [main.record_event()])
-        keep = []                                                        # buffers other streams still read: until the join
-        for i in range(self.num_blocks):
-            ev0 = main.record_event()
-            calls = {}
-            for j in order:                                              # (prepared first: nothing is issued if a block is not eligible)
-                with torch.cuda.stream(sts[j]):
-                    calls[depths[j]] = _native_block_call(self.hosa_blocks[j][i], bufs[depths[j]], plan, depths[j])
-            if any(c is None for c in calls.values()):
-                if i == 0:
-                    main.wait_stream(rs)                                 # (RTSA 0 is simply recomputed by the plain schedule)
-                    return None
-                raise RuntimeError('relay-first schedule: a block of iteration %d lost its native call' % i)
-            for j in order:                                              # token rows: CPE, LN1, qkv (finest level first)
-                d = depths[j]
-                if sts[j] is not main and (i == 0 or _ITER_JOIN):          # (later iterations: the level's own stream order)
-                    sts[j].wait_event(ev0)
-                with torch.cuda.stream(sts[j]):
-                    calls[d].run(1)
-            fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
-            keep.append((dict(bufs), dict(rts), rt_all, fresh))
-            group = [j for j in order if small[j]] if _MERGED_ATTN else []
-            if len(group) < 2:
-                group = []
-            for j in order:                                              # relay rows in, their LN1 / qkv
-                d = depths[j]
-                sts[j].wait_event(ev_rt)
-                with torch.cuda.stream(sts[j]):
-                    calls[d].run(3, self.down_projections[j][i](fresh[d]) if proj else fresh[d])
-            for j in order:                                              # window attention (the small levels in one launch)
-                if j in group:
-                    continue
-                with torch.cuda.stream(sts[j]):
-                    ops.block_attention_multi([calls[depths[j]]])
-            if group:
-                lead = sts[group[0]]
-                for j in group[1:]:
-                    lead.wait_event(sts[j].record_event())
-                with torch.cuda.stream(lead):
-                    ops.block_attention_multi([calls[depths[j]] for j in group])
-                    ev_att = lead.record_event()
-                for j in group:
-                    if sts[j] is not lead:
-                        sts[j].wait_event(ev_att)
-            # the relay rows' proj + MLP of every level go to the RTSA stream (they feed nothing else), the token rows' follow on
-            # the level's own stream at once: the two touch disjoint rows of the block's buffers
-            for j in order:
-                rs.wait_event(sts[j].record_event())
-            with torch.cuda.stream(rs):
-                for j in order:
-                    d = depths[j]
-                    out = calls[d].run(5)
-                    rts[d] = self.up_projections[j][i](out[nts[j]:]) if proj else out[nts[j]:]
-            if i + 1 < self.num_blocks:                                  # ... the next RTSA starts behind them ...
-                rt_all, ev_rt = rtsa(i + 1, [])
-            else:
-                ev_last = rs.record_event()
-            for j in order:                                              # ... beside the token rows' proj + MLP
-                with torch.cuda.stream(sts[j]):
-                    bufs[depths[j]] = calls[depths[j]].run(6)
-            for j in order:                                              # (relay-token propagation reads the relay rows too)
-                d = depths[j]
-                if self.hosa_blocks[j][i].propagate:
-                    sts[j].wait_event(ev_last if i + 1 == self.num_blocks else ev_rt)
-                    with torch.cuda.stream(sts[j]):
-                        bufs[d] = self.hosa_blocks[j][i]._tail(bufs[d], plan, d)
-                        rts[d] = self.up_projections[j][i](bufs[d][nts[j]:]) if proj else bufs[d][nts[j]:]
-            keep.append(calls)
-            if _ITER_JOIN or i + 1 == self.num_blocks:
-                for j in range(nlev):
-                    if sts[j] is not main:
-                        main.wait_stream(sts[j])
-            if i + 1 == self.num_blocks:
-                main.wait_stream(rs)
-            # (three iterations' worth: a level stream may run a whole iteration behind the RTSA stream that reads its rows)
-            keep = keep if i == 0 else keep[-6:]
-        del keep
-        return {d: bufs[d][:nt] for d, nt in zip(depths, nts)}, rts
-
-    def _iterations(self, data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa, part):
-        if early and _RELAY_FIRST and not _SERIAL_STREAMS and _NATIVE_BLOCK:
-            res = self._iterations_relay_first(data, plan, depths, bufs, rts, nts, proj, part)
-            if res is not None:
-                return res
+    def _iterations(self, data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa):
         done = None          # early schedule: per-level end-of-iteration events of the previous iteration
         first = None         # ... and the buffers the schedule started from (allocated on the main stream, read by the others)
         for i in range(self.num_blocks):                                # 593-633
@@ -1430,8 +1249,8 @@ class HOTFormerStage(nn.Module):
                 # part on its own stream first, RTSA runs beside it on a stream of its own, the rest of the block follows
                 # once both are done -- the ~120 us chain of eight tiny RTSA launches leaves the critical path.
                 main = torch.cuda.current_stream()
-                side = [main] * (len(depths) - 1) if _SERIAL_STREAMS else (part[1] if part else self._side_streams(data.device))
-                rs = main if (_SERIAL_STREAMS or not _RTSA_STREAM) else (part[2] if part else self._rtsa_stream(data.device))
+                side = [main] * (len(depths) - 1) if _SERIAL_STREAMS else self._side_streams(data.device)
+                rs = main if (_SERIAL_STREAMS or not _RTSA_STREAM) else self._rtsa_stream(data.device)
                 small = [not (j == 0 or bufs[d].shape[0] > _SIDE_STREAM_MAX_ROWS) for j, d in enumerate(depths)]
                 sts = [side[j - 1] if small[j] else main for j in range(len(depths))]
                 # issue order = critical path first (the host runs only just ahead of the GPU here): the finest level's
@@ -1459,21 +1278,14 @@ class HOTFormerStage(nn.Module):
                             calls[d].run(1)
 
                 phase1(order[0])
-                flags = _hop_flags(data.device) if (_FLAG_HOPS and not _SERIAL_STREAMS and rs is not main) else None
                 if join:
                     rs.wait_event(ev0)
-                elif flags is not None:
-                    for fl, val in done:                   # (device-flag hops: ~3 us per link against ~14 for an event)
-                        ops.flag_wait(fl, val, rs)
                 else:
                     for ev in done:
                         rs.wait_event(ev)
                 with torch.cuda.stream(rs):
                     rt_all = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
                     ev_rt = rs.record_event()
-                    if flags is not None:
-                        rt_flag = (flags[0], _hop_next())
-                        ops.flag_set(rt_flag[0], rt_flag[1], rs)
                 for j in order[1:]:
                     phase1(j)
                 fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
@@ -1492,10 +1304,7 @@ class HOTFormerStage(nn.Module):
 
                 for j in order:
                     d = depths[j]
-                    if flags is not None:
-                        ops.flag_wait(rt_flag[0], rt_flag[1], sts[j])
-                    else:
-                        sts[j].wait_event(ev_rt)
+                    sts[j].wait_event(ev_rt)
                     with torch.cuda.stream(sts[j]):
                         if j in group:
                             calls[d].run(3, relay_in(j))                      # relay rows in, their LN1 / qkv
@@ -1523,12 +1332,6 @@ class HOTFormerStage(nn.Module):
                     for j in range(len(depths)):
                         if sts[j] is not main:
                             main.wait_stream(sts[j])
-                elif flags is not None:
-                    done = []
-                    for n, st in enumerate(dict.fromkeys(sts)):
-                        val = _hop_next()
-                        ops.flag_set(flags[1 + n], val, st)
-                        done.append((flags[1 + n], val))
                 else:
                     done = [st.record_event() for st in dict.fromkeys(sts)]
                 del calls, old, fresh, rt_all

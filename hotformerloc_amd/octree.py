@@ -71,19 +71,6 @@ def _split_ranges(edges: np.ndarray, step: int):
     return rid, first, np.minimum(step, edges[rid + 1] - first)
 
 
-_TAP_STREAMS = {}
-_TAP_STREAM = __import__('os').environ.get('HFL_TAP_STREAM', '0') != '0'
-
-
-def _tap_stream(device):
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _TAP_STREAMS.get(idx)
-    if st is None:
-        st = _TAP_STREAMS[idx] = torch.cuda.Stream(device=torch.device('cuda', idx), priority=-1)
-    return st
-
-
 class Octree:
     def __init__(self, depth: int, full_depth: int = 2, batch_size: int = 1,
                  device: Union[torch.device, str] = 'cpu', **kwargs):
@@ -337,16 +324,12 @@ class Octree:
         if pending:
             self._finish_tap_lists()
         # The lists depend on the neighbour tables only, and the host needs their per-tap counts (one read) before it can size
-        # the convolutions' buffers.  On the caller's stream the kernels queue behind whatever the GPU is still running (the
-        # previous forward's tail): the host waits for all of it, then issues the next forward into an idle GPU (~0.8 ms of
-        # launch-latency gaps at the start of a step).  HFL_TAP_STREAM=1 puts them on a high-priority stream of their own
-        # (ordered behind the tables by an event): the counts then arrive while the GPU is still busy and the host never falls
-        # behind (issue time 9 ms per step instead of 13) -- and the step got SLOWER, 19 ms against 13: with the host a whole
-        # forward ahead every stream's queue is full, the coarse levels' and relay tokens' launches start as early as their
-        # dependencies allow and crowd the finest level's chain, whose launch order the just-ahead host had been enforcing for
-        # free.  Off by default (round 4 measurement).
+        # the convolutions' buffers.  They run on the caller's stream, behind whatever the GPU is still running.  (On a
+        # high-priority stream of their own the counts arrive earlier and the host runs a whole forward ahead -- and the step got
+        # slower, 19 ms against 13: the just-ahead host had been enforcing the intended launch order of the H-OSA iterations for
+        # free.  Round 4, profiles/r04_x_ab_tap_stream_resident.log.)
         cur = torch.cuda.current_stream(self.device)
-        st = _tap_stream(self.device) if _TAP_STREAM else cur
+        st = cur
         nev = self.__dict__.get('_neigh_event')
         if nev is not None:
             st.wait_event(nev)

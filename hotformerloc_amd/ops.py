@@ -382,6 +382,8 @@ def layer_norm_relu(x, weight, bias, eps: float = 1e-5, split2: bool = False):
         out = torch.empty((x2.shape[0], 2 * c), dtype=torch.bfloat16, device=x.device)
     else:
         out = torch.empty_like(x2)
+    if x2.shape[0] == 0:
+        return out
     with _timed('hfl_layer_norm_relu', x2.numel() * 8):
         check(_native.load().hfl_layer_norm_relu(None if split2 else out.data_ptr(), out.data_ptr() if split2 else None,
                                                  x2.data_ptr(), weight.data_ptr(), bias.data_ptr(), x2.shape[0], c,
@@ -880,18 +882,6 @@ def mixer_tail(x: torch.Tensor, channel_w, channel_b, row_w, row_b):
                                         _f32c(row_w).data_ptr(), _f32c(row_b).data_ptr(), b, k, c, ko, d, _stream()),
           'hfl_mixer_tail')
     return out
-
-
-def flag_set(flag: torch.Tensor, value: int, stream):
-    """Queue `*flag = value` (release) behind the work already in `stream` (hfl_flag_set)."""
-    check(_native.load().hfl_flag_set(flag.data_ptr(), int(value) & 0xffffffff, ctypes.c_void_p(stream.cuda_stream)),
-          'hfl_flag_set')
-
-
-def flag_wait(flag: torch.Tensor, value: int, stream, max_polls: int = 1 << 17):
-    """Queue a one-lane poll of `*flag >= value` (acquire, bounded) in front of what follows in `stream` (hfl_flag_wait)."""
-    check(_native.load().hfl_flag_wait(flag.data_ptr(), int(value) & 0xffffffff, int(max_polls),
-                                       ctypes.c_void_p(stream.cuda_stream)), 'hfl_flag_wait')
 
 
 def attn_pool_ok(channels: int) -> bool:

@@ -28,21 +28,6 @@ extern "C" {
 
 typedef void* hfl_stream_t; /* hipStream_t */
 
-/* CU-partitioned streams (no reference counterpart: the reference runs its three pyramid depths on plain CUDA streams,
- * models/hotformerloc_backbone.py:28-53,604-633).  hfl_stream_create_cu_mask makes a HIP stream restricted to the CUs of mask
- * bits [first_bit, first_bit + n_bits) (both multiples of 8: n_bits / 8 CUs of every XCD); every launcher of this library
- * sizes its persistent grids by the CU count of the stream it is given.  Used to run the finest pyramid level's chip-filling
- * kernels and the coarse levels' / relay tokens' latency-bound launches side by side without competing for CUs. */
-int hfl_stream_create_cu_mask(hfl_stream_t* out, int first_bit, int n_bits);
-int hfl_stream_destroy(hfl_stream_t stream);
-/* Ordering between two streams through a device word instead of an event: hfl_flag_set queues a store of `value` to *flag
- * (release) behind the work already in `stream`; hfl_flag_wait queues a one-lane kernel that polls *flag until it is >= value
- * (acquire; at most max_polls polls of ~0.5 us, then it gives up and lets the stream go on) in front of the work that follows
- * in its stream.  flag: 4 bytes of device memory, zero-initialised by the caller, values increasing.  (What the reference does
- * with torch.cuda streams and `wait_stream`, models/hotformerloc_backbone.py:604-633, where the hop has to be short.) */
-int hfl_flag_set(unsigned int* flag, unsigned int value, hfl_stream_t stream);
-int hfl_flag_wait(const unsigned int* flag, unsigned int value, int max_polls, hfl_stream_t stream);
-
 #define HFL_OK 0
 #define HFL_EINVAL (-1)      /* unsupported shape / argument            */
 #define HFL_ECAPACITY (-2)   /* input exceeds a documented kernel limit */
@@ -297,12 +282,13 @@ int hfl_gemm_bf16(float* out, const uint16_t* a, const uint16_t* w, const float*
 int hfl_gemm_bf16_tn(float* out, const uint16_t* a, const uint16_t* b, int64_t n_rows_stacked, int n_out,
                      int k_out, hfl_stream_t stream);
 
-/* Tuning / A-B hook: select a kernel variant at run time.  Keys: "window_attention" (4 = default two-lookup
- * kernel, 2 = three-lookup kernel, also the fallback for depth > 5 or |delta| > pos_bnd, 1 = first version),
- * "window_heads_per_wg" (waves per workgroup, default 4), "window_v4_wgs_per_cu" / "window_v2_wgs_per_cu"
- * (persistent-grid multipliers), "window_debug" (ablation bits of tools/kbench.py), "cpe_variant" (0 = direct
- * gathers, default; 1 = LDS-staged de-duplicated gathers), "cpe_lds_wgs_per_cu", "cpe_chunk_rows",
- * "linear_ablate".  Returns HFL_EINVAL for an unknown key. */
+/* Test / measurement hook: select a kernel variant at run time; "reset" restores every default.  Keys kept in the product
+ * build: "window_attention" (4 = default, 2 = three-lookup fp32 kernel), "window_rpe_form1_max_depth" (table form of the fp16
+ * kernel), "window_bwd", "window_heads_per_wg", "window_v4_wgs_per_cu" / "window_v2_wgs_per_cu", "window_debug",
+ * "tail_split" / "dynamic_units" / "mlp_stagger" (left-over rows, work tickets and start stagger of the row-tile kernels),
+ * "attn_fused_split", "cpe_variant", "cpe_chunk_rows", "x3_dbg".  The variants that lost their A/B measurements in rounds
+ * 2-4 (per-round launches, relay rows first, CU-masked streams, device-flag hops, the x3 ring kernel, 4-wave row tiles) are
+ * gone from the library; their logs are under profiles/.  Returns HFL_EINVAL for an unknown key. */
 int hfl_set_variant(const char* key, int value);
 
 /* ------------------------------------------------------------------------
@@ -580,9 +566,6 @@ typedef struct hfl_block_io {
                                                           MLP.  3 + 4 split phase 2 around the attention: 3 = relay rows in and
                                                           their LN1 / qkv, 4 = proj and MLP; between them the caller runs the
                                                           attention of this and other blocks with hfl_block_attention_x3_multi.
-                                                          5 + 6 split phase 4 by rows: 5 = proj and MLP of the RELAY rows (needs
-                                                          fc1_w / fc2_w also when mlp_pack is set), 6 = of the token rows; after
-                                                          5 the next iteration's relay-token self-attention has its input.
                                                           All phases of a block share `arena`. */
 } hfl_block_io;
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels);

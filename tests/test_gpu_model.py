@@ -437,75 +437,6 @@ def test_early_phase_schedule_equals_the_sequential_one():
 
 
 @pytest.mark.gpu
-def test_relay_first_schedule_gives_the_same_descriptors():
-    """H-OSA iterations with the relay rows' proj + MLP issued before the token rows' (hfl_block_io.phase 5 / 6), so that the
-    next iteration's relay-token self-attention starts beside the token rows' tail: the same per-row operators on the same
-    rows in another order.  Bitwise equal while every MLP is the three-launch form (small batch); with the fused MLP launch on
-    the finest level (large batch) the relay rows take the three-launch form and the token rows' left-over split changes its
-    summation order, so descriptors agree to fp32 rounding.  Also with relay-token propagation, and run to run."""
-    from hotformerloc_amd import model as M
-    params, depth = load_config('wild-places')
-    for n_clouds, prop, tol in ((4, False, 0.0), (4, True, 0.0), (13, False, 2e-5)):
-        params.ct_propagation = prop
-        model = model_factory(params)
-        syn.fill_synthetic_weights(model, 'stress')
-        model = model.cuda().eval()
-        octree = build_batch_octree(syn.make_clouds(61, n_clouds, 4096 if n_clouds > 4 else 2500, params.coordinates), depth, 2,
-                                    'cuda')
-        out = {}
-        saved = M._RELAY_FIRST
-        try:
-            for rf in (True, False, True):
-                M._RELAY_FIRST = rf
-                with torch.no_grad():
-                    y = model({'octree': octree})['global']
-                torch.cuda.synchronize()
-                if rf in out:
-                    assert torch.equal(out[rf], y)
-                out[rf] = y
-        finally:
-            M._RELAY_FIRST = saved
-        if tol == 0.0:
-            assert torch.equal(out[True], out[False]), (n_clouds, prop)
-        else:
-            rel = ((out[True] - out[False]).norm(dim=1) / out[False].norm(dim=1)).max().item()
-            assert rel < tol, (n_clouds, rel)
-    params.ct_propagation = False
-
-
-@pytest.mark.gpu
-def test_cu_partitioned_streams_give_the_same_descriptors():
-    """H-OSA iterations with the finest pyramid level on a CU-masked stream (192 CUs) and the coarse levels + RTSA on the
-    other 64 (hfl_stream_create_cu_mask; an option, off by default) against plain streams: same kernels on the same rows; the
-    only arithmetic that depends on the CU count is the summation order of the fused MLP's left-over rows (hidden dimension
-    split over the workgroups of the stream's CUs), so descriptors agree to fp32 rounding, each configuration is deterministic
-    run to run, and a 64 / 192 split the other way round works too."""
-    from hotformerloc_amd import model as M
-    params, depth = load_config('wild-places')
-    model = model_factory(params)
-    syn.fill_synthetic_weights(model, 'stress')
-    model = model.cuda().eval()
-    octree = build_batch_octree(syn.make_clouds(41, 12, 4096, params.coordinates), depth, 2, 'cuda')
-    out = {}
-    saved = M._CU_PARTITION
-    try:
-        for part in (192, 0, 192, 64, 0):
-            M.set_cu_partition(part)
-            with torch.no_grad():
-                y = model({'octree': octree})['global']
-            torch.cuda.synchronize()
-            assert torch.isfinite(y).all()
-            if part in out:
-                assert torch.equal(out[part], y)                    # run to run
-            out[part] = y
-    finally:
-        M.set_cu_partition(saved)
-    for part in (192, 64):
-        rel = ((out[part] - out[0]).norm(dim=1) / out[0].norm(dim=1)).max().item()
-        assert rel < 2e-5, (part, rel)
-
-
-@pytest.mark.gpu
 def test_merged_window_attention_launch_equals_one_launch_per_level():
     """The window attention of an H-OSA iteration's three pyramid levels as ONE launch (hfl_block_attention_x3_multi between
     block phases 3 and 4) against one launch per level: the same windows through the same kernel, bitwise equal descriptors;

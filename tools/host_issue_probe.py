@@ -1,5 +1,7 @@
 """How long does the host take to ISSUE one forward (no synchronisation) vs how long the GPU takes to run it?"""
-import os, sys, time
+import faulthandler, functools, os, sys, time
+faulthandler.enable()
+print = functools.partial(print, flush=True)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hotformerloc_amd import build_batch_octree, load_config, model_factory, synthetic as syn
