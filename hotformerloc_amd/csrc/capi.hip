@@ -92,7 +92,11 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (phase != 4 && !fused_attn && !relay_fused) {
     // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phases 2, 3)
     const int64_t r0 = phase != 0 ? nt : 0, nr = rows - r0;
-    if (nr > 0) {
+    if (nr > 0 && w->qkv_pack != nullptr) {      // (the same launch the phased schedule uses: bitwise the same rows)
+      rc = hfl_ln_qkv_fused(qkv + r0 * 3 * C, x0 + r0 * C, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale,
+                            nr, (int)C, stream);
+      if (rc != HFL_OK) return rc;
+    } else if (nr > 0) {
       rc = hfl_layer_norm_split2(a2 + r0 * 2 * C, x0 + r0 * C, w->norm1_gamma, w->norm1_beta, nr, C, w->eps, stream);
       if (rc != HFL_OK) return rc;
       rc = hfl_linear_x3_qkv(qkv + r0 * 3 * C, a2 + r0 * 2 * C, w->qkv_w, w->qkv_b, nr, (int)C, (int)(3 * C), w->q_scale,

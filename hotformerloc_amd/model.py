@@ -164,10 +164,12 @@ def _w2(lin: nn.Linear):
     return hit[2]
 
 
-# LN2 -> fc1 -> GELU -> fc2 -> residual as ONE launch (csrc/mlp_fused.hip) from this many rows on: below it the launch cannot
-# fill the chip with its 128 / 256-row workgroup passes and the three-launch form is as fast (tools/mlp_fused_probe.py)
+# LN2 -> fc1 -> GELU -> fc2 -> residual as ONE launch (csrc/mlp_fused.hip) from this many rows on.  (Rounds 3-4: 24 576 -- below
+# that the three-launch form is as fast ALONE.  In the step the coarse pyramid levels' chains are launch-bound: with them on the
+# fused launches too -- hidden / feature dimension split over the chip -- three alternating runs gave 2952-2975 clouds/s against
+# 2914-2947, profiles/r05_g_ab.log.)
 _MLP_FUSED = os.environ.get('HFL_MLP_FUSED', '1') != '0'
-_MLP_FUSED_MIN_ROWS = int(os.environ.get('HFL_MLP_FUSED_MIN_ROWS', '24576'))
+_MLP_FUSED_MIN_ROWS = int(os.environ.get('HFL_MLP_FUSED_MIN_ROWS', '1000'))
 
 
 def _mlp_pack(mlp: 'MLP', rows: int):
@@ -196,7 +198,7 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 # the output features split over the workgroups (round 4) that shape takes 101 us and the restriction is gone
 # (HFL_QKV_FUSED_MIN_FILL restores it).
 _QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
-_QKV_FUSED_MIN_ROWS = int(os.environ.get('HFL_QKV_FUSED_MIN_ROWS', '24576'))
+_QKV_FUSED_MIN_ROWS = int(os.environ.get('HFL_QKV_FUSED_MIN_ROWS', '1000'))
 _RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
 # relay-token block: LN1 -> qkv as ONE launch (csrc/qkv_fused.hip, output features split over the chip for the ~2 k rows) and
 # the ragged attention reading its fp16 (hi, lo) rows and writing attention.proj's split2 operand itself

@@ -6,10 +6,32 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from hotformerloc_amd import build_batch_octree, load_config, ops, synthetic as syn  # noqa: E402
 from hotformerloc_amd import _native  # noqa: E402
 from hotformerloc_amd.plan import WindowPlan  # noqa: E402
+import ctypes  # noqa: E402
+from hotformerloc_amd._native import WindowAttnDesc, check  # noqa: E402
+
+
+def attn_fused_rt(x, gamma, beta, eps, qkv_pack, qkv_bias, q_scale, relay_qkv, tok_meta, rpe_table, n_tokens, n_windows, patch_size,
+                  n_heads, batch_size, depth, out=None):
+    """ctypes wrapper of hfl_attn_fused_rt_fwd (the experiment's entry point: build the library with attn_fused_rt.hip added)."""
+    lib = _native.load()
+    fn = lib.hfl_attn_fused_rt_fwd
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_float] + [ctypes.c_void_p] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 5
+    c = x.shape[1]
+    if out is None:
+        out = torch.zeros((n_tokens + n_windows, 2 * c), dtype=torch.bfloat16, device=x.device)
+    bnd = int(0.8 * patch_size)
+    desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=n_tokens, n_windows=n_windows, patch_size=patch_size, dilation=1, n_relay=1,
+                          n_heads=n_heads, pos_bnd=bnd, batch_size=batch_size, scale=16 ** -0.5, depth=depth)
+    tables = None if rpe_table is None else ops.rpe_expand(rpe_table, n_heads, bnd, depth, 2)
+    check(fn(out.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), qkv_pack.data_ptr(), qkv_bias.data_ptr(),
+             float(q_scale), relay_qkv.data_ptr(), tok_meta.data_ptr(), None if tables is None else tables.data_ptr(),
+             ctypes.byref(desc), ops._stream()), 'hfl_attn_fused_rt_fwd')
+    return out
 
 
 def timeit(fn, n=20):
@@ -56,7 +78,7 @@ def main(cfg):
             return ops.ln_qkv_fused(x[nt:], gamma, beta, 1e-5, pack, b, qs, out=qkv_all[nt:])
 
         def one():
-            return ops.attn_fused_rt(x[:nt], gamma, beta, 1e-5, pack, b, qs, qkv_all[nt:], plan.meta[d], table, nt, W, K, H,
+            return attn_fused_rt(x[:nt], gamma, beta, 1e-5, pack, b, qs, qkv_all[nt:], plan.meta[d], table, nt, W, K, H,
                                      plan.B, d, out=out)
         # (the expanded table is cached per table tensor and consumer: the three-table form of the comparison gets its own copy)
         lib.hfl_set_variant(b'window_rpe_form1_max_depth', 0)
