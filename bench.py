@@ -568,6 +568,10 @@ def main():
             line['fp32_linear' if fp32_line['gemm'] == 'fp32' else 'split_linear'] = fp32_line
         if e2e_line:
             line['e2e'] = e2e_line
+        cpe = cpe_l1_bound() if (args.config == 'wild-places' and not args.train) else None
+        if cpe:
+            others = dict(others or {})
+            others['hfl_cpe_forward.bound'] = cpe
         if others:
             line['kernels'] = others
         if args.train:
@@ -610,6 +614,23 @@ def main():
             if 'other' in last:
                 par[fp32_line['gemm']] = parity_record(last['other'], want)
             line['parity'] = par
+        # descriptors of the timed workload against the REFERENCE's own output for this exact batch and these weights (the
+        # reference model files run in the build container: oracle/gen_golden.py::WORKLOAD_CASES -> tests/golden/
+        # model_wild_places_b32.npz; tests/test_gpu_model.py::test_full_size_workloads_match_reference_golden checks the same)
+        gold = os.path.join(ROOT, 'tests', 'golden', 'model_wild_places_b32.npz')
+        if (world == 1 and not args.train and args.config == 'wild-places' and args.batch == 32 and args.points == 4096
+                and not args.points_max and os.path.exists(gold) and 'value' in last):
+            import numpy as np
+            ref = np.load(gold)['descriptors']
+            pr = {'reference': 'tests/golden/model_wild_places_b32.npz (reference model output, oracle/gen_golden.py)',
+                  args.gemm: parity_record(last['value'], ref)}
+            if 'other' in last and fp32_line:
+                pr[fp32_line['gemm']] = parity_record(last['other'], ref)
+            line['parity_reference'] = pr
+        # the keys a truncated record must keep come first
+        head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'parity_reference', 'parity', 'fp32_linear', 'roofline', 'cpu_baseline', 'gpu_over_cpu')
+        line = {**{k: line[k] for k in head if k in line}, **{k: v for k, v in line.items() if k not in head}}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
@@ -693,7 +714,7 @@ def native_fused_timing(step, steps):
                     'frac_of_8TBps': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
                     'note': 'x in + split2 out = 8 B per (row, channel) + 8 B of metadata per token; the two launches it '
                             'replaces move 24 B per (row, channel)'},
-            'mfma_busy_pmc': pmc_mfma_busy('r04_fused_counters.txt'),
+            'mfma_busy_pmc': pmc_mfma_busy('r05_fused_counters.txt') or pmc_mfma_busy('r04_fused_counters.txt'),
             'timing': 'HIP event pair around every launch, recorded by the library, serialised schedule, after the timed region'}
 
 
@@ -716,7 +737,7 @@ def rowtile_roofline(groups, total):
             'frac': round(issued / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
             'useful_tflops_fp32_equivalent': round(flops / (ms * 1e-3) / 1e12, 2), 'launches': n,
             'avg_launch_us': round(ms / n * 1e3, 2), 'by_launch_size': by,
-            'mfma_busy_pmc': pmc_mfma_busy('r04_mlp_counters.txt'),
+            'mfma_busy_pmc': pmc_mfma_busy('r05_mlp_counters.txt') or pmc_mfma_busy('r04_mlp_counters.txt'),
             'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
 
 
@@ -727,10 +748,12 @@ def pmc_mfma_busy(name):
     path = os.path.join(ROOT, 'profiles', name)
     if not os.path.exists(path):
         return None
-    vals = {}
+    vals, stamps = {}, []
     for ln in open(path):
         f = ln.split()
-        if len(f) >= 2 and f[0].isupper():
+        if len(f) == 3 and f[0] == 'kernel_source_sha1':
+            stamps.append((f[1], f[2]))
+        elif len(f) >= 2 and f[0].isupper():
             try:
                 vals[f[0]] = float(f[1])
             except ValueError:
@@ -738,8 +761,56 @@ def pmc_mfma_busy(name):
     busy, gui = vals.get('SQ_VALU_MFMA_BUSY_CYCLES'), vals.get('GRBM_GUI_ACTIVE')
     if not busy or not gui:
         return None
-    return {'frac': round(busy / (4 * 256 * gui / 8.0), 4), 'source': 'profiles/' + name,
-            'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), rocprofv3 --pmc survey of the kernel alone'}
+    # a committed survey is evidence for the kernel source it was taken on: it carries the sha1 of that source
+    # (tools/stamp_sources.py); a survey whose source has changed since is reported as stale, not as a measurement
+    fresh = bool(stamps) and all(source_sha1(rel) == sha for rel, sha in stamps)
+    out = {'frac': round(busy / (4 * 256 * gui / 8.0), 4) if fresh else None, 'source': 'profiles/' + name,
+           'how': 'SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), rocprofv3 --pmc survey of the kernel alone'}
+    if not fresh:
+        out['stale'] = ('kernel source changed since the survey' if stamps else 'survey carries no source stamp') + \
+                       ' (value at survey time: %.4f)' % (busy / (4 * 256 * gui / 8.0))
+    return out
+
+
+def source_sha1(rel):
+    import hashlib
+    try:
+        return hashlib.sha1(open(os.path.join(ROOT, rel), 'rb').read()).hexdigest()
+    except OSError:
+        return None
+
+
+def cpe_l1_bound():
+    """What bounds hfl_cpe_forward (the depth-wise octree conv + LayerNorm + residual, libs/dwconv/csrc/dwconv.cu:24-42 +
+    models/layers/octformer_layers.py:138-142), from the committed L1 / TA / L2 counter survey of its depth-4 launch
+    (tools/cpe_counters.sh -> profiles/r05_cpe_counters.txt): the vector L1 moves one 64-B line per clock and CU, so
+    TCP_TOTAL_CACHE_ACCESSES / 256 CUs clocks is the launch's floor; `frac_of_l1_bound` = that floor / the kernel's clocks."""
+    path = os.path.join(ROOT, 'profiles', 'r05_cpe_counters.txt')
+    if not os.path.exists(path):
+        return None
+    vals, stamps = {}, []
+    for ln in open(path):
+        f = ln.split()
+        if len(f) == 3 and f[0] == 'kernel_source_sha1':
+            stamps.append((f[1], f[2]))
+        elif len(f) >= 2 and (f[0].isupper() or f[0].startswith('T')):
+            try:
+                vals[f[0]] = float(f[1])
+            except ValueError:
+                pass
+    need = ('TCP_TOTAL_CACHE_ACCESSES_sum', 'GRBM_GUI_ACTIVE', 'TCP_TCC_READ_REQ_sum', 'TCC_HIT_sum', 'TCC_MISS_sum',
+            'TD_TD_BUSY_sum', 'TCP_GATE_EN1_sum', 'TA_TA_BUSY_sum')
+    if any(k not in vals for k in need):
+        return None
+    clk = vals['GRBM_GUI_ACTIVE'] / 8.0
+    fresh = bool(stamps) and all(source_sha1(rel) == sha for rel, sha in stamps)
+    return {'bound': 'vector L1 line rate (64 B / clock / CU)', 'source': 'profiles/r05_cpe_counters.txt',
+            'fresh': fresh,
+            'frac_of_l1_bound': round(vals['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256.0 / clk, 3),
+            'l1_hit_rate': round(1.0 - vals['TCP_TCC_READ_REQ_sum'] / vals['TCP_TOTAL_CACHE_ACCESSES_sum'], 3),
+            'l2_hit_rate': round(vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']), 3),
+            'l1_busy': round(vals['TCP_GATE_EN1_sum'] / 256.0 / clk, 3), 'td_busy': round(vals['TD_TD_BUSY_sum'] / 256.0 / clk, 3),
+            'ta_busy': round(vals['TA_TA_BUSY_sum'] / 256.0 / clk, 3)}
 
 
 def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32, serialised):
@@ -749,7 +820,7 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
     n, ms, nbytes, flops, moved = rec
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for cand in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for cand in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         pmc = os.path.join(ROOT, 'profiles', cand)
         if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
@@ -779,7 +850,7 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
                      'frac_issued_of_peak_used': round(useful_tf * (3.5 if f16 else 1.0) /
                                                        (MFMA_F16_PEAK_TFLOPS if f16 else mfma_peak_f32), 4),
                      'useful_over_f32_peak': round(useful_tf / MFMA_F32_PEAK_TFLOPS, 4),
-                     'mfma_busy_pmc': pmc_mfma_busy('r04_attn_counters.txt') if f16 else None},
+                     'mfma_busy_pmc': (pmc_mfma_busy('r05_attn_counters.txt') or pmc_mfma_busy('r04_attn_counters.txt')) if f16 else None},
             'timing': ('HIP event pair around every launch (recorded by the library on the launch stream for the fp16 kernel, '
                        'by ops.KernelTimer for the fp32 one) over %d steps re-run right after the timed region, never inside '
                        'it, with the step\'s launch schedule on ONE stream; the kernel trace of that schedule is '

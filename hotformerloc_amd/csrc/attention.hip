@@ -1662,6 +1662,7 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_dynamic(1);
   } else if (is("attn_fused_split")) {
     hfl_internal_set_attn_fused_split(value);
+
   } else if (is("dynamic_units")) {
     hfl_internal_set_mlp_dynamic(value);
   } else if (is("tail_split")) {
