@@ -35,7 +35,8 @@ class BlockWeights(ctypes.Structure):
                 ('norm1_gamma', c_void_p), ('norm1_beta', c_void_p), ('norm2_gamma', c_void_p), ('norm2_beta', c_void_p),
                 ('qkv_w', c_void_p), ('proj_w', c_void_p), ('fc1_w', c_void_p), ('fc2_w', c_void_p),
                 ('qkv_b', c_void_p), ('proj_b', c_void_p), ('fc1_b', c_void_p), ('fc2_b', c_void_p),
-                ('rpe_table', c_void_p), ('mlp_pack', c_void_p), ('qkv_pack', c_void_p), ('fuse_attention', c_int32)]
+                ('rpe_table', c_void_p), ('mlp_pack', c_void_p), ('qkv_pack', c_void_p), ('fuse_attention', c_int32),
+                ('rpe_tables3', c_void_p)]
 
 
 class RelayBlockWeights(ctypes.Structure):
@@ -179,6 +180,9 @@ SIGNATURES = {
     'hfl_attn_fused_ok': (c_int, [c_void_p, c_int, c_int]),
     'hfl_attn_fused_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                            c_void_p, c_void_p]),
+    'hfl_attn_ws_ok': (c_int, [c_void_p, c_int]),
+    'hfl_attn_ws_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
+                        c_void_p, c_void_p, c_void_p, c_void_p]),
     'hfl_qkv_fused_pack_bytes': (c_int64, [c_int]),
     'hfl_qkv_fused_pack': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'hfl_ln_qkv_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int64, c_int,

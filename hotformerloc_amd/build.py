@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libhotformerloc_hip.so'
 ARCH = 'gfx950'
-SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'gemm_x3.hip', 'mlp_fused.hip', 'qkv_fused.hip', 'attn_fused.hip', 'attn_pool.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
+SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'gemm_x3.hip', 'mlp_fused.hip', 'qkv_fused.hip', 'attn_fused.hip', 'attn_ws.hip', 'attn_pool.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 # hipBLASLt for hfl_gemm_bf16 (the ROCm copy that matches the headers; rpath so the loader finds it)
@@ -29,7 +29,8 @@ EXTRA_FLAGS = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
                # scalar ops produces) stalls the matrix pipe, plain VALU does not
                'mlp_fused.hip': ['-fno-slp-vectorize'],
                'qkv_fused.hip': ['-fno-slp-vectorize'],
-               'attn_fused.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+               'attn_fused.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1'],
+               'attn_ws.hip': ['-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _hipcc() -> str:

@@ -1603,6 +1603,9 @@ void hfl_internal_set_mlp_dbg(int v);
 void hfl_internal_set_mlp_tail_split(int v);
 void hfl_internal_set_mlp_dynamic(int v);
 void hfl_internal_set_attn_fused_split(int v);
+#ifdef HFL_PROBES
+void hfl_internal_set_ws_dbg(int v);
+#endif
 void hfl_internal_set_qkv_tail_split(int v);
 // bench.py: switch the per-launch timing of the fp16 window kernel on / off (both drop what was recorded) ...
 int hfl_internal_rpe_form(int depth, int bnd, int f16) { return rpe_form(depth, bnd, f16); }     // (csrc/attn_fused.hip)
@@ -1662,7 +1665,10 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_dynamic(1);
   } else if (is("attn_fused_split")) {
     hfl_internal_set_attn_fused_split(value);
-
+#ifdef HFL_PROBES
+  } else if (is("ws_dbg")) {
+    hfl_internal_set_ws_dbg(value);
+#endif
   } else if (is("dynamic_units")) {
     hfl_internal_set_mlp_dynamic(value);
   } else if (is("tail_split")) {

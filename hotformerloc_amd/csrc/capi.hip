@@ -45,11 +45,16 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   int rc;
   const int phase = io->phase;
   if (phase < 0 || phase > 4) return HFL_EINVAL;
+  // relay-token blocks of the shape csrc/attn_ws.hip takes: LN1 -> qkv -> window attention of the token rows are ONE launch
+  // behind the relay rows' qkv (their q / k / v are operands of every window), so phase 1 is the CPE alone.  (Phase 3 -- the
+  // attention goes out in a merged launch of several blocks -- keeps the separate qkv launch.)
+  const bool ws = (w->fuse_attention & 2) != 0 && rows > nt && nt > 0 && w->qkv_pack != nullptr && w->rpe_tables3 != nullptr &&
+                  w->rpe_table != nullptr && hfl_attn_ws_ok(desc, (int)C) != 0;
   // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention)
   if (phase <= 1 && nt > 0) {
     rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
     if (rc != HFL_OK) return rc;
-    if (phase == 1) {           // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
+    if (phase == 1 && !ws) {    // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
       if (w->qkv_pack != nullptr) {
         rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
       } else {
@@ -67,7 +72,11 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   // -- the window attention waits for it, the copy of the rows into the block's buffer is only needed by proj's residual --
   // as one launch with the output features split over the workgroups instead of copy, LayerNorm, GEMM: three dependent small
   // launches of the finest level's critical chain per iteration)
-  const bool relay_fused = (phase == 2 || phase == 3) && rows > nt && w->qkv_pack != nullptr;
+  const bool relay_fused = (phase == 2 || phase == 3 || (phase == 0 && ws)) && rows > nt && w->qkv_pack != nullptr;
+  if (ws && phase == 3) {
+    rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
+    if (rc != HFL_OK) return rc;
+  }
   if (relay_fused) {
     const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
     rc = hfl_ln_qkv_fused(qkv + nt * 3 * C, src, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale,
@@ -82,7 +91,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   }
   // blocks without relay rows (the OctFormer stage), whole-block call: LN1 -> qkv -> window attention as ONE launch, q / k / v
   // never in HBM (csrc/attn_fused.hip), when the configuration is one it takes
-  const bool fused_attn = phase == 0 && rows == nt && w->fuse_attention != 0 && w->qkv_pack != nullptr &&
+  const bool fused_attn = phase == 0 && rows == nt && (w->fuse_attention & 1) != 0 && w->qkv_pack != nullptr &&
                           hfl_attn_fused_ok(desc, (int)C, w->rpe_table != nullptr) != 0;
   if (fused_attn) {
     rc = hfl_attn_fused_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, io->tok_meta,
@@ -105,7 +114,11 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
     }
   }
   if (phase == 3) return HFL_OK;
-  if (phase != 4 && !fused_attn) {
+  if (phase != 4 && ws) {
+    rc = hfl_attn_ws_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, qkv + nt * 3 * C,
+                         io->tok_meta, w->rpe_tables3, desc, stream);
+    if (rc != HFL_OK) return rc;
+  } else if (phase != 4 && !fused_attn) {
     rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
     if (rc != HFL_OK) return rc;
   }

@@ -99,6 +99,9 @@ _GATHER_IN_GEMM = os.environ.get('HFL_GATHER_IN_GEMM', '1') != '0'   # grouped t
 _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
 _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
+# LN1 -> qkv -> window attention of a relay-token block's token rows as one launch (csrc/attn_ws.hip) from this many token rows
+_ATTN_WS = os.environ.get('HFL_ATTN_WS', '0') != '0'
+_ATTN_WS_MIN_ROWS = int(os.environ.get('HFL_ATTN_WS_MIN_ROWS', '40000'))
 _MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
 
 
@@ -859,6 +862,13 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     qpack = _qkv_pack(att, nt)
     w.qkv_pack = None if qpack is None else qpack.data_ptr()
     w.fuse_attention = 1 if _ATTN_FUSED else 0
+    tables3 = None
+    if (_ATTN_WS and qpack is not None and table is not None and rows > nt >= _ATTN_WS_MIN_ROWS
+            and att.dilation == 1 and att.rt_per_window == 1
+            and ops.attn_ws_ok(nt, plan.n_windows[depth], att.patch_size, att.num_heads, depth, C)):
+        tables3 = ops.rpe_expand(table, att.num_heads, bnd, depth, 2)
+        w.fuse_attention |= 2
+    w.rpe_tables3 = None if tables3 is None else tables3.data_ptr()
     pack = _mlp_pack(mlp, rows)
     if pack is not None:
         w.mlp_pack, w.fc1_w, w.fc2_w = pack.data_ptr(), None, None
@@ -870,7 +880,7 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
                           dilation=att.dilation, n_relay=att.rt_per_window, n_heads=att.num_heads, pos_bnd=bnd,
                           batch_size=plan.B, scale=16 ** -0.5, depth=depth,
                           rpe_expanded=None if expanded is None else expanded.data_ptr())
-    return ops.BlockCall(w, (keep, expanded, pack, qpack), x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
+    return ops.BlockCall(w, (keep, expanded, pack, qpack, tables3), x_in, plan.neigh(depth), plan.meta[depth], nt, desc)
 
 
 def _native_block(block, x_in, relay, plan: WindowPlan, depth: int):
@@ -1296,7 +1306,9 @@ class HOTFormerStage(nn.Module):
                 # ONE launch: their windows are one or two per workgroup, latency-bound launches of 14 and 21 us alone.  The
                 # join is between those side streams only.  (Measured alternatives: all three levels in one launch joined
                 # on the main stream -3.5 % of the step; the small levels back to back on one side stream -3 %.)
-                group = [j for j in order if small[j] and calls[depths[j]] is not None] if _MERGED_ATTN else []
+                # (blocks on the one-launch LN1 -> qkv -> attention path have no separate attention launch to merge)
+                group = [j for j in order if small[j] and calls[depths[j]] is not None
+                         and not calls[depths[j]].weights.fuse_attention & 2] if _MERGED_ATTN else []
                 if len(group) < 2:
                     group = []
                 outs = {}

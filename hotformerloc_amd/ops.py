@@ -724,6 +724,41 @@ def attn_fused(x, gamma, beta, eps: float, qkv_pack, qkv_bias, q_scale: float, t
     return out
 
 
+def attn_ws_ok(n_tokens: int, n_windows: int, patch_size: int, n_heads: int, depth: int, channels: int) -> bool:
+    """Whether `attn_ws` takes this relay-token block configuration."""
+    desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=n_tokens, n_windows=n_windows, patch_size=patch_size, dilation=1,
+                          n_relay=1, n_heads=n_heads, pos_bnd=int(0.8 * patch_size), batch_size=1, scale=16 ** -0.5, depth=depth)
+    return bool(_native.load().hfl_attn_ws_ok(ctypes.byref(desc), int(channels)))
+
+
+def attn_ws(x, gamma, beta, eps: float, qkv_pack, qkv_bias, q_scale: float, relay_qkv, tok_meta, rpe_table, n_tokens: int,
+            n_windows: int, patch_size: int, n_heads: int, batch_size: int, depth: int, out=None):
+    """split2(window_attention(qkv(LayerNorm(x)), relay q / k / v)) of a relay-token block in ONE launch (hfl_attn_ws_fwd):
+    x (n_tokens, C) f32 token rows, relay_qkv (n_windows, 3C) the relay rows' fp16 (hi, lo) operand rows (`ln_qkv_fused` over
+    them) -> (n_tokens + n_windows, 2C) bf16, the operand of the proj GEMM (relay rows at n_tokens + window)."""
+    _dev(x, gamma, beta, qkv_pack, qkv_bias, relay_qkv, tok_meta, rpe_table)
+    x = _f32c(x)
+    c = x.shape[1]
+    assert x.shape[0] >= n_tokens and relay_qkv.is_contiguous() and relay_qkv.shape[0] >= n_windows
+    if out is None:
+        out = torch.zeros((n_tokens + n_windows, 2 * c), dtype=torch.bfloat16, device=x.device)
+    bnd = int(0.8 * patch_size)
+    desc = WindowAttnDesc(n_tokens=n_tokens, rt_row0=n_tokens, n_windows=n_windows, patch_size=patch_size, dilation=1,
+                          n_relay=1, n_heads=n_heads, pos_bnd=bnd, batch_size=batch_size, scale=16 ** -0.5, depth=depth)
+    tables = None
+    if rpe_table is not None:
+        tables = rpe_expand(rpe_table, n_heads, bnd, depth, 2)
+        assert tables is not None
+    with _timed('hfl_attn_ws_fwd', n_tokens * c * 8 + n_tokens * 8 + n_windows * c * 16,
+                6 * n_tokens * c * c + 4 * (patch_size + 1) ** 2 * c * n_windows):
+        check(_native.load().hfl_attn_ws_fwd(out.data_ptr(), x.data_ptr(), _f32c(gamma).data_ptr(), _f32c(beta).data_ptr(),
+                                             float(eps), qkv_pack.data_ptr(), _f32c(qkv_bias).data_ptr(), float(q_scale),
+                                             relay_qkv.data_ptr(), tok_meta.data_ptr(),
+                                             None if tables is None else tables.data_ptr(), ctypes.byref(desc), _stream()),
+              'hfl_attn_ws_fwd')
+    return out
+
+
 def window_attention_f16_ok(n_rows: int, patch_size: int, dilation: int, n_relay: int, n_heads: int, depth: int) -> bool:
     """Whether the window kernel takes the fp16 (hi, lo) qkv layout for this launch (else: fp32 qkv)."""
     desc = WindowAttnDesc(n_tokens=n_rows, rt_row0=0, n_windows=1, patch_size=patch_size, dilation=dilation,

@@ -445,6 +445,23 @@ int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, con
 int hfl_layer_norm_relu(float* out_f32, uint16_t* out_split2, const float* x, const float* gamma, const float* beta,
                         int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
 
+/* 9e'. norm1 -> attention.qkv -> window attention of a RELAY-TOKEN block (models/hotformerloc_backbone.py:197-216,
+ *      models/octformer_backbone.py:52-93: C = 256, 16 heads, K = 48 tokens + 1 relay token per window, dilation 1) as ONE launch
+ *      with specialised waves (csrc/attn_ws.hip: six waves run the qkv GEMM of 96 rows head pair by head pair, six run the
+ *      window attention of the pair before from LDS): q, k, v of the token rows never cross HBM.
+ *        out_split2 (rows, 2C) bf16 split2: the attention output of the token rows [0, n_tokens) and of the relay rows
+ *                   [rt_row0, rt_row0 + n_windows) -- the operand of attention.proj (hfl_linear_x3)
+ *        x          (n_tokens, C) f32 token rows (after the CPE); gamma / beta / eps: norm1
+ *        qkv_pack   hfl_qkv_fused_pack image of attention.qkv.weight; qkv_bias (3C); q_scale = head_dim^-0.5 * log2(e)
+ *        relay_qkv  (n_windows, 3C) fp16 (hi, lo) operand rows of the relay tokens = hfl_ln_qkv_fused over the relay rows
+ *        rpe_tables3  hfl_window_rpe_expand(..., f16_operand = 2) of the block's RPE table, or NULL (disable_RPE)
+ *      hfl_attn_ws_ok: 1 when the configuration is taken (channels 256, 16 heads, n_relay 1, dilation 1, K = 48, depth <= 7),
+ *      else 0 -- the caller then runs hfl_ln_qkv_fused + hfl_window_attention_fwd_ex. */
+int hfl_attn_ws_ok(const hfl_window_attn_desc* desc, int channels);
+int hfl_attn_ws_fwd(void* out_split2, const float* x, const float* gamma, const float* beta, float eps, const void* qkv_pack,
+                    const float* qkv_bias, float q_scale, const void* relay_qkv, const uint32_t* tok_meta,
+                    const float* rpe_tables3, const hfl_window_attn_desc* desc, hfl_stream_t stream);
+
 /* 9c. The pre-norm MLP branch of a transformer block as ONE launch (csrc/mlp_fused.hip):
  *       out (n_rows, C) = x + fc2(gelu(fc1(LayerNorm(x; gamma, beta, eps)) + b1)) + b2        fc1: C -> 4C, fc2: 4C -> C
  * Replaces norm2 -> mlp.fc1 -> GELU -> mlp.fc2 -> residual add (models/octformer_backbone.py:275-278,
@@ -547,9 +564,14 @@ typedef struct hfl_block_weights {
   const void* qkv_pack;                                /* hfl_qkv_fused_pack image of qkv_w or NULL: when set, phase 1 runs LN1 -> qkv
                                                           of the token rows as ONE launch (hfl_ln_qkv_fused); qkv_w is still
                                                           read for the relay rows */
-  int32_t fuse_attention;                              /* != 0: a whole-block call (phase 0) of a block WITHOUT relay rows runs LN1
+  int32_t fuse_attention;                              /* bit 0: a whole-block call (phase 0) of a block WITHOUT relay rows runs LN1
                                                           -> qkv -> window attention as ONE launch (hfl_attn_fused_fwd) when
-                                                          hfl_attn_fused_ok takes the configuration; needs qkv_pack */
+                                                          hfl_attn_fused_ok takes the configuration; needs qkv_pack.
+                                                          bit 1: a block WITH relay rows runs LN1 -> qkv -> window attention of its
+                                                          token rows as ONE launch (hfl_attn_ws_fwd) when hfl_attn_ws_ok takes the
+                                                          configuration; needs qkv_pack and rpe_tables3.  Phase 1 is then the CPE
+                                                          alone (the launch reads the relay rows' q / k / v) */
+  const float* rpe_tables3;                            /* hfl_window_rpe_expand(..., f16_operand = 2) of rpe_table, or NULL */
 } hfl_block_weights;
 typedef struct hfl_block_io {
   const float* x_in;

@@ -1187,6 +1187,65 @@ def test_window_attention_multi_launch_equals_single_launches():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 30, 2500, 4096, 4096]), ('oxford', 9, [4096, 1000]),
+                                                    ('wild-places', 7, [4096] * 12)])
+def test_attn_ws_equals_the_two_launches(cfg, octree_depth, sizes):
+    """hfl_attn_ws_fwd (LayerNorm -> qkv -> window attention of a relay-token block in ONE launch with specialised GEMM /
+    attention waves: C = 256, 16 heads, K = 48 tokens + the window's relay token, models/hotformerloc_backbone.py:197-216)
+    against hfl_ln_qkv_fused over [token rows | relay rows] + the fp16 window kernel with the relay tokens (the path
+    test_window_attention_matches_oracle pins to the oracle's materialised hat_window_mask + padded RPE).  Token rows: the
+    same operations in the same order -> BITWISE equal (the two-launch kernel switched to the three-table RPE form the fused
+    kernel always uses).  Relay rows: their one query per window runs on the VALU in fp32 instead of a 16-row MFMA tile ->
+    equal to one unit of the split2 output's low half.  Every pyramid depth of the config, with and without RPE, ragged
+    batches (partly padded last windows, windows that straddle clouds), more tiles than CUs (several units per workgroup, the
+    left-over tiles split by head pairs), deterministic."""
+    from hotformerloc_amd import _native
+    lib = _native.load()
+    clouds = [syn.unit_ball_cloud(700 + i, n) for i, n in enumerate(sizes)]
+    params, ref, dev, oplan, plan = _plans(clouds, cfg, octree_depth)
+    K = params.patch_size
+    H, C = 16, 256
+    g = torch.Generator(device='cuda').manual_seed(5)
+    gamma = torch.rand(C, device='cuda', generator=g) + 0.5
+    beta = torch.randn(C, device='cuda', generator=g) * 0.1
+    w = torch.randn(3 * C, C, device='cuda', generator=g) * 0.08
+    b = torch.randn(3 * C, device='cuda', generator=g) * 0.1
+    qs = 16 ** -0.5 * 1.4426950408889634
+    pack = ops.qkv_fused_pack(w)
+    bnd = int(0.8 * K)
+    try:
+        lib.hfl_set_variant(b'window_rpe_form1_max_depth', 0)
+        for depth in plan.pyramid_depths:
+            nt, W = plan.n_tokens[depth], plan.n_windows[depth]
+            assert ops.attn_ws_ok(nt, W, K, H, depth, C), (cfg, depth)
+            x = torch.randn(nt + W, C, device='cuda', generator=g) * 1.3 + 0.2
+            for with_rpe in (True, False):
+                table = torch.randn(3 * (2 * bnd + 1), H, device='cuda', generator=g) * 0.3 if with_rpe else None
+                qkv = ops.ln_qkv_fused(x, gamma, beta, 1e-5, pack, b, qs)
+                two = ops.window_attention(qkv, plan.meta[depth], table, nt, W, K, 1, 1, H, plan.B, rt_row0=nt, depth=depth,
+                                           out_split=2, qkv_f16=True)
+                one = ops.attn_ws(x[:nt], gamma, beta, 1e-5, pack, b, qs, qkv[nt:], plan.meta[depth], table, nt, W, K, H,
+                                  plan.B, depth)
+                nbad = (one[:nt].view(torch.int16) != two[:nt].view(torch.int16)).any(dim=1).sum().item()
+                assert nbad == 0, (cfg, depth, with_rpe, nbad)
+
+                def val(t):
+                    v = t[nt:nt + W].float().view(W, C // 32, 2, 32)
+                    return (v[:, :, 0] + v[:, :, 1]).reshape(W, C)
+                a, r = val(one), val(two)
+                assert torch.isfinite(a).all()
+                err = (a - r).abs().max().item()
+                assert err <= 1.2e-5 * max(r.abs().max().item(), 1.0), (cfg, depth, with_rpe, err)
+                again = ops.attn_ws(x[:nt], gamma, beta, 1e-5, pack, b, qs, qkv[nt:], plan.meta[depth], table, nt, W, K, H,
+                                    plan.B, depth)
+                assert torch.equal(one.view(torch.int16), again.view(torch.int16))
+    finally:
+        lib.hfl_set_variant(b'window_rpe_form1_max_depth', 4)
+    assert not ops.attn_ws_ok(1000, 21, 48, 8, 4, 128)            # C = 128 blocks have no relay tokens: hfl_attn_fused_fwd
+    assert not ops.attn_ws_ok(1000, 16, 64, 16, 4, 256)           # K = 64 (CS-Wild-Places): the two launches
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 30, 2500, 4096]), ('cs-wild-places', 7, [6000, 4096]),
                                                     ('oxford', 9, [4096, 1000])])
 def test_attn_fused_equals_the_two_launches(cfg, octree_depth, sizes):

@@ -437,6 +437,33 @@ def test_early_phase_schedule_equals_the_sequential_one():
 
 
 @pytest.mark.gpu
+def test_attn_ws_block_path_matches_the_two_launch_path():
+    """HFL_ATTN_WS: LN1 -> qkv -> window attention of the relay-token blocks' token rows as ONE launch (hfl_attn_ws_fwd behind
+    hfl_block_forward_x3, phase 1 = the CPE alone) against the default two launches, in the early-phase schedule and the
+    sequential one: the same arithmetic per score except the relative-position term (three 1-D tables summed per score
+    against the two-lookup form), so the descriptors agree to rounding; early and sequential are bitwise equal to each other."""
+    from hotformerloc_amd import model as M
+    params, depth = load_config('wild-places')
+    model = model_factory(params)
+    syn.fill_synthetic_weights(model, 'stress')
+    model = model.cuda().eval()
+    octree = build_batch_octree(syn.make_clouds(93, 4, 2500, params.coordinates), depth, 2, 'cuda')
+    out = {}
+    for ws, early in ((False, True), (True, True), (True, False)):
+        M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE = ws, 0, early
+        try:
+            with torch.no_grad():
+                out[ws, early] = model({'octree': octree})['global']
+            torch.cuda.synchronize()
+        finally:
+            M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE = False, 40000, True
+    assert torch.equal(out[True, True], out[True, False])
+    a, b = out[False, True].double(), out[True, True].double()
+    rel = ((a - b).norm(dim=1) / a.norm(dim=1)).max().item()
+    assert 0.0 < rel < 2e-5, rel            # (not the same launches: > 0; bar = 20 x what is observed)
+
+
+@pytest.mark.gpu
 def test_merged_window_attention_launch_equals_one_launch_per_level():
     """The window attention of an H-OSA iteration's three pyramid levels as ONE launch (hfl_block_attention_x3_multi between
     block phases 3 and 4) against one launch per level: the same windows through the same kernel, bitwise equal descriptors;
