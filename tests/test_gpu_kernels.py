@@ -1195,8 +1195,10 @@ def test_attn_ws_equals_the_two_launches(cfg, octree_depth, sizes):
     against hfl_ln_qkv_fused over [token rows | relay rows] + the fp16 window kernel with the relay tokens (the path
     test_window_attention_matches_oracle pins to the oracle's materialised hat_window_mask + padded RPE).  Token rows: the
     same operations in the same order -> BITWISE equal (the two-launch kernel switched to the three-table RPE form the fused
-    kernel always uses).  Relay rows: their one query per window runs on the VALU in fp32 instead of a 16-row MFMA tile ->
-    equal to one unit of the split2 output's low half.  Every pyramid depth of the config, with and without RPE, ragged
+    kernel always uses).  Relay rows: their one query per window is a query tile with one live column -> the same values (bar:
+    one unit of the split2 output's low half).  With RPE also against the oracle's composition LayerNorm -> Linear -> attention
+    on the reference's materialised hat_window_mask + padded RPE, <= 3e-5 of the largest value (the output is the proj GEMM's
+    split-bf16 operand: 16 significant bits per value).  Every pyramid depth of the config, with and without RPE, ragged
     batches (partly padded last windows, windows that straddle clouds), more tiles than CUs (several units per workgroup, the
     left-over tiles split by head pairs), deterministic."""
     from hotformerloc_amd import _native
@@ -1239,6 +1241,25 @@ def test_attn_ws_equals_the_two_launches(cfg, octree_depth, sizes):
                 again = ops.attn_ws(x[:nt], gamma, beta, 1e-5, pack, b, qs, qkv[nt:], plan.meta[depth], table, nt, W, K, H,
                                     plan.B, depth)
                 assert torch.equal(one.view(torch.int16), again.view(torch.int16))
+                if with_rpe:
+                    # ... and against the ORACLE composition in fp64 -> fp32: LayerNorm -> Linear -> scaled-dot-product attention
+                    # on the reference's materialised windows, hat_window_mask and zero-padded RPE
+                    # (models/hotformerloc_backbone.py:197-214, models/octformer_backbone.py:52-93)
+                    xd = x.cpu().double()
+                    ln = torch.nn.functional.layer_norm(xd, (C,), gamma.cpu().double(), beta.cpu().double(), 1e-5)
+                    q64 = (ln @ w.cpu().double().t() + b.cpu().double()).float()
+                    xw = torch.cat([q64[nt:].unsqueeze(1), oplan.to_windows(q64[:nt], depth, False)], 1)
+                    q_, k_, v_ = xw.reshape(-1, K + 1, 3, H, 16).permute(2, 0, 3, 1, 4)
+                    rpe = torch.nn.functional.pad(hotformer_ref.rpe_bias(table.cpu(), oplan.rel_pos[depth], K, 1), (1, 0, 1, 0))
+                    want = hotformer_ref._sdpa(q_, k_, v_, oplan.hat_mask[depth].unsqueeze(1) + rpe, 0.25)
+                    want = want.transpose(1, 2).reshape(-1, K + 1, C)
+                    got = one.float().cpu().view(nt + W, C // 32, 2, 32)
+                    got = (got[:, :, 0] + got[:, :, 1]).reshape(nt + W, C)
+                    e_tok = (got[:nt] - oplan.from_windows(want[:, 1:], depth, False)).abs().max().item()
+                    real_w = -(-nt // K)
+                    e_rt = (got[nt:nt + real_w] - want[:real_w, 0]).abs().max().item()
+                    print('attn_ws vs oracle composition', cfg, depth, 'token rows %.2e relay rows %.2e' % (e_tok, e_rt))
+                    assert max(e_tok, e_rt) <= 3e-5 * max(want.abs().max().item(), 1.0), (cfg, depth, e_tok, e_rt)
     finally:
         lib.hfl_set_variant(b'window_rpe_form1_max_depth', 4)
     assert not ops.attn_ws_ok(1000, 21, 48, 8, 4, 128)            # C = 128 blocks have no relay tokens: hfl_attn_fused_fwd
