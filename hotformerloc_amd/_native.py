@@ -52,7 +52,12 @@ class RelayBlockIO(ctypes.Structure):
     """hfl_relay_block_io"""
     _fields_ = [('x_in', c_void_p), ('out', c_void_p), ('arena', c_void_p), ('seq_rows', c_void_p), ('seq_off', c_void_p),
                 ('n_rows', c_int64), ('batch', c_int32), ('max_seq_len', c_int32), ('orphan_rows', c_void_p),
-                ('n_orphans', c_int32)]
+                ('n_orphans', c_int32), ('x_segments', c_void_p)]
+
+
+class RowSegments(ctypes.Structure):
+    """hfl_row_segments"""
+    _fields_ = [('n', c_int32), ('ptr', c_void_p * 4), ('row0', c_int64 * 4)]
 
 
 class BlockIO(ctypes.Structure):
@@ -185,6 +190,9 @@ SIGNATURES = {
                         c_void_p, c_void_p, c_void_p, c_void_p]),
     'hfl_qkv_fused_pack_bytes': (c_int64, [c_int]),
     'hfl_qkv_fused_pack': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    'hfl_ln_qkv_fused_seg': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int64, c_int,
+                                     c_void_p]),
+    'hfl_linear_x3_seg': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_ln_qkv_fused': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_int64, c_int,
                          c_void_p]),
     'hfl_segment_softmax': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -50,79 +50,77 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   // attention goes out in a merged launch of several blocks -- keeps the separate qkv launch.)
   const bool ws = (w->fuse_attention & 2) != 0 && rows > nt && nt > 0 && w->qkv_pack != nullptr && w->rpe_tables3 != nullptr &&
                   w->rpe_table != nullptr && hfl_attn_ws_ok(desc, (int)C) != 0;
-  // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention)
-  if (phase <= 1 && nt > 0) {
-    rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
-    if (rc != HFL_OK) return rc;
-    if (phase == 1 && !ws) {    // per-row operators: the token rows' LN1 and qkv do not wait for the relay rows either
-      if (w->qkv_pack != nullptr) {
-        rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
-      } else {
-        rc = hfl_layer_norm_split2(a2, x0, w->norm1_gamma, w->norm1_beta, nt, C, w->eps, stream);
-        if (rc != HFL_OK) return rc;
-        rc = hfl_linear_x3_qkv(qkv, a2, w->qkv_w, w->qkv_b, nt, (int)C, (int)(3 * C), w->q_scale, stream);
-      }
-      if (rc != HFL_OK) return rc;
-    }
-  }
-  if (phase == 1) return HFL_OK;
-  // ---- phase 2 (or the whole block) = phase 3 (the relay rows up to their qkv) + the window attention + phase 4 (the rest);
-  // 3 and 4 exist so that the attention of several blocks can go out as one launch in between (hfl_block_attention_x3_multi)
-  // (phases 2 / 3 with the fused LN1 -> qkv launch available: the relay rows' qkv reads them where they are and goes out FIRST
-  // -- the window attention waits for it, the copy of the rows into the block's buffer is only needed by proj's residual --
-  // as one launch with the output features split over the workgroups instead of copy, LayerNorm, GEMM: three dependent small
-  // launches of the finest level's critical chain per iteration)
-  const bool relay_fused = (phase == 2 || phase == 3 || (phase == 0 && ws)) && rows > nt && w->qkv_pack != nullptr;
-  if (ws && phase == 3) {
-    rc = hfl_ln_qkv_fused(qkv, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nt, (int)C, stream);
-    if (rc != HFL_OK) return rc;
-  }
-  if (relay_fused) {
-    const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
-    rc = hfl_ln_qkv_fused(qkv + nt * 3 * C, src, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale,
-                          rows - nt, (int)C, stream);
-    if (rc != HFL_OK) return rc;
-  }
-  if (phase != 4 && rows > nt) {
-    const float* src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
-    hipError_t e = hipMemcpyAsync(x0 + nt * C, src, (size_t)(rows - nt) * C * 4, hipMemcpyDeviceToDevice,
-                                  static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return (int)e;
-  }
   // blocks without relay rows (the OctFormer stage), whole-block call: LN1 -> qkv -> window attention as ONE launch, q / k / v
   // never in HBM (csrc/attn_fused.hip), when the configuration is one it takes
   const bool fused_attn = phase == 0 && rows == nt && (w->fuse_attention & 1) != 0 && w->qkv_pack != nullptr &&
                           hfl_attn_fused_ok(desc, (int)C, w->rpe_table != nullptr) != 0;
-  if (fused_attn) {
-    rc = hfl_attn_fused_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, io->tok_meta,
-                            w->rpe_table, desc, stream);
+  // The relay rows (what the relay-token block of the iteration produced, or x_in's) are read WHERE THEY ARE when the fused
+  // LN1 -> qkv launch is available: by that launch and by proj's residual (a two-segment row table); the block's own buffer
+  // holds them only on the unfused path, whose LayerNorm reads it.
+  const float* relay_src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
+  const bool relay_in_place = rows > nt && w->qkv_pack != nullptr && (w->fuse_attention & 4) == 0;
+  const bool part1 = phase <= 1, part3 = phase == 0 || phase == 2 || phase == 3, part_att = phase == 0 || phase == 2,
+             part4 = phase == 0 || phase == 2 || phase == 4;
+  auto ln_qkv = [&](int64_t r0, int64_t nr, const float* src) -> int {       // rows [r0, r0 + nr) of qkv from src (nr x C)
+    if (nr <= 0) return HFL_OK;
+    if (w->qkv_pack != nullptr)
+      return hfl_ln_qkv_fused(qkv + r0 * 3 * C, src, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, nr,
+                              (int)C, stream);
+    int r = hfl_layer_norm_split2(a2 + r0 * 2 * C, src, w->norm1_gamma, w->norm1_beta, nr, C, w->eps, stream);
+    if (r != HFL_OK) return r;
+    return hfl_linear_x3_qkv(qkv + r0 * 3 * C, a2 + r0 * 2 * C, w->qkv_w, w->qkv_b, nr, (int)C, (int)(3 * C), w->q_scale, stream);
+  };
+  // ---- phase 1: everything that reads TOKEN rows only (independent of this iteration's relay-token self-attention): the CPE
+  // and, per-row operators that they are, the token rows' LN1 and qkv
+  if (part1 && nt > 0) {
+    rc = hfl_cpe_forward(x0, io->x_in, w->cpe_weight, w->cpe_gamma, w->cpe_beta, io->neigh, nt, C, 27, w->eps, 1, stream);
     if (rc != HFL_OK) return rc;
+    if (!ws && !fused_attn) {
+      rc = ln_qkv(0, nt, x0);
+      if (rc != HFL_OK) return rc;
+    }
   }
-  if (phase != 4 && !fused_attn && !relay_fused) {
-    // LN1 + qkv of the rows phase 1 has not done: all of them (phase 0) or the relay rows (phases 2, 3)
-    const int64_t r0 = phase != 0 ? nt : 0, nr = rows - r0;
-    if (nr > 0 && w->qkv_pack != nullptr) {      // (the same launch the phased schedule uses: bitwise the same rows)
-      rc = hfl_ln_qkv_fused(qkv + r0 * 3 * C, x0 + r0 * C, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale,
-                            nr, (int)C, stream);
-      if (rc != HFL_OK) return rc;
-    } else if (nr > 0) {
-      rc = hfl_layer_norm_split2(a2 + r0 * 2 * C, x0 + r0 * C, w->norm1_gamma, w->norm1_beta, nr, C, w->eps, stream);
-      if (rc != HFL_OK) return rc;
-      rc = hfl_linear_x3_qkv(qkv + r0 * 3 * C, a2 + r0 * 2 * C, w->qkv_w, w->qkv_b, nr, (int)C, (int)(3 * C), w->q_scale,
-                             stream);
+  if (phase == 1) return HFL_OK;
+  // ---- phase 2 (or the rest of the whole block) = phase 3 (the relay rows up to their qkv) + the window attention + phase 4
+  // (proj, MLP); 3 and 4 exist so that the attention of several blocks can go out as one launch in between
+  // (hfl_block_attention_x3_multi).  The relay rows' qkv goes out FIRST: the window attention waits for it.
+  if (part3 && rows > nt) {
+    if (!relay_in_place) {
+      hipError_t e = hipMemcpyAsync(x0 + nt * C, relay_src, (size_t)(rows - nt) * C * 4, hipMemcpyDeviceToDevice,
+                                    static_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return (int)e;
+    }
+    rc = ln_qkv(nt, rows - nt, relay_in_place ? relay_src : x0 + nt * C);
+    if (rc != HFL_OK) return rc;
+    if (ws && phase == 3) {
+      rc = ln_qkv(0, nt, x0);
       if (rc != HFL_OK) return rc;
     }
   }
   if (phase == 3) return HFL_OK;
-  if (phase != 4 && ws) {
-    rc = hfl_attn_ws_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, qkv + nt * 3 * C,
-                         io->tok_meta, w->rpe_tables3, desc, stream);
-    if (rc != HFL_OK) return rc;
-  } else if (phase != 4 && !fused_attn) {
-    rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
+  if (part_att) {
+    if (fused_attn) {
+      rc = hfl_attn_fused_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, io->tok_meta,
+                              w->rpe_table, desc, stream);
+    } else if (ws) {
+      rc = hfl_attn_ws_fwd(o2, x0, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b, w->q_scale, qkv + nt * 3 * C,
+                           io->tok_meta, w->rpe_tables3, desc, stream);
+    } else {
+      rc = hfl_window_attention_fwd_ex(o2, qkv, nullptr, io->tok_meta, w->rpe_table, desc, 2 | 0x100, stream);
+    }
     if (rc != HFL_OK) return rc;
   }
-  rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
+  if (relay_in_place) {
+    hfl_row_segments res;
+    res.n = 2;
+    res.ptr[0] = x0; res.row0[0] = 0;
+    res.ptr[1] = relay_src; res.row0[1] = nt;
+    res.ptr[2] = res.ptr[3] = nullptr; res.row0[2] = res.row0[3] = 0;
+    if (nt == 0) { res.n = 1; res.ptr[0] = relay_src; }
+    rc = hfl_linear_x3_seg(x1, o2, w->proj_w, w->proj_b, &res, rows, (int)C, (int)C, stream);
+  } else {
+    rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, x0, rows, (int)C, (int)C, 0, stream);
+  }
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // the MLP branch in one launch: the 4C-wide hidden activation stays in registers
     // (workspace of the left-over rows' partial sums: behind the twelve units, sized by hfl_block_forward_x3_arena)
@@ -132,7 +130,7 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   if (rc != HFL_OK) return rc;
   rc = hfl_linear_x3(g2, h2, w->fc1_w, w->fc1_b, nullptr, rows, (int)C, (int)(4 * C), 1, stream);
   if (rc != HFL_OK) return rc;
-  return hfl_linear_x3(io->out, g2, w->fc2_w, w->fc2_b, x1, rows, (int)(4 * C), (int)C, 0, stream);
+  return hfl_linear_x3(io->out, g2, w->fc2_w, w->fc2_b, x1, rows, (int)C * 4, (int)C, 0, stream);
 }
 
 int64_t hfl_block_forward_x3_arena(int64_t n_rows, int64_t channels) {
@@ -180,10 +178,17 @@ int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay
   uint16_t* h2 = reinterpret_cast<uint16_t*>(a + 7 * unit);
   uint16_t* g2 = reinterpret_cast<uint16_t*>(a + 8 * unit);
   int rc;
+  const hfl_row_segments* xs = io->x_segments;
+  if (xs != nullptr && w->qkv_pack == nullptr) return HFL_EINVAL;
+  if (xs == nullptr && io->x_in == nullptr) return HFL_EINVAL;
   if (w->qkv_pack != nullptr) {
     // LN1 -> qkv as one launch into the fp16 (hi, lo) operand rows, the attention from them straight into proj's operand
-    rc = hfl_ln_qkv_fused(qkv, io->x_in, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b,
-                          0.25f * 1.4426950408889634f, rows, (int)C, stream);
+    if (xs != nullptr)          // the pyramid levels' relay rows where the levels left them
+      rc = hfl_ln_qkv_fused_seg(qkv, xs, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b,
+                                0.25f * 1.4426950408889634f, rows, (int)C, stream);
+    else
+      rc = hfl_ln_qkv_fused(qkv, io->x_in, w->norm1_gamma, w->norm1_beta, w->eps, w->qkv_pack, w->qkv_b,
+                            0.25f * 1.4426950408889634f, rows, (int)C, stream);
     if (rc != HFL_OK) return rc;
     rc = hfl_relay_attention_f16_fwd(o2, qkv, io->seq_rows, io->seq_off, io->batch, w->n_heads, io->max_seq_len, io->orphan_rows,
                                      io->n_orphans, stream);
@@ -200,7 +205,10 @@ int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay
     rc = hfl_split2(o2, att, rows, C, stream);
     if (rc != HFL_OK) return rc;
   }
-  rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, io->x_in, rows, (int)C, (int)C, 0, stream);
+  if (xs != nullptr)
+    rc = hfl_linear_x3_seg(x1, o2, w->proj_w, w->proj_b, xs, rows, (int)C, (int)C, stream);
+  else
+    rc = hfl_linear_x3(x1, o2, w->proj_w, w->proj_b, io->x_in, rows, (int)C, (int)C, 0, stream);
   if (rc != HFL_OK) return rc;
   if (w->mlp_pack != nullptr)       // LN2 -> fc1 -> GELU -> fc2 -> residual in one launch, hidden dimension split over the chip
     return hfl_ln_mlp_fused_ws(io->out, x1, w->norm2_gamma, w->norm2_beta, w->eps, w->mlp_pack, w->fc1_b, w->fc2_b, rows, (int)C,

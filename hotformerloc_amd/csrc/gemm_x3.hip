@@ -48,6 +48,7 @@ struct X3Params {
   const uint16_t* w;        // (N, K/32, 2, 32) bf16
   const float* bias;        // (N) or null
   const float* residual;    // (M, N) or null (EPI 0 only; may alias out)
+  HflRowSeg res_seg;        // residual rows in several arrays (res_seg.n > 1; residual = res_seg.ptr[0])
   const int32_t* tiles;     // grouped launch (EPI 0): per row tile {first row, rows (<= 128), first row of its W block}, or null
   const int32_t* gather;    // grouped launch: row m of the A operand is x[gather[m]] (the live pairs' input rows: the octree
                             // convolution's gather done by the tile loader), or null: x[m]
@@ -97,7 +98,8 @@ __device__ __forceinline__ void x3_epilogue(const X3Params& p, f32x4 (&acc)[4][M
       for (int it = 0; it < 8; ++it) {
         const int64_t m = m_tile + h * 32 + it * 4 + fq;
         rs[h][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.residual != nullptr && m < m_end && n_ok) rs[h][it] = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+        if (p.residual != nullptr && m < m_end && n_ok)
+          rs[h][it] = *reinterpret_cast<const float4*>((p.res_seg.n > 1 ? hfl_seg_row(p.res_seg, m, N) : p.residual + m * N) + nbase);
       }
   }
 #pragma unroll
@@ -344,13 +346,21 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
                      float q_scale, hfl_stream_t stream, float* aux = nullptr, const float* row_scale = nullptr,
                      const int32_t* tiles = nullptr, int64_t n_tiles = 0, const int32_t* gather = nullptr,
-                     int64_t n_src_rows = 0);
+                     int64_t n_src_rows = 0, const HflRowSeg* res_seg = nullptr);
 
 int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream) {
   return x3_launch(out, x_split2, w_split2, bias, residual, n_rows, in_features, out_features,
                    gelu_split_out ? 1 : 0, 1.0f, stream);
+}
+
+int hfl_linear_x3_seg(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                      const hfl_row_segments* residual, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream) {
+  HflRowSeg seg;
+  if (!hfl_seg_from(residual, n_rows, &seg)) return HFL_EINVAL;
+  return x3_launch(out, x_split2, w_split2, bias, seg.ptr[0], n_rows, in_features, out_features, 0, 1.0f, stream, nullptr,
+                   nullptr, nullptr, 0, nullptr, 0, &seg);
 }
 
 int hfl_linear_x3_rows(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
@@ -405,7 +415,7 @@ int hfl_linear_x3_gelu_bwd(uint16_t* out_split2, const uint16_t* dy_split2, cons
 static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
                      const float* residual, int64_t n_rows, int in_features, int out_features, int epi,
                      float q_scale, hfl_stream_t stream, float* aux, const float* row_scale, const int32_t* tiles,
-                     int64_t n_tiles, const int32_t* gather, int64_t n_src_rows) {
+                     int64_t n_tiles, const int32_t* gather, int64_t n_src_rows, const HflRowSeg* res_seg) {
   const int gelu_split_out = epi == 1 || epi == 3 || epi == 4;
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
   const bool narrow = tiles != nullptr && epi == 0 && out_features == 64;       // W blocks padded to 128 rows by the caller
@@ -415,6 +425,7 @@ static int x3_launch(void* out, const uint16_t* x_split2, const uint16_t* w_spli
   if (n_rows == 0) return HFL_OK;
   X3Params p;
   p.out = out; p.x = x_split2; p.w = w_split2; p.bias = bias; p.residual = residual; p.aux = aux;
+  p.res_seg = res_seg != nullptr ? *res_seg : hfl_seg_single(residual);
   p.row_scale = row_scale;
   p.tiles = tiles;
   p.gather = gather;

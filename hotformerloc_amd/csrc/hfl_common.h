@@ -32,6 +32,41 @@ static inline int hfl_stream_cus(hipStream_t s) { return hfl_internal_stream_cus
 
 static inline int64_t hfl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// A logical (rows, C) f32 matrix whose rows live in up to four separate arrays (hfl_row_segments of the C-ABI): rows
+// [row[i], row[i + 1]) at ptr[i]; unused entries have row = INT64_MAX.  n == 1 is the plain pointer.
+struct HflRowSeg {
+  const float* ptr[4];
+  long long row[4];
+  int n;
+};
+static inline HflRowSeg hfl_seg_single(const float* p) {
+  HflRowSeg s;
+  for (int i = 0; i < 4; ++i) { s.ptr[i] = p; s.row[i] = i == 0 ? 0 : 0x7fffffffffffffffLL; }
+  s.n = 1;
+  return s;
+}
+// from the C-ABI struct; false when it is malformed for a matrix of n_rows rows
+static inline bool hfl_seg_from(const hfl_row_segments* in, int64_t n_rows, HflRowSeg* out) {
+  if (in == nullptr || in->n < 1 || in->n > 4 || in->row0[0] != 0) return false;
+  *out = hfl_seg_single(in->ptr[0]);
+  out->n = in->n;
+  for (int i = 0; i < in->n; ++i) {
+    if (in->ptr[i] == nullptr || (i > 0 && in->row0[i] < in->row0[i - 1]) || in->row0[i] > n_rows) return false;
+    out->ptr[i] = in->ptr[i];
+    out->row[i] = in->row0[i];
+  }
+  return true;
+}
+__device__ __forceinline__ const float* hfl_seg_row(const HflRowSeg& s, long long r, long long stride) {
+  const float* p = s.ptr[0] + r * stride;
+  if (s.n > 1) {
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (r >= s.row[i]) p = s.ptr[i] + (r - s.row[i]) * stride;
+  }
+  return p;
+}
+
 // index-table element access for int32 / int64 neighbour tables
 template <typename IdxT>
 __device__ __forceinline__ int64_t hfl_ld_idx(const IdxT* p, int64_t i) {

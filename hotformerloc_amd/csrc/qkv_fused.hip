@@ -29,6 +29,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct QkvFusedParams {
   unsigned char* out;         // (M, 3C) attention operand rows: 3C * 4 B per row
   const float* x;             // (M, C) f32
+  HflRowSeg xseg;             // ... or its rows in several arrays (xseg.n > 1; x = xseg.ptr[0])
   const float* gamma;         // (C)
   const float* beta;          // (C)
   const unsigned char* pack;  // hfl_qkv_fused_pack image of Wqkv
@@ -185,7 +186,7 @@ ln_qkv_fused_kernel(const QkvFusedParams p) {
       int64_t r = (int64_t)(tile0 + k) * 16 + fr;
       if (r >= p.M) r = p.M - 1;
       if (!have[t]) r = 0;
-      const float* xr = p.x + r * C + fq * 8;
+      const float* xr = (p.xseg.n > 1 ? hfl_seg_row(p.xseg, r, C) : p.x + r * C) + fq * 8;
       float4 a[KS][2];
       float sum = 0.f;
 #pragma unroll
@@ -423,8 +424,25 @@ int hfl_qkv_fused_pack(void* pack, const float* w_qkv, int channels, hfl_stream_
   HFL_RETURN_LAST_ERROR();
 }
 
+static int ln_qkv_fused_launch(void* qkv_out, const float* x, const HflRowSeg* xseg, const float* gamma, const float* beta,
+                               float eps, const void* pack, const float* bias, float q_scale, int64_t n_rows, int channels,
+                               hfl_stream_t stream);
+
 int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* bias, float q_scale, int64_t n_rows, int channels, hfl_stream_t stream) {
+  return ln_qkv_fused_launch(qkv_out, x, nullptr, gamma, beta, eps, pack, bias, q_scale, n_rows, channels, stream);
+}
+
+int hfl_ln_qkv_fused_seg(void* qkv_out, const hfl_row_segments* x, const float* gamma, const float* beta, float eps,
+                         const void* pack, const float* bias, float q_scale, int64_t n_rows, int channels, hfl_stream_t stream) {
+  HflRowSeg seg;
+  if (n_rows < 0 || !hfl_seg_from(x, n_rows, &seg)) return HFL_EINVAL;
+  return ln_qkv_fused_launch(qkv_out, seg.ptr[0], &seg, gamma, beta, eps, pack, bias, q_scale, n_rows, channels, stream);
+}
+
+static int ln_qkv_fused_launch(void* qkv_out, const float* x, const HflRowSeg* xseg, const float* gamma, const float* beta,
+                               float eps, const void* pack, const float* bias, float q_scale, int64_t n_rows, int channels,
+                               hfl_stream_t stream) {
   if (qkv_out == nullptr || x == nullptr || gamma == nullptr || beta == nullptr || pack == nullptr || bias == nullptr ||
       n_rows < 0)
     return HFL_EINVAL;
@@ -433,6 +451,7 @@ int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const fl
   if (hfl_cdiv(n_rows, 16) > 0x7fffffffLL) return HFL_ECAPACITY;
   QkvFusedParams p;
   p.out = static_cast<unsigned char*>(qkv_out); p.x = x; p.gamma = gamma; p.beta = beta;
+  p.xseg = xseg != nullptr ? *xseg : hfl_seg_single(x);
   p.pack = static_cast<const unsigned char*>(pack); p.bias = bias; p.M = n_rows; p.eps = eps; p.q_scale = q_scale;
   p.n_tiles = (int)hfl_cdiv(n_rows, 16);
   int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));

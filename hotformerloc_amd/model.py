@@ -100,6 +100,8 @@ _LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: 
 _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
 _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
 # LN1 -> qkv -> window attention of a relay-token block's token rows as one launch (csrc/attn_ws.hip) from this many token rows
+_RTSA_SEGMENTS = os.environ.get('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
+_RELAY_IN_PLACE = os.environ.get('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
 _ATTN_WS = os.environ.get('HFL_ATTN_WS', '0') != '0'
 _ATTN_WS_MIN_ROWS = int(os.environ.get('HFL_ATTN_WS_MIN_ROWS', '40000'))
 _MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
@@ -861,7 +863,7 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     mlp = block.mlp
     qpack = _qkv_pack(att, nt)
     w.qkv_pack = None if qpack is None else qpack.data_ptr()
-    w.fuse_attention = 1 if _ATTN_FUSED else 0
+    w.fuse_attention = (1 if _ATTN_FUSED else 0) | (0 if _RELAY_IN_PLACE else 4)
     tables3 = None
     if (_ATTN_WS and qpack is not None and table is not None and rows > nt >= _ATTN_WS_MIN_ROWS
             and att.dilation == 1 and att.rt_per_window == 1
@@ -1075,6 +1077,19 @@ class RelayTokenTransformerBlock(nn.Module):
             res = (w, keep)
         self.__dict__['_native_cache'] = (stamp, res)
         return res
+
+    def forward_parts(self, parts, plan):
+        """forward(torch.cat(parts)) -- without the concatenation launch when the native call can read the rows where they are
+        (hfl_relay_block_io.x_segments: the fused LN1 -> qkv launch and proj's residual take a row-segment table)."""
+        p0 = parts[0]
+        if (_RTSA_SEGMENTS and len(parts) <= 4 and _GEMM_MODE == 'x3' and _split_path(p0) and not self.use_layer_scale
+                and not _drops(self) and _NATIVE_BLOCK and ops.KernelTimer.active is None
+                and all(p.dtype == torch.float32 and p.is_contiguous() and p.shape[0] > 0 for p in parts)):
+            static = self._native_static(p0.device)
+            if static is not None and static[0].qkv_pack:
+                return ops.relay_block_forward_x3(static[0], static[1], list(parts), plan.seq_rows, plan.seq_off, plan.B,
+                                                  plan.max_seq_len, plan.orphan_rows)
+        return self(torch.cat(list(parts), 0), plan)
 
     def forward(self, rt, plan):
         if _GEMM_MODE == 'x3' and _split_path(rt) and not self.use_layer_scale and not _drops(self) and rt.shape[0] > 0:
@@ -1296,7 +1311,7 @@ class HOTFormerStage(nn.Module):
                     for ev in done:
                         rs.wait_event(ev)
                 with torch.cuda.stream(rs):
-                    rt_all = self.rtsa_blocks[i](torch.cat([rts[d] for d in depths], 0), plan)
+                    rt_all = self.rtsa_blocks[i].forward_parts([rts[d] for d in depths], plan)
                     ev_rt = rs.record_event()
                 for j in order[1:]:
                     phase1(j)
@@ -1350,11 +1365,10 @@ class HOTFormerStage(nn.Module):
                     done = [st.record_event() for st in dict.fromkeys(sts)]
                 del calls, old, fresh, rt_all
                 continue
-            rt_all = torch.cat([rts[d] for d in depths], 0)
             if ckpt:                                                    # 596-601
-                rt_all = _checkpoint_block(self.rtsa_blocks[i], rt_all, plan)
+                rt_all = _checkpoint_block(self.rtsa_blocks[i], torch.cat([rts[d] for d in depths], 0), plan)
             else:
-                rt_all = self.rtsa_blocks[i](rt_all, plan)
+                rt_all = self.rtsa_blocks[i].forward_parts([rts[d] for d in depths], plan)
             fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
             if _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda:
                 # the three depths are independent inside an iteration (the reference runs them on

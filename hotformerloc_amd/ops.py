@@ -405,7 +405,7 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
               out=None, row_scale=None) -> torch.Tensor:
     """y = x W^T [+ bias] [+ residual] (fp32), or with gelu_split_out the split2 bf16 operand of the next Linear,
     split2(gelu(x W^T + bias)); x2 / w2 are split2 operands (hfl_linear_x3)."""
-    _dev(x2, w2, bias, residual)
+    _dev(x2, w2, bias, *(residual if isinstance(residual, (list, tuple)) else (residual,)))
     assert x2.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x2.is_contiguous() and w2.is_contiguous()
     m, k2 = x2.shape
     n = w2.shape[0]
@@ -418,6 +418,15 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
     else:
         if out is None:
             out = torch.empty((m, n), dtype=torch.float32, device=x2.device)
+        if isinstance(residual, (list, tuple)):       # the residual rows in several arrays (hfl_linear_x3_seg)
+            assert row_scale is None
+            seg, rows = row_segments(residual)
+            assert rows == m and residual[0].shape[1] == n
+            with _timed('hfl_linear_x3', m * k * 4 + m * n * 8, 2 * m * k * n):
+                check(_native.load().hfl_linear_x3_seg(out.data_ptr(), x2.data_ptr(), w2.data_ptr(),
+                                                       None if bias is None else _f32c(bias).data_ptr(), ctypes.byref(seg),
+                                                       m, k, n, _stream()), 'hfl_linear_x3_seg')
+            return out
         if residual is not None:
             residual = _f32c(residual)
             assert tuple(residual.shape) == (m, n)
@@ -576,10 +585,11 @@ class BlockCall:
                                   phase=0)
 
     def run(self, phase: int, relay=None):
-        if relay is not None:
+        if relay is not None:           # (stays set for the later phases of the call: phase 4's proj reads the relay rows there)
             _dev(relay)
+            assert relay.dtype == torch.float32 and relay.is_contiguous()
             self.keep = self.keep + (relay,)
-        self.io.relay = None if relay is None else relay.data_ptr()
+            self.io.relay = relay.data_ptr()
         self.io.phase = phase
         check(self.lib.hfl_block_forward_x3(ctypes.byref(self.weights), ctypes.byref(self.io), ctypes.byref(self.desc),
                                             _stream()), 'hfl_block_forward_x3')
@@ -598,14 +608,37 @@ def block_attention_multi(calls):
     check(lib.hfl_block_attention_x3_multi(n, ws, ios, ds, _stream()), 'hfl_block_attention_x3_multi')
 
 
+def row_segments(parts):
+    """hfl_row_segments of the row-wise concatenation of `parts` (1..4 contiguous f32 (rows_i, C) tensors): (struct, rows)."""
+    assert 1 <= len(parts) <= 4
+    _dev(*parts)
+    seg = _native.RowSegments()
+    seg.n = len(parts)
+    r = 0
+    for i, t in enumerate(parts):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == parts[0].shape[1]
+        seg.ptr[i], seg.row0[i] = t.data_ptr(), r
+        r += t.shape[0]
+    return seg, r
+
+
 def relay_block_forward_x3(weights, keep_alive, rt, seq_rows, seq_off, batch: int, max_seq_len: int, orphan_rows=None):
-    """The relay-token transformer block (RTSA) of the inference path in ONE native call (hfl_relay_block_forward_x3)."""
-    _dev(rt, seq_rows, seq_off, orphan_rows)
-    rows, c = rt.shape
+    """The relay-token transformer block (RTSA) of the inference path in ONE native call (hfl_relay_block_forward_x3).  rt: the
+    (rows, C) relay rows, or a list of up to four tensors whose row-wise concatenation they are (the pyramid levels' relay rows
+    where the levels left them: needs weights.qkv_pack)."""
+    seg = None
+    if isinstance(rt, (list, tuple)):
+        seg, rows = row_segments(rt)
+        c, dev, x_ptr = rt[0].shape[1], rt[0].device, None
+    else:
+        _dev(rt)
+        (rows, c), dev, x_ptr = rt.shape, rt.device, rt.data_ptr()
+    _dev(seq_rows, seq_off, orphan_rows)
     lib = _native.load()
-    out = torch.empty((rows, c), dtype=torch.float32, device=rt.device)
-    arena = torch.empty(int(lib.hfl_relay_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=rt.device)
-    io = _native.RelayBlockIO(x_in=rt.data_ptr(), out=out.data_ptr(), arena=arena.data_ptr(), seq_rows=seq_rows.data_ptr(),
+    out = torch.empty((rows, c), dtype=torch.float32, device=dev)
+    arena = torch.empty(int(lib.hfl_relay_block_forward_x3_arena(rows, c)), dtype=torch.uint8, device=dev)
+    io = _native.RelayBlockIO(x_in=x_ptr, x_segments=None if seg is None else ctypes.addressof(seg),
+                              out=out.data_ptr(), arena=arena.data_ptr(), seq_rows=seq_rows.data_ptr(),
                               seq_off=seq_off.data_ptr(), n_rows=rows, batch=batch, max_seq_len=max_seq_len,
                               orphan_rows=None if orphan_rows is None or orphan_rows.numel() == 0 else orphan_rows.data_ptr(),
                               n_orphans=0 if orphan_rows is None else orphan_rows.numel())
@@ -671,7 +704,18 @@ def qkv_fused_pack(w_qkv: torch.Tensor) -> torch.Tensor:
 def ln_qkv_fused(x, gamma, beta, eps: float, pack, bias, q_scale: float, out=None):
     """LayerNorm + qkv projection into the fp16 (hi, lo) operand layout of the window kernel in ONE launch
     (hfl_ln_qkv_fused = layer_norm_split2 + linear_x3_qkv): an opaque (rows, 3C) float32-sized buffer."""
-    _dev(x, gamma, beta, pack, bias)
+    _dev(gamma, beta, pack, bias)
+    if isinstance(x, (list, tuple)):                  # the rows in several arrays (hfl_ln_qkv_fused_seg)
+        seg, m = row_segments(x)
+        c = x[0].shape[1]
+        if out is None:
+            out = torch.empty((m, 3 * c), dtype=torch.float32, device=x[0].device)
+        with _timed('hfl_ln_qkv_fused', m * c * 16, 6 * m * c * c):
+            check(_native.load().hfl_ln_qkv_fused_seg(out.data_ptr(), ctypes.byref(seg), _f32c(gamma).data_ptr(),
+                                                      _f32c(beta).data_ptr(), float(eps), pack.data_ptr(), _f32c(bias).data_ptr(),
+                                                      float(q_scale), m, c, _stream()), 'hfl_ln_qkv_fused_seg')
+        return out
+    _dev(x)
     x = _f32c(x)
     m, c = x.shape
     if out is None:

@@ -389,6 +389,18 @@ int hfl_linear_x3(void* out, const uint16_t* x_split2, const uint16_t* w_split2,
                   const float* residual, int64_t n_rows, int in_features, int out_features, int gelu_split_out,
                   hfl_stream_t stream);
 int hfl_split2(uint16_t* out, const float* x, int64_t n_rows, int64_t channels, hfl_stream_t stream);
+/* A logical (n_rows, C) f32 matrix whose rows live in up to four separate arrays: rows [row0[i], row0[i + 1]) at ptr[i] (C floats
+ * per row, row-major), row0[0] = 0, 1 <= n <= 4.  The [tokens | relay rows] buffer of an H-OSA block, whose relay rows arrive
+ * from the relay-token block, and the relay-token block's input, the concatenation of the pyramid levels' relay rows
+ * (models/hotformerloc_backbone.py:593-633: `torch.cat` / index assignment there), are read through it where they are. */
+typedef struct hfl_row_segments {
+  int32_t n;
+  const float* ptr[4];
+  int64_t row0[4];
+} hfl_row_segments;
+/* hfl_linear_x3 (f32 output) with the residual rows read through a segment table. */
+int hfl_linear_x3_seg(float* out, const uint16_t* x_split2, const uint16_t* w_split2, const float* bias,
+                      const hfl_row_segments* residual, int64_t n_rows, int in_features, int out_features, hfl_stream_t stream);
 /* Grouped form: ONE launch over row tiles that use DIFFERENT weight blocks -- the per-tap products of an octree convolution
  * over its live (row, tap) pairs (models/layers/octformer_layers.py:89-95; model.OctreeConv._forward_live_taps), which were
  * 27 library GEMM launches.  tiles (n_tiles, 3) int32 = {first row, rows (1..128), first row of the tile's weight block in
@@ -503,6 +515,9 @@ int64_t hfl_qkv_fused_pack_bytes(int channels);
 int hfl_qkv_fused_pack(void* pack, const float* w_qkv, int channels, hfl_stream_t stream);
 int hfl_ln_qkv_fused(void* qkv_out, const float* x, const float* gamma, const float* beta, float eps, const void* pack,
                      const float* bias, float q_scale, int64_t n_rows, int channels, hfl_stream_t stream);
+/* ... with the input rows read through a segment table (hfl_row_segments above). */
+int hfl_ln_qkv_fused_seg(void* qkv_out, const hfl_row_segments* x, const float* gamma, const float* beta, float eps,
+                         const void* pack, const float* bias, float q_scale, int64_t n_rows, int channels, hfl_stream_t stream);
 
 /* 9e. LayerNorm -> qkv projection -> window attention as ONE launch (csrc/attn_fused.hip): norm1 -> attention.qkv -> mask /
  *     RPE bias / SDPA of `x = x + attn(norm1(x))` (models/octformer_backbone.py:52-93,275-276) up to the attention output,
@@ -570,12 +585,14 @@ typedef struct hfl_block_weights {
                                                           bit 1: a block WITH relay rows runs LN1 -> qkv -> window attention of its
                                                           token rows as ONE launch (hfl_attn_ws_fwd) when hfl_attn_ws_ok takes the
                                                           configuration; needs qkv_pack and rpe_tables3.  Phase 1 is then the CPE
-                                                          alone (the launch reads the relay rows' q / k / v) */
+                                                          alone (the launch reads the relay rows' q / k / v).
+                                                          bit 2: copy the relay rows into the block's buffer first (the form before
+                                                          proj's residual read them in place; for A/B runs) */
   const float* rpe_tables3;                            /* hfl_window_rpe_expand(..., f16_operand = 2) of rpe_table, or NULL */
 } hfl_block_weights;
 typedef struct hfl_block_io {
   const float* x_in;
-  const float* relay;
+  const float* relay;                                  /* also in phase 4: proj's residual reads the relay rows there */
   float* out;
   void* arena;
   const int32_t* neigh;                                /* (n_tokens, 27) */
@@ -629,6 +646,8 @@ typedef struct hfl_relay_block_io {
   const int32_t* orphan_rows;                          /* rows that belong to no sequence (relay tokens of pure padding windows):
                                                           their attention output is zero; read when qkv_pack is set */
   int32_t n_orphans;
+  const hfl_row_segments* x_segments;                  /* optional, needs qkv_pack: the input rows where the pyramid levels left
+                                                          them (no concatenation launch); x_in is then not read */
 } hfl_relay_block_io;
 int64_t hfl_relay_block_forward_x3_arena(int64_t n_rows, int64_t channels);
 int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay_block_io* io, hfl_stream_t stream);

@@ -1187,6 +1187,38 @@ def test_window_attention_multi_launch_equals_single_launches():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('c', [256, 128])
+def test_row_segment_forms_equal_the_concatenated_input(c):
+    """hfl_ln_qkv_fused_seg / hfl_linear_x3_seg (rows of the input / of the residual read from up to four arrays: the relay rows
+    of the pyramid levels where the levels left them, models/hotformerloc_backbone.py:593-633) against the same launches on
+    torch.cat of the parts: bitwise equal, for one to four parts, parts that end inside a row tile, many rows and few."""
+    g = torch.Generator(device='cuda').manual_seed(21)
+    gamma = torch.rand(c, device='cuda', generator=g) + 0.5
+    beta = torch.randn(c, device='cuda', generator=g) * 0.1
+    wq = torch.randn(3 * c, c, device='cuda', generator=g) * 0.08
+    bq = torch.randn(3 * c, device='cuda', generator=g) * 0.1
+    pack = ops.qkv_fused_pack(wq)
+    wp = ops.split2(torch.randn(c, c, device='cuda', generator=g) * 0.08)
+    bp = torch.randn(c, device='cuda', generator=g) * 0.1
+    for sizes in ([1392, 292, 44], [5], [7, 1], [40000, 1392], [100, 28, 3, 129], [66775, 1392]):
+        parts = [torch.randn(n, c, device='cuda', generator=g) for n in sizes]
+        whole = torch.cat(parts, 0)
+        a = ops.ln_qkv_fused(whole, gamma, beta, 1e-5, pack, bq, 0.36)
+        b = ops.ln_qkv_fused(parts, gamma, beta, 1e-5, pack, bq, 0.36)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), ('ln_qkv', sizes)
+        x2 = ops.split2(torch.randn(whole.shape[0], c, device='cuda', generator=g))
+        ya = ops.linear_x3(x2, wp, bias=bp, residual=whole)
+        yb = ops.linear_x3(x2, wp, bias=bp, residual=parts)
+        assert torch.equal(ya, yb), ('linear', sizes)
+    lib = __import__('hotformerloc_amd._native', fromlist=['x']).load()
+    from hotformerloc_amd._native import RowSegments
+    import ctypes
+    bad = RowSegments()
+    bad.n = 5
+    assert lib.hfl_linear_x3_seg(ya.data_ptr(), x2.data_ptr(), wp.data_ptr(), None, ctypes.byref(bad), 4, c, c, None) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('cfg,octree_depth,sizes', [('wild-places', 7, [4096, 30, 2500, 4096, 4096]), ('oxford', 9, [4096, 1000]),
                                                     ('wild-places', 7, [4096] * 12)])
 def test_attn_ws_equals_the_two_launches(cfg, octree_depth, sizes):
