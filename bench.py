@@ -26,7 +26,9 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
   fp32_linear    the boundary-faithful step with every Linear as an fp32 GEMM and fp32-MFMA attention -- the
                  reference's arithmetic
   e2e            a FRESH octree per step from device-resident points: device build + neighbour tables + forward
-  train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process
+  train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process; activations kept
+                 (checkpoint policy 'auto': the device has room) -- train_cs_checkpointed = the same with the reference's
+                 per-block recomputation (bitwise the same gradients)
   oxford         BASELINE config 5's per-rank workload (Oxford cfg, B = 64, octree depth 9), in a child process
   unpinned_host  the headline step with the CPU affinity left alone, in a child process (the headline itself runs on its rank's
                  eighth of the host's logical CPUs: --pin-cores); every leg's `host_issue` = host time to queue the K steps vs
@@ -165,7 +167,7 @@ def parity_record(got, want):
             'clouds': int(got.shape[0]), 'bar': 1e-3, 'ok': bool(np.isfinite(got).all() and rel.max() <= 1e-3)}
 
 
-def train_leg(args):
+def train_leg(args, env_extra=None):
     """BASELINE config 3 (CS-Wild-Places cfg, B = 64, 4096..32768 points per cloud, forward + backward) timed by this same
     script in a CHILD process (its own hipBLASLt schedule, its own allocator), same warm-up / step / barrier protocol."""
     saved = os.environ.pop('TENSILE_STREAMK_DATA_PARALLEL', None)
@@ -173,18 +175,19 @@ def train_leg(args):
         return child_leg(['--config', 'cs-wild-places', '--train', '--steps', str(args.train_leg_steps), '--warmup',
                           str(args.train_leg_warmup)],
                          'child process: python bench.py --config cs-wild-places --train (BASELINE config 3)',
-                         keys=('peak_memory_GiB',))
+                         keys=('peak_memory_GiB', 'checkpointing'), env_extra=env_extra)
     finally:
         if saved is not None:
             os.environ['TENSILE_STREAMK_DATA_PARALLEL'] = saved
 
 
-def child_leg(extra, what, timeout=900, keys=()):
+def child_leg(extra, what, timeout=900, keys=(), env_extra=None):
     """One more workload timed by this same script in a CHILD process (same warm-up / step / barrier protocol)."""
     cmd = [sys.executable, os.path.abspath(__file__), '--no-extras', '--no-cpu-baseline'] + extra
     env = dict(os.environ)
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
+    env.update(env_extra or {})
     t0 = time.perf_counter()
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -576,6 +579,13 @@ def main():
             line['kernels'] = others
         if args.train:
             line['peak_memory_GiB'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+            from hotformerloc_amd import model as _M
+            # activation checkpointing: the reference's configs set grad_checkpoint (a second forward of every block to save
+            # memory); policy 'auto' keeps the activations while more than half of the device's memory is free -- bitwise the
+            # same gradients (tests/test_gpu_model.py::test_grad_checkpoint_recomputes_the_same_gradients)
+            line['checkpointing'] = {'policy': _M._CHECKPOINT_POLICY,
+                                     'recomputing': bool(_M._use_checkpoint(model.backbone.backbone.hotf_stage)),
+                                     'device_memory_GiB': round(torch.cuda.get_device_properties(0).total_memory / 2 ** 30, 1)}
         # host side of the timed region: seconds until the last launch of the K steps was queued (no synchronisation
         # inside the region), next to the region's wall time.  issue ~ wall means the host is the bound.
         line['host_issue'] = {'ms_per_step_issue': round(last['value_issue_s'] / args.steps * 1e3, 3),
@@ -586,6 +596,9 @@ def main():
             log('config-3 training leg (child process) ...')
             line['train_cs'] = train_leg(args)
             log('train leg:', line['train_cs'])
+            # the same step with the reference's checkpointing (every block's forward twice, a third of the memory)
+            line['train_cs_checkpointed'] = train_leg(args, {'HFL_CHECKPOINT': 'always'})
+            log('train leg (checkpointed):', line['train_cs_checkpointed'])
         if extras and not args.no_oxford_leg and args.config == 'wild-places':
             log('config-5 per-rank workload (Oxford cfg, B = 64, depth 9; child process) ...')
             line['oxford'] = child_leg(['--config', 'oxford', '--batch', '64', '--steps', str(args.steps), '--warmup',

@@ -315,10 +315,44 @@ def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm
     return ops.add_bias(x, ops.split_mm(g3, _w3(mlp.fc2)), mlp.fc2.bias)
 
 
+# Activation checkpointing policy.  `grad_checkpoint = True` in the reference's configs buys memory with a second forward of
+# every block (written for 24-80 GB devices).  'always': as the reference; 'never': keep the activations; 'auto' (default):
+# keep them while the device has room -- an MI355X has 288 GB and the largest shipped training shape (CS-Wild-Places, 64
+# clouds) keeps ~40 GB -- and checkpoint like the reference once less than _CHECKPOINT_FREE_FRACTION of the memory is free.
+# The results are the same either way (the recomputation repeats the same launches on the same inputs).
+_CHECKPOINT_POLICY = os.environ.get('HFL_CHECKPOINT', 'auto')
+_CHECKPOINT_FREE_FRACTION = float(os.environ.get('HFL_CHECKPOINT_FREE_FRACTION', '0.5'))
+
+
+def set_checkpoint_policy(policy: str):
+    """'always' | 'never' | 'auto' (see above); returns the previous policy."""
+    global _CHECKPOINT_POLICY
+    assert policy in ('always', 'never', 'auto')
+    prev, _CHECKPOINT_POLICY = _CHECKPOINT_POLICY, policy
+    return prev
+
+
+def _memory_is_tight(device) -> bool:
+    free, total = torch.cuda.mem_get_info(device)
+    # (what the caching allocator holds but has not handed out is free for this purpose)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    return free < _CHECKPOINT_FREE_FRACTION * total
+
+
 def _use_checkpoint(stage) -> bool:
     """The reference checkpoints every transformer block `if self.grad_checkpoint and self.training`
-    (models/octformer_backbone.py:415-416, models/hotformerloc_backbone.py:596-618)."""
-    return bool(stage.grad_checkpoint) and stage.training and torch.is_grad_enabled()
+    (models/octformer_backbone.py:415-416, models/hotformerloc_backbone.py:596-618); here additionally subject to the policy
+    above (decided once per forward and stage: all blocks of a stage go the same way)."""
+    if not (bool(stage.grad_checkpoint) and stage.training and torch.is_grad_enabled()):
+        return False
+    if _CHECKPOINT_POLICY == 'always':
+        return True
+    if _CHECKPOINT_POLICY == 'never':
+        return False
+    p = next(stage.parameters(), None)
+    if p is None or not p.is_cuda:
+        return True
+    return _memory_is_tight(p.device)
 
 
 def _checkpoint_block(blk, *args):

@@ -356,27 +356,48 @@ def test_large_oxford_batch_completes_and_is_deterministic():
 def test_grad_checkpoint_recomputes_the_same_gradients():
     """`grad_checkpoint` (default True, `misc/utils.py:89`; per-block non-reentrant checkpointing,
     `models/hotformerloc_backbone.py:596-618`, `models/octformer_backbone.py:415-416`): the custom autograd
-    Functions are re-entrant-safe -- recomputation in the backward gives the gradients of the plain run and less
-    peak memory."""
+    Functions are re-entrant-safe -- recomputation in the backward gives the gradients of the plain run, BITWISE, and less
+    peak memory.  That equality is what lets the default policy ('auto', model.set_checkpoint_policy) keep the activations
+    while the device has room and recompute like the reference only when memory is tight."""
+    from hotformerloc_amd import model as M
     params, depth = load_config('cs-wild-places')
     params.drop_path = 0.0
     clouds = [syn.forest_cloud(300 + i, 5000) if i % 2 else syn.unit_ball_cloud(300 + i, 4096) for i in range(4)]
     proj = torch.from_numpy(syn.hash_uniform(11, 4 * 256).reshape(4, 256).astype(np.float32)).cuda()
     res = {}
-    for ck in (False, True):
-        params.grad_checkpoint = ck
-        model = model_factory(params)
-        assert model.backbone.backbone.hotf_stage.grad_checkpoint is ck
-        syn.fill_synthetic_weights(model, 'stress')
-        model = model.cuda().train()
-        octree = build_batch_octree(clouds, depth, 2, 'cuda')
-        torch.cuda.synchronize()
-        torch.cuda.reset_peak_memory_stats()
-        y = model({'octree': octree})['global']
-        (y * proj).sum().backward()
-        torch.cuda.synchronize()
-        res[ck] = (y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
-                   torch.cuda.max_memory_allocated())
+    prev = M.set_checkpoint_policy('always')          # the reference's behaviour: grad_checkpoint decides
+    try:
+        for ck in (False, True):
+            params.grad_checkpoint = ck
+            model = model_factory(params)
+            assert model.backbone.backbone.hotf_stage.grad_checkpoint is ck
+            syn.fill_synthetic_weights(model, 'stress')
+            model = model.cuda().train()
+            octree = build_batch_octree(clouds, depth, 2, 'cuda')
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            y = model({'octree': octree})['global']
+            (y * proj).sum().backward()
+            torch.cuda.synchronize()
+            res[ck] = (y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
+                       torch.cuda.max_memory_allocated())
+        # policy 'auto' (the default): grad_checkpoint = True recomputes only when the device is short of memory
+        stage = model.backbone.backbone.hotf_stage
+        assert M._use_checkpoint(stage)
+        M.set_checkpoint_policy('auto')
+        assert not M._use_checkpoint(stage)                  # a few hundred MB in use of 288 GB
+        frac, M._CHECKPOINT_FREE_FRACTION = M._CHECKPOINT_FREE_FRACTION, 1.1
+        try:
+            assert M._use_checkpoint(stage)                  # "less than 110 % free": always tight
+        finally:
+            M._CHECKPOINT_FREE_FRACTION = frac
+        M.set_checkpoint_policy('never')
+        assert not M._use_checkpoint(stage)
+        model.eval()
+        M.set_checkpoint_policy('always')
+        assert not M._use_checkpoint(stage)                  # inference never checkpoints
+    finally:
+        M.set_checkpoint_policy(prev)
     assert torch.equal(res[False][0], res[True][0])
     for k, g in res[False][1].items():
         h = res[True][1][k]
