@@ -27,7 +27,7 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
                  reference's arithmetic
   e2e            a FRESH octree per step from device-resident points: device build + neighbour tables + forward
   train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process; activations kept
-                 (checkpoint policy 'auto': the device has room) -- train_cs_checkpointed = the same with the reference's
+                 (checkpoint policy 'auto': they fit) -- train_cs_checkpointed = the same with the reference's
                  per-block recomputation (bitwise the same gradients)
   oxford         BASELINE config 5's per-rank workload (Oxford cfg, B = 64, octree depth 9), in a child process
   unpinned_host  the headline step with the CPU affinity left alone, in a child process (the headline itself runs on its rank's
@@ -583,8 +583,10 @@ def main():
             # activation checkpointing: the reference's configs set grad_checkpoint (a second forward of every block to save
             # memory); policy 'auto' keeps the activations while more than half of the device's memory is free -- bitwise the
             # same gradients (tests/test_gpu_model.py::test_grad_checkpoint_recomputes_the_same_gradients)
+            # (recomputing: peak memory tells -- 14.4 GiB with the recomputation, 40.7 GiB without on this workload)
             line['checkpointing'] = {'policy': _M._CHECKPOINT_POLICY,
-                                     'recomputing': bool(_M._use_checkpoint(model.backbone.backbone.hotf_stage)),
+                                     'keeps_activations_when': 'estimated activation bytes of a stage < %.2f x free device memory'
+                                                               % _M._CHECKPOINT_FREE_FRACTION,
                                      'device_memory_GiB': round(torch.cuda.get_device_properties(0).total_memory / 2 ** 30, 1)}
         # host side of the timed region: seconds until the last launch of the K steps was queued (no synchronisation
         # inside the region), next to the region's wall time.  issue ~ wall means the host is the bound.

@@ -317,11 +317,16 @@ def _block_tail_split(x, attn_out3, attn: 'OctreeAttention', norm2: nn.LayerNorm
 
 # Activation checkpointing policy.  `grad_checkpoint = True` in the reference's configs buys memory with a second forward of
 # every block (written for 24-80 GB devices).  'always': as the reference; 'never': keep the activations; 'auto' (default):
-# keep them while the device has room -- an MI355X has 288 GB and the largest shipped training shape (CS-Wild-Places, 64
-# clouds) keeps ~40 GB -- and checkpoint like the reference once less than _CHECKPOINT_FREE_FRACTION of the memory is free.
+# keep them when they fit comfortably -- an MI355X has 288 GB and the largest shipped training shape (CS-Wild-Places, 64
+# clouds) keeps ~40 GB -- and checkpoint like the reference otherwise: a stage keeps its blocks' activations when their
+# estimated size is below _CHECKPOINT_FREE_FRACTION of the memory that is free when the stage starts.
 # The results are the same either way (the recomputation repeats the same launches on the same inputs).
 _CHECKPOINT_POLICY = os.environ.get('HFL_CHECKPOINT', 'auto')
 _CHECKPOINT_FREE_FRACTION = float(os.environ.get('HFL_CHECKPOINT_FREE_FRACTION', '0.5'))
+# what one transformer block keeps per (row, channel) for its backward: MLP branch x 4 + LN split 4 + GELU split 16 +
+# pre-activation 16, attention branch x 4 + LN split 4 + qkv 12 + attention split 4, CPE input and norm ~16 (measured:
+# 40.7 GiB against 38 GiB by this count on the config-3 workload)
+_BLOCK_BYTES_PER_ROW_CHANNEL = 80
 
 
 def set_checkpoint_policy(policy: str):
@@ -332,27 +337,27 @@ def set_checkpoint_policy(policy: str):
     return prev
 
 
-def _memory_is_tight(device) -> bool:
-    free, total = torch.cuda.mem_get_info(device)
+def _free_memory(device) -> int:
+    free, _ = torch.cuda.mem_get_info(device)
     # (what the caching allocator holds but has not handed out is free for this purpose)
-    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-    return free < _CHECKPOINT_FREE_FRACTION * total
+    return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
 
 
-def _use_checkpoint(stage) -> bool:
+def _use_checkpoint(stage, row_channels: int = 0, n_blocks: int = 1, device=None) -> bool:
     """The reference checkpoints every transformer block `if self.grad_checkpoint and self.training`
     (models/octformer_backbone.py:415-416, models/hotformerloc_backbone.py:596-618); here additionally subject to the policy
-    above (decided once per forward and stage: all blocks of a stage go the same way)."""
+    above, decided once per forward and stage (all blocks of a stage go the same way): `row_channels` = sum over the stage's
+    levels of rows x channels, `n_blocks` = blocks per level."""
     if not (bool(stage.grad_checkpoint) and stage.training and torch.is_grad_enabled()):
         return False
     if _CHECKPOINT_POLICY == 'always':
         return True
     if _CHECKPOINT_POLICY == 'never':
         return False
-    p = next(stage.parameters(), None)
-    if p is None or not p.is_cuda:
+    if device is None or device.type != 'cuda' or row_channels <= 0:
         return True
-    return _memory_is_tight(p.device)
+    need = row_channels * n_blocks * _BLOCK_BYTES_PER_ROW_CHANNEL
+    return need > _CHECKPOINT_FREE_FRACTION * _free_memory(device)
 
 
 def _checkpoint_block(blk, *args):
@@ -975,7 +980,7 @@ class OctFormerStage(nn.Module):
                            conv_norm, dp[i], layer_scale, xcpe) for i in range(num_blocks)])
 
     def forward(self, x, plan, depth):
-        ckpt = _use_checkpoint(self)
+        ckpt = _use_checkpoint(self, x.shape[0] * x.shape[1], len(self.blocks), x.device)
         for blk in self.blocks:
             # activation checkpointing per block, non-reentrant, as octformer_backbone.py:415-416
             x = _checkpoint_block(blk, x, plan, depth) if ckpt else blk(x, plan, depth)
@@ -1259,7 +1264,7 @@ class HOTFormerStage(nn.Module):
         feats = {depths[0]: data}
         for j, d in enumerate(depths[:-1]):
             feats[d - 1] = self.downsamples[j](feats[d], plan.octree, d)
-        ckpt = _use_checkpoint(self)
+        ckpt = _use_checkpoint(self, sum(f.shape[0] * f.shape[1] for f in feats.values()), self.num_blocks, data.device)
         for i in range(self.num_blocks):
             for j, d in enumerate(depths):
                 blk = self.hosa_blocks[j][i]
@@ -1287,7 +1292,7 @@ class HOTFormerStage(nn.Module):
         # relay rows as RTSA sees them: each level's own rows, or (per-level widths) their projection to the widest level
         rts = {d: (self.init_up_projections[j](bufs[d][nt:]) if proj else bufs[d][nt:])          # 585-591
                for j, (d, nt) in enumerate(zip(depths, nts))}
-        ckpt = _use_checkpoint(self)
+        ckpt = _use_checkpoint(self, sum(b.shape[0] * b.shape[1] for b in bufs.values()), self.num_blocks, data.device)
 
         def hosa(j, d, i, buf, fresh_d):
             """down-projection -> H-OSA block -> up-projection of one level (610-630); returns (buffer, relay rows for RTSA)"""

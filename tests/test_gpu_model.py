@@ -382,20 +382,23 @@ def test_grad_checkpoint_recomputes_the_same_gradients():
             res[ck] = (y.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()},
                        torch.cuda.max_memory_allocated())
         # policy 'auto' (the default): grad_checkpoint = True recomputes only when the device is short of memory
-        stage = model.backbone.backbone.hotf_stage
-        assert M._use_checkpoint(stage)
+        stage, dev = model.backbone.backbone.hotf_stage, torch.device('cuda', 0)
+        rc = 20000 * 256                                     # rows x channels of this batch's pyramid levels, roughly
+        assert M._use_checkpoint(stage, rc, 10, dev)
         M.set_checkpoint_policy('auto')
-        assert not M._use_checkpoint(stage)                  # a few hundred MB in use of 288 GB
-        frac, M._CHECKPOINT_FREE_FRACTION = M._CHECKPOINT_FREE_FRACTION, 1.1
+        assert not M._use_checkpoint(stage, rc, 10, dev)     # 4 GB of activations, > 250 GB free
+        assert M._use_checkpoint(stage, 100 * rc, 10, dev)   # 400 GB would not fit
+        assert M._use_checkpoint(stage)                      # no estimate: as the reference
+        frac, M._CHECKPOINT_FREE_FRACTION = M._CHECKPOINT_FREE_FRACTION, 1e-6
         try:
-            assert M._use_checkpoint(stage)                  # "less than 110 % free": always tight
+            assert M._use_checkpoint(stage, rc, 10, dev)     # nothing counts as fitting
         finally:
             M._CHECKPOINT_FREE_FRACTION = frac
         M.set_checkpoint_policy('never')
-        assert not M._use_checkpoint(stage)
+        assert not M._use_checkpoint(stage, rc, 10, dev)
         model.eval()
         M.set_checkpoint_policy('always')
-        assert not M._use_checkpoint(stage)                  # inference never checkpoints
+        assert not M._use_checkpoint(stage, rc, 10, dev)     # inference never checkpoints
     finally:
         M.set_checkpoint_policy(prev)
     assert torch.equal(res[False][0], res[True][0])

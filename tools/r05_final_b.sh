@@ -16,6 +16,7 @@ python tools/stamp_sources.py hotformerloc_amd/csrc/mlp_fused.hip >> $out/r05_ml
 tools/prof_train.sh r05_train_cs --config cs-wild-places > $out/r05_train_prof.log 2>&1
 rm -rf $out/r05_train_cs_stats
 timeout 900 python tools/train_ops_profile.py > $out/r05_train_ops.txt 2> $out/r05_train_ops.err
+HFL_CHECKPOINT=always timeout 900 python tools/train_ops_profile.py > $out/r05_train_ops_checkpointed.txt 2>> $out/r05_train_ops.err
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/r05_smoke.log 2>&1
 tail -5 $out/r05_attn_counters.txt $out/r05_fused_counters.txt $out/r05_mlp_counters.txt
 head -30 $out/r05_train_cs_summary_table.md
