@@ -221,3 +221,39 @@ def test_tall_mm_split_k_weight_gradient_equals_autograd():
                 col.grad = w.grad = b.grad = None
     finally:
         TallMmFn.CHUNK = old
+
+
+def test_ctypes_structures_match_the_c_header(tmp_path):
+    """Every struct the C-ABI passes by pointer (include/hotformerloc_hip.h) against its ctypes mirror in _native.py: a C program
+    compiled here with gcc prints sizeof and every member's offset; both must agree field by field (a silent mismatch would
+    hand the library shifted pointers)."""
+    import ctypes
+    import shutil
+    import subprocess
+    from hotformerloc_amd import _native
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    pairs = [('hfl_window_attn_desc', _native.WindowAttnDesc), ('hfl_row_segments', _native.RowSegments),
+             ('hfl_block_weights', _native.BlockWeights), ('hfl_block_io', _native.BlockIO),
+             ('hfl_relay_block_weights', _native.RelayBlockWeights), ('hfl_relay_block_io', _native.RelayBlockIO)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hotformerloc_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    subprocess.run(['gcc', '-std=c99', '-I', inc, str(src), '-o', str(exe)], check=True)
+    got = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+        a, b, c = ln.split()
+        got[a, b] = int(c)
+    for cname, cls in pairs:
+        assert got[cname, 'sizeof'] == ctypes.sizeof(cls), (cname, got[cname, 'sizeof'], ctypes.sizeof(cls))
+        n_c = sum(1 for k in got if k[0] == cname) - 1
+        assert n_c == len(cls._fields_)
+        for fname, _ in cls._fields_:
+            assert got[cname, fname] == getattr(cls, fname).offset, (cname, fname)
