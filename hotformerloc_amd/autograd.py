@@ -551,6 +551,44 @@ def mlp_x3(h, w1, b1, w2, b2):
     return MlpX3Fn.apply(h, w1, b1, w2, b2)
 
 
+# ------------------------------------------------ conditional position encoding, training forward as one launch
+class CpeFn(torch.autograd.Function):
+    """[x +] LayerNorm(dwconv(x)) (CPE.forward and its callers' residual: models/layers/octformer_layers.py:138-142,
+    models/octformer_backbone.py:258) with the inference path's fused launch as the forward -- it additionally writes the
+    convolution's output, which is all the backward needs besides x: LayerNorm backward (hfl_layer_norm_bwd), the data
+    gradient of the convolution through the inverse neighbour table and its weight gradient (libs/dwconv/dwconv/nn.py:31-43),
+    and the skip connection's gradient added to the data gradient.  Replaces three launches (dwconv, LayerNorm, add) and two
+    saved tensors' worth of passes in every block's forward."""
+
+    @staticmethod
+    def forward(ctx, x, weights, gamma, beta, neigh, residual, eps):
+        x = x.contiguous()
+        conv = torch.empty_like(x)
+        out = ops.cpe_forward(x, weights, gamma, beta, neigh, residual, eps, conv_out=conv)
+        ctx.save_for_backward(x, conv, weights, gamma, neigh)
+        ctx.residual, ctx.eps = bool(residual), eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .dwconv import _inverse_of
+        x, conv, weights, gamma, neigh = ctx.saved_tensors
+        need = ctx.needs_input_grad                    # (x, weights, gamma, beta, neigh, residual, eps)
+        dout = dout.contiguous()
+        dconv, dg, dbeta = ops.layer_norm_bwd(dout, conv, gamma, ctx.eps)
+        dx = None
+        if need[0]:
+            dx = ops.dwconv_forward_backward(dconv, weights.contiguous(), _inverse_of(neigh))
+            if ctx.residual:
+                dx += dout
+        dw = ops.dwconv_weight_backward(dconv, x, neigh) if need[1] else None
+        return dx, dw, (dg if need[2] else None), (dbeta if need[3] else None), None, None, None
+
+
+def cpe(x, weights, gamma, beta, neigh, residual: bool, eps: float):
+    return CpeFn.apply(x, weights, gamma, beta, neigh, residual, eps)
+
+
 # ------------------------------------------------ LayerNorm with HIP forward and backward
 class LayerNormFn(torch.autograd.Function):
     """LayerNorm over the channel axis: `hfl_layer_norm` forward (keeps only its input), `hfl_layer_norm_bwd` backward.

@@ -239,7 +239,8 @@ __global__ void inverse_neigh_kernel(IdxT* __restrict__ ineigh, const IdxT* __re
 // ------------------------------------------------------------------ fused CPE
 // TPR lanes own one row (C = 4*TPR); LayerNorm statistics by butterfly over TPR lanes.
 template <int TPR>
-__global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, const float* __restrict__ x,
+__global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, float* __restrict__ conv_out,
+                               const float* __restrict__ x,
                                const float* __restrict__ weight, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const int32_t* __restrict__ neigh,
                                int64_t n_rows, int K, float eps, int residual, int chunk_rows) {
@@ -341,6 +342,8 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
     float4 y = make_float4(fmaf(d.x * rstd, gm.x, bt.x), fmaf(d.y * rstd, gm.y, bt.y),
                            fmaf(d.z * rstd, gm.z, bt.z), fmaf(d.w * rstd, gm.w, bt.w));
     if (live) {
+      // (training: the convolution's output is the LayerNorm backward's input)
+      if (conv_out != nullptr) reinterpret_cast<float4*>(conv_out + h * C)[tx] = acc;
       if (residual) {
         const float4 xv = reinterpret_cast<const float4*>(x + h * C)[tx];
         y.x += xv.x; y.y += xv.y; y.z += xv.z; y.w += xv.w;
@@ -354,14 +357,14 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, c
 static int g_cpe_chunk_rows = 0;   // 0: rows interleaved over blocks; >0: contiguous chunk per block
 
 template <int TPR>
-static int launch_cpe(float* out, const float* x, const float* w, const float* gamma,
+static int launch_cpe(float* out, float* conv_out, const float* x, const float* w, const float* gamma,
                       const float* beta, const int32_t* neigh, int64_t n, int K, float eps,
                       int residual, hipStream_t s) {
   constexpr int RPB = 256 / TPR;
   const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * (sizeof(int32_t) + 1) + 16;
   const int64_t need = hfl_cdiv(n, RPB);
   const int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
-  cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, x, w, gamma, beta, neigh, n, K, eps, residual,
+  cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, conv_out, x, w, gamma, beta, neigh, n, K, eps, residual,
                                                g_cpe_chunk_rows);
   HFL_RETURN_LAST_ERROR();
 }
@@ -419,19 +422,25 @@ int hfl_inverse_neigh(void* ineigh, const void* neigh, int idx64, int64_t n_rows
   HFL_RETURN_LAST_ERROR();
 }
 
-int hfl_cpe_forward(float* out, const float* x, const float* weight, const float* gamma,
-                    const float* beta, const int32_t* neigh, int64_t n_rows, int64_t channels,
-                    int kngh, float eps, int residual, hfl_stream_t stream) {
+int hfl_cpe_forward_save(float* out, float* conv_out, const float* x, const float* weight, const float* gamma,
+                         const float* beta, const int32_t* neigh, int64_t n_rows, int64_t channels,
+                         int kngh, float eps, int residual, hfl_stream_t stream) {
   if (n_rows < 0 || kngh <= 0 || kngh > kMaxTaps) return HFL_EINVAL;
   if (n_rows == 0) return HFL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (channels) {
-    case 256: return launch_cpe<64>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-    case 128: return launch_cpe<32>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-    case 64:  return launch_cpe<16>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-    case 32:  return launch_cpe<8>(out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 256: return launch_cpe<64>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 128: return launch_cpe<32>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 64:  return launch_cpe<16>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 32:  return launch_cpe<8>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
     default:  return HFL_EINVAL;
   }
+}
+
+int hfl_cpe_forward(float* out, const float* x, const float* weight, const float* gamma,
+                    const float* beta, const int32_t* neigh, int64_t n_rows, int64_t channels,
+                    int kngh, float eps, int residual, hfl_stream_t stream) {
+  return hfl_cpe_forward_save(out, nullptr, x, weight, gamma, beta, neigh, n_rows, channels, kngh, eps, residual, stream);
 }
 
 int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table, int64_t n_dst_rows,

@@ -101,6 +101,7 @@ _EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row ha
 _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
 # LN1 -> qkv -> window attention of a relay-token block's token rows as one launch (csrc/attn_ws.hip) from this many token rows
 _RTSA_SEGMENTS = os.environ.get('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
+_TRAIN_CPE_FUSED = os.environ.get('HFL_TRAIN_CPE_FUSED', '1') != '0'  # training CPE forward as the fused launch (autograd.CpeFn)
 _RELAY_IN_PLACE = os.environ.get('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
 _ATTN_WS = os.environ.get('HFL_ATTN_WS', '0') != '0'
 _ATTN_WS_MIN_ROWS = int(os.environ.get('HFL_ATTN_WS_MIN_ROWS', '40000'))
@@ -712,6 +713,11 @@ class CPE(nn.Module):
                 out.copy_(y)
                 return out
             return y
+        if (_TRAIN_CPE_FUSED and _grad_path(data) and data.shape[1] in (32, 64, 128, 256) and data.is_cuda
+                and data.dtype == torch.float32 and out is None):
+            # training: the fused launch as the forward (it also writes the convolution's output for the backward)
+            return ag.cpe(data, self.conv.weights, self.norm.weight, self.norm.bias, plan.neigh(depth), residual,
+                          self.norm.eps)
         if _grad_path(data) or data.shape[1] not in (32, 64, 128, 256):
             # dwconv (HIP fwd/bwd, libs/dwconv semantics) -> LayerNorm -> residual (also the inference path of channel
             # widths the fused kernel is not instantiated for, e.g. 192 in per-level-width configurations)

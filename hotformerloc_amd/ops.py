@@ -166,10 +166,11 @@ def inverse_neigh(neigh: torch.Tensor):
     return out
 
 
-def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5, out=None):
+def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5, out=None, conv_out=None):
     """out = [x +] LayerNorm(dwconv(x, weight, neigh)) * gamma + beta (fused).  `out` may be a
-    preallocated contiguous (n, C) view (e.g. the token rows of a larger buffer)."""
-    _dev(x, weight, gamma, beta, neigh)
+    preallocated contiguous (n, C) view (e.g. the token rows of a larger buffer); `conv_out` (n, C) f32, optional:
+    receives dwconv(x) (the training forward keeps it for the LayerNorm backward: hfl_cpe_forward_save)."""
+    _dev(x, weight, gamma, beta, neigh, conv_out)
     x = _f32c(x)
     assert neigh.dtype == torch.int32 and neigh.is_contiguous()
     if out is None:
@@ -180,6 +181,13 @@ def cpe_forward(x, weight, gamma, beta, neigh, residual: bool, eps: float = 1e-5
     n, c = x.shape
     # algorithmic bytes: read x once, write out once, read the int32 neighbour rows
     with _timed('hfl_cpe_forward', n * c * 8 + n * neigh.shape[1] * 4, 2 * neigh.shape[1] * n * c):
+        if conv_out is not None:
+            assert conv_out.shape == x.shape and conv_out.is_contiguous() and conv_out.dtype == torch.float32
+            check(_native.load().hfl_cpe_forward_save(
+                out.data_ptr(), conv_out.data_ptr(), x.data_ptr(), _f32c(weight).data_ptr(), _f32c(gamma).data_ptr(),
+                _f32c(beta).data_ptr(), neigh.data_ptr(), n, c, neigh.shape[1],
+                float(eps), int(bool(residual)), _stream()), 'hfl_cpe_forward_save')
+            return out
         check(_native.load().hfl_cpe_forward(
             out.data_ptr(), x.data_ptr(), _f32c(weight).data_ptr(), _f32c(gamma).data_ptr(),
             _f32c(beta).data_ptr(), neigh.data_ptr(), n, c, neigh.shape[1],

@@ -77,6 +77,13 @@ int hfl_cpe_forward(float* out, const float* x, const float* weight, const float
                     const float* beta, const int32_t* neigh, int64_t n_rows,
                     int64_t channels, int kngh, float eps, int residual,
                     hfl_stream_t stream);
+/* The same launch for the training forward: additionally writes conv_out (n, C) = dwconv(x), the input of the LayerNorm
+ * backward (hfl_layer_norm_bwd_add), so that loss.backward() through CPE (training/trainer.py:344-362) needs no second
+ * pass over the neighbourhoods; conv_out = NULL is hfl_cpe_forward. */
+int hfl_cpe_forward_save(float* out, float* conv_out, const float* x, const float* weight, const float* gamma,
+                         const float* beta, const int32_t* neigh, int64_t n_rows,
+                         int64_t channels, int kngh, float eps, int residual,
+                         hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 2. Octree construction  (replaces ocnn.octree.Octree.build_octree /

@@ -323,6 +323,47 @@ def test_cpe_fused_and_gather():
         assert torch.equal(got, want)
 
 
+def test_cpe_training_function_matches_fp64_autograd_of_the_reference_formula():
+    """autograd.CpeFn (the fused CPE launch as the training forward, keeping the convolution's output; backward = LayerNorm
+    backward + dwconv data / weight gradients + the skip gradient) against fp64 torch autograd through the reference's
+    formula  [x +] LayerNorm(sum_k w[k] * x[neigh[:, k]])  (models/layers/octformer_layers.py:138-142,
+    libs/dwconv/dwconv/nn.py:17-43), and against the three-launch training path it replaces."""
+    from hotformerloc_amd import autograd as ag
+    from hotformerloc_amd import dwconv as hdw
+    clouds = [syn.unit_ball_cloud(31, 3000), syn.unit_ball_cloud(32, 1800)]
+    dev = build_batch_octree(clouds, 7, 2, DEV)
+    g = torch.Generator(device='cuda').manual_seed(4)
+    for depth, C in ((5, 128), (4, 256), (3, 256)):
+        neigh = dev.get_neigh(depth, '333', 1, True).contiguous()
+        n = neigh.shape[0]
+        for residual in (True, False):
+            leaves = [torch.randn(n, C, device='cuda', generator=g), torch.randn(27, 1, C, device='cuda', generator=g) * 0.3,
+                      1 + 0.1 * torch.randn(C, device='cuda', generator=g), 0.1 * torch.randn(C, device='cuda', generator=g)]
+            proj = torch.randn(n, C, device='cuda', generator=g)
+
+            def run(kind):
+                x, w, gm, bt = [t.detach().clone().double().requires_grad_() if kind == 'ref' else t.detach().clone().requires_grad_()
+                                for t in leaves]
+                if kind == 'fused':
+                    y = ag.cpe(x, w, gm, bt, neigh, residual, 1e-5)
+                elif kind == 'three':
+                    y = ag.layer_norm(hdw.octree_dwconv(x, w, neigh), gm, bt, 1e-5)
+                    y = x + y if residual else y
+                else:
+                    idx = neigh.long()
+                    col = torch.cat([x, x.new_zeros(1, C)], 0)[torch.where(idx >= 0, idx, n)]      # (n, 27, C)
+                    conv = (col * w.view(1, 27, C)).sum(1)
+                    y = torch.nn.functional.layer_norm(conv, (C,), gm, bt, 1e-5)
+                    y = x + y if residual else y
+                (y * (proj.double() if kind == 'ref' else proj)).sum().backward()
+                return [y.detach()] + [t.grad for t in (x, w, gm, bt)]
+            ref, fused, three = run('ref'), run('fused'), run('three')
+            for name, r, f, t in zip(('out', 'dx', 'dw', 'dgamma', 'dbeta'), ref, fused, three):
+                scale = r.abs().max().item()
+                ef, et = (f.double() - r).abs().max().item() / scale, (t.double() - r).abs().max().item() / scale
+                assert ef < 2e-5 and et < 2e-5, (depth, C, residual, name, ef, et)
+
+
 # ---------------------------------------------------------------------- attention
 def _plans(clouds, cfg, octree_depth):
     params, _ = load_config(cfg)
