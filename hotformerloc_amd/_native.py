@@ -81,6 +81,7 @@ SIGNATURES = {
                                 c_int64, c_int, c_float, c_int, c_void_p]),
     'hfl_cpe_forward_save': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_int64, c_int, c_float, c_int, c_void_p]),
+    'hfl_dwconv_add': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'hfl_octree_scratch_bytes': (c_int64, [c_int64, c_int, c_int, c_int]),
     'hfl_octree_build_clouds': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -8,6 +8,8 @@ The reference gets all of this from PyTorch autograd over its materialised masks
 
 import ctypes
 
+import os
+
 import torch
 
 from . import _native, ops
@@ -552,6 +554,9 @@ def mlp_x3(h, w1, b1, w2, b2):
 
 
 # ------------------------------------------------ conditional position encoding, training forward as one launch
+_CPE_BWD_GATHER = os.environ.get('HFL_TRAIN_CPE_BWD_GATHER', '1') != '0'
+
+
 class CpeFn(torch.autograd.Function):
     """[x +] LayerNorm(dwconv(x)) (CPE.forward and its callers' residual: models/layers/octformer_layers.py:138-142,
     models/octformer_backbone.py:258) with the inference path's fused launch as the forward -- it additionally writes the
@@ -577,7 +582,10 @@ class CpeFn(torch.autograd.Function):
         dout = dout.contiguous()
         dconv, dg, dbeta = ops.layer_norm_bwd(dout, conv, gamma, ctx.eps)
         dx = None
-        if need[0]:
+        if need[0] and _CPE_BWD_GATHER and x.shape[1] in (32, 64, 128, 256) and neigh.dtype == torch.int32:
+            # the same gather as the forward, over the inverse table, the skip gradient added in its epilogue
+            dx = ops.dwconv_add(dconv, weights, _inverse_of(neigh), dout if ctx.residual else None)
+        elif need[0]:
             dx = ops.dwconv_forward_backward(dconv, weights.contiguous(), _inverse_of(neigh))
             if ctx.residual:
                 dx += dout

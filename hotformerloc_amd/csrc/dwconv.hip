@@ -238,9 +238,11 @@ __global__ void inverse_neigh_kernel(IdxT* __restrict__ ineigh, const IdxT* __re
 
 // ------------------------------------------------------------------ fused CPE
 // TPR lanes own one row (C = 4*TPR); LayerNorm statistics by butterfly over TPR lanes.
-template <int TPR>
+// NORM = false: the convolution alone, out = dwconv(x) [+ add] (the data gradient of the training path: x = the incoming
+// gradient, neigh = the inverse table, add = the skip connection's gradient).
+template <int TPR, bool NORM>
 __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, float* __restrict__ conv_out,
-                               const float* __restrict__ x,
+                               const float* __restrict__ x, const float* __restrict__ add,
                                const float* __restrict__ weight, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const int32_t* __restrict__ neigh,
                                int64_t n_rows, int K, float eps, int residual, int chunk_rows) {
@@ -253,8 +255,8 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, f
   const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
   for (int i = threadIdx.x; i < K * TPR; i += blockDim.x)
     s_w[i] = reinterpret_cast<const float4*>(weight)[i];
-  const float4 gm = reinterpret_cast<const float4*>(gamma)[tx];
-  const float4 bt = reinterpret_cast<const float4*>(beta)[tx];
+  const float4 gm = NORM ? reinterpret_cast<const float4*>(gamma)[tx] : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 bt = NORM ? reinterpret_cast<const float4*>(beta)[tx] : make_float4(0.f, 0.f, 0.f, 0.f);
 
   // iteration space: `it` enumerates groups of RPB rows.  chunk_rows == 0: group it of block b is
   // b + it*gridDim (interleaved).  chunk_rows > 0: a block owns chunk_rows consecutive rows at a time
@@ -334,18 +336,21 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, f
         }
       }
     }
-    const float inv_c = 1.0f / (float)C;
-    const float mean = hfl_group_sum<TPR>((acc.x + acc.y) + (acc.z + acc.w)) * inv_c;
-    const float4 d = make_float4(acc.x - mean, acc.y - mean, acc.z - mean, acc.w - mean);
-    const float var = hfl_group_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * inv_c;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    float4 y = make_float4(fmaf(d.x * rstd, gm.x, bt.x), fmaf(d.y * rstd, gm.y, bt.y),
-                           fmaf(d.z * rstd, gm.z, bt.z), fmaf(d.w * rstd, gm.w, bt.w));
+    float4 y = acc;
+    if (NORM) {
+      const float inv_c = 1.0f / (float)C;
+      const float mean = hfl_group_sum<TPR>((acc.x + acc.y) + (acc.z + acc.w)) * inv_c;
+      const float4 d = make_float4(acc.x - mean, acc.y - mean, acc.z - mean, acc.w - mean);
+      const float var = hfl_group_sum<TPR>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * inv_c;
+      const float rstd = 1.0f / sqrtf(var + eps);
+      y = make_float4(fmaf(d.x * rstd, gm.x, bt.x), fmaf(d.y * rstd, gm.y, bt.y),
+                      fmaf(d.z * rstd, gm.z, bt.z), fmaf(d.w * rstd, gm.w, bt.w));
+    }
     if (live) {
       // (training: the convolution's output is the LayerNorm backward's input)
-      if (conv_out != nullptr) reinterpret_cast<float4*>(conv_out + h * C)[tx] = acc;
+      if (NORM && conv_out != nullptr) reinterpret_cast<float4*>(conv_out + h * C)[tx] = acc;
       if (residual) {
-        const float4 xv = reinterpret_cast<const float4*>(x + h * C)[tx];
+        const float4 xv = reinterpret_cast<const float4*>(add + h * C)[tx];
         y.x += xv.x; y.y += xv.y; y.z += xv.z; y.w += xv.w;
       }
       reinterpret_cast<float4*>(out + h * C)[tx] = y;
@@ -356,16 +361,16 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, f
 
 static int g_cpe_chunk_rows = 0;   // 0: rows interleaved over blocks; >0: contiguous chunk per block
 
-template <int TPR>
-static int launch_cpe(float* out, float* conv_out, const float* x, const float* w, const float* gamma,
+template <int TPR, bool NORM>
+static int launch_cpe(float* out, float* conv_out, const float* x, const float* add, const float* w, const float* gamma,
                       const float* beta, const int32_t* neigh, int64_t n, int K, float eps,
                       int residual, hipStream_t s) {
   constexpr int RPB = 256 / TPR;
   const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * (sizeof(int32_t) + 1) + 16;
   const int64_t need = hfl_cdiv(n, RPB);
   const int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
-  cpe_fwd_kernel<TPR><<<blocks, 256, lds, s>>>(out, conv_out, x, w, gamma, beta, neigh, n, K, eps, residual,
-                                               g_cpe_chunk_rows);
+  cpe_fwd_kernel<TPR, NORM><<<blocks, 256, lds, s>>>(out, conv_out, x, add, w, gamma, beta, neigh, n, K, eps, residual,
+                                                     g_cpe_chunk_rows);
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -429,10 +434,25 @@ int hfl_cpe_forward_save(float* out, float* conv_out, const float* x, const floa
   if (n_rows == 0) return HFL_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (channels) {
-    case 256: return launch_cpe<64>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-    case 128: return launch_cpe<32>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-    case 64:  return launch_cpe<16>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
-    case 32:  return launch_cpe<8>(out, conv_out, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 256: return launch_cpe<64, true>(out, conv_out, x, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 128: return launch_cpe<32, true>(out, conv_out, x, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 64:  return launch_cpe<16, true>(out, conv_out, x, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    case 32:  return launch_cpe<8, true>(out, conv_out, x, x, weight, gamma, beta, neigh, n_rows, kngh, eps, residual, s);
+    default:  return HFL_EINVAL;
+  }
+}
+
+int hfl_dwconv_add(float* out, const float* data, const float* weight, const int32_t* neigh, const float* add,
+                   int64_t n_out, int64_t channels, int kngh, hfl_stream_t stream) {
+  if (n_out < 0 || kngh <= 0 || kngh > kMaxTaps || out == data || out == nullptr) return HFL_EINVAL;
+  if (n_out == 0) return HFL_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int res = add != nullptr ? 1 : 0;
+  switch (channels) {
+    case 256: return launch_cpe<64, false>(out, nullptr, data, add, weight, nullptr, nullptr, neigh, n_out, kngh, 0.f, res, s);
+    case 128: return launch_cpe<32, false>(out, nullptr, data, add, weight, nullptr, nullptr, neigh, n_out, kngh, 0.f, res, s);
+    case 64:  return launch_cpe<16, false>(out, nullptr, data, add, weight, nullptr, nullptr, neigh, n_out, kngh, 0.f, res, s);
+    case 32:  return launch_cpe<8, false>(out, nullptr, data, add, weight, nullptr, nullptr, neigh, n_out, kngh, 0.f, res, s);
     default:  return HFL_EINVAL;
   }
 }

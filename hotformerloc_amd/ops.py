@@ -139,6 +139,23 @@ def dwconv_forward_backward(data: torch.Tensor, weight: torch.Tensor, neigh: tor
     return out
 
 
+def dwconv_add(data: torch.Tensor, weight: torch.Tensor, neigh: torch.Tensor, add=None):
+    """dwconv(data, weight, neigh) [+ add] through the CPE kernel's gather (hfl_dwconv_add): int32 table, C in {32, 64, 128,
+    256}; the data gradient of CPE (neigh = the inverse table, add = the skip connection's gradient)."""
+    _dev(data, weight, neigh, add)
+    data, weight = _f32c(data), _f32c(weight)
+    assert neigh.dtype == torch.int32 and neigh.is_contiguous()
+    m, k = neigh.shape
+    c = data.shape[1]
+    out = torch.empty((m, c), dtype=torch.float32, device=data.device)
+    if add is not None:
+        add = _f32c(add)
+        assert tuple(add.shape) == (m, c)
+    check(_native.load().hfl_dwconv_add(out.data_ptr(), data.data_ptr(), weight.data_ptr(), neigh.data_ptr(),
+                                        None if add is None else add.data_ptr(), m, c, k, _stream()), 'hfl_dwconv_add')
+    return out
+
+
 def dwconv_weight_backward(grad: torch.Tensor, data: torch.Tensor, neigh: torch.Tensor):
     """libs/dwconv/csrc/dwconv.h:14 -- -> (K,1,C)."""
     _dev(grad, data, neigh)

@@ -84,6 +84,12 @@ int hfl_cpe_forward_save(float* out, float* conv_out, const float* x, const floa
                          const float* beta, const int32_t* neigh, int64_t n_rows,
                          int64_t channels, int kngh, float eps, int residual,
                          hfl_stream_t stream);
+/* The convolution alone through the same gather (live taps compacted per row): out = dwconv(data, weight, neigh) [+ add].
+ * The data gradient of CPE in loss.backward(): data = gradient of the convolution's output, neigh = the INVERSE neighbour
+ * table (hfl_inverse_neigh, libs/dwconv/dwconv/nn.py:36-38), add = the skip connection's gradient (or NULL).
+ * int32 tables, C in {32, 64, 128, 256}, kngh <= 27; out must not alias data. */
+int hfl_dwconv_add(float* out, const float* data, const float* weight, const int32_t* neigh, const float* add,
+                   int64_t n_out, int64_t channels, int kngh, hfl_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 2. Octree construction  (replaces ocnn.octree.Octree.build_octree /
