@@ -1603,6 +1603,7 @@ void hfl_internal_set_mlp_dbg(int v);
 void hfl_internal_set_mlp_tail_split(int v);
 void hfl_internal_set_mlp_dynamic(int v);
 void hfl_internal_set_attn_fused_split(int v);
+void hfl_internal_set_ws_map(int v);
 #ifdef HFL_PROBES
 void hfl_internal_set_ws_dbg(int v);
 #endif
@@ -1665,6 +1666,8 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_mlp_dynamic(1);
   } else if (is("attn_fused_split")) {
     hfl_internal_set_attn_fused_split(value);
+  } else if (is("ws_map")) {
+    hfl_internal_set_ws_map(value);
 #ifdef HFL_PROBES
   } else if (is("ws_dbg")) {
     hfl_internal_set_ws_dbg(value);

@@ -51,6 +51,7 @@ constexpr int WROWS = 96;            // token rows per workgroup tile
 constexpr int WGW = 6;               // GEMM waves
 constexpr int WAW = 8;               // attention waves (two per SIMD: a unit is a chain of LDS round trips, two waves cover each other)
 constexpr int WW = WGW + WAW;
+constexpr int WLAUNCH = 16;           // waves launched (four per SIMD): two of them leave at once, see WsParams::map
 constexpr int WKS = WC / 32;         // k-steps of the qkv GEMM
 constexpr int WSTAGE = WC * 64;      // bytes of a weight stage: 8 k-steps x 16 features x 128 B
 constexpr int WNSLOT = 3;
@@ -88,6 +89,7 @@ struct WsParams {
   int batch;
   float eps;
   float q_scale;
+  int map;                         // wave -> role map (see the kernel)
 #ifdef HFL_PROBES
   int dbg;                         // timing ablations (wrong results): 1 no attention work, 2 no GEMM k-loop, 4 no weight stream, 8 no relay units
 #endif
@@ -157,13 +159,23 @@ struct WsJob {
 };
 
 template <int RPE>
-__global__ void __launch_bounds__(WW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(WLAUNCH * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 attn_ws_kernel(const WsParams p) {
   typedef __attribute__((address_space(3))) const float lds_f32;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool gemm_wave = wave < WGW;
+  // role of the hardware wave (waves go to SIMD id % 4 in launch order): map 0 = GEMM waves 0..5 (two on SIMDs 0 / 1, one on
+  // 2 / 3), attention waves 6..13 (two per SIMD); map 1 = the attention waves where the GEMM waves are not: three on SIMDs 2 / 3
+  // (hardware waves 6, 7, 10, 11, 14, 15), one on SIMDs 0 / 1 (8, 9).  The two waves without a role leave after the
+  // first barrier.
+  int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.map == 1) {
+    const int hw = wave;
+    wave = hw < 8 ? hw : hw < 10 ? hw + 4 : hw < 12 ? hw - 2 : hw < 14 ? -1 : hw - 4;
+  } else if (wave >= WW) {
+    wave = -1;
+  }
+  const bool gemm_wave = wave >= 0 && wave < WGW;
   const int fr = lane & 15, fq = lane >> 4;          // GEMM: row of the wave's tile, k / feature quarter
   const int c = lane & 15, g = lane >> 4;            // attention: column of a 16-tile, 4-row group
   float* s_tab = reinterpret_cast<float*>(w_lds + WL_TAB);
@@ -176,12 +188,13 @@ attn_ws_kernel(const WsParams p) {
   const int TS = RPE ? ((3 * W + 3) & ~3) : 0;
   const int n_tok = (int)p.n_tokens;
 
-  for (int i = tid; i < 3 * WC / 4; i += WW * 64) reinterpret_cast<float4*>(bs)[i] = reinterpret_cast<const float4*>(p.bias)[i];
-  for (int i = tid; i < WC / 4; i += WW * 64) {
+  for (int i = tid; i < 3 * WC / 4; i += WLAUNCH * 64) reinterpret_cast<float4*>(bs)[i] = reinterpret_cast<const float4*>(p.bias)[i];
+  for (int i = tid; i < WC / 4; i += WLAUNCH * 64) {
     reinterpret_cast<float4*>(gms)[i] = reinterpret_cast<const float4*>(p.gamma)[i];
     reinterpret_cast<float4*>(bts)[i] = reinterpret_cast<const float4*>(p.beta)[i];
   }
   __syncthreads();
+  if (wave < 0) return;
 
   const int n_units = p.full_tiles + (p.n_tiles - p.full_tiles) * p.tail_parts;
   auto unit_of = [&](int unit, int& tile, int& pr0, int& npr) {
@@ -648,6 +661,8 @@ struct WsTimingRec {
   double bytes, flops_gemm, flops_attn;
 };
 static int g_ws_timing = 0;
+static int g_ws_map = 0;
+extern "C" void hfl_internal_set_ws_map(int v) { g_ws_map = v == 1 ? 1 : 0; }
 #ifdef HFL_PROBES
 static int g_ws_dbg = 0;
 extern "C" void hfl_internal_set_ws_dbg(int v) { g_ws_dbg = v; }
@@ -685,7 +700,7 @@ int hfl_attn_ws_fwd(void* out_split2, const float* x, const float* gamma, const 
   // of K x the stage dilation, models/octree.py:73-75 -- have a relay row too)
   const int64_t t_tok = hfl_cdiv(d->n_tokens, WROWS), t_win = hfl_cdiv(d->n_windows, WNWIN);
   p.n_tiles = (int)(t_tok > t_win ? t_tok : t_win); p.depth = d->depth;
-  p.batch = d->batch_size; p.eps = eps; p.q_scale = q_scale;
+  p.batch = d->batch_size; p.eps = eps; p.q_scale = q_scale; p.map = g_ws_map;
 #ifdef HFL_PROBES
   p.dbg = g_ws_dbg;
 #endif
@@ -718,8 +733,8 @@ int hfl_attn_ws_fwd(void* out_split2, const float* x, const float* gamma, const 
       return HFL_EINVAL;
     }
   }
-  if (p.rpe2 != nullptr) attn_ws_kernel<1><<<grid, WW * 64, 0, s>>>(p);
-  else attn_ws_kernel<0><<<grid, WW * 64, 0, s>>>(p);
+  if (p.rpe2 != nullptr) attn_ws_kernel<1><<<grid, WLAUNCH * 64, 0, s>>>(p);
+  else attn_ws_kernel<0><<<grid, WLAUNCH * 64, 0, s>>>(p);
   if (timed) {
     (void)hipEventRecord(rec.e1, s);
     std::lock_guard<std::mutex> lk(g_ws_mu);
