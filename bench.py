@@ -34,7 +34,8 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
                  eighth of the host's logical CPUs: --pin-cores); every leg's `host_issue` = host time to queue the K steps vs
                  their wall time
 and then, outside any timed value: the `roofline` legs (HIP events per launch: the fp16 window kernel, `roofline_fused` for the
-one-kernel LayerNorm -> qkv -> attention launch of the OctFormer stage, `roofline_fp32` for the fp32 leg) and the `cpu_baseline`
+one-kernel LayerNorm -> qkv -> attention launch of the OctFormer stage, `roofline_ws` for the one with relay tokens of the
+finest pyramid level, `roofline_fp32` for the fp32 leg) and the `cpu_baseline`
 (the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol) whose descriptors are also the
 `parity` reference of the timed workload's GPU descriptors (BASELINE metric: "descriptor L2 vs ref").
 """
@@ -416,7 +417,7 @@ def main():
                 'ms_per_step': round(dt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup}
 
     extras = world == 1 and not args.train and not args.no_extras
-    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = fused_roof = mlp_roof = None
+    resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = fused_roof = ws_roof = mlp_roof = None
     with (torch.enable_grad() if args.train else torch.inference_mode()):
         # ---- the headline: W warm-ups, K timed steps, nothing instrumented inside the timed region
         elapsed = timed(step, args.steps, args.warmup, tag='value')
@@ -475,6 +476,7 @@ def main():
                     rec, iso_sizes = native_attention_timing(step, args.steps)
                     kern_iso = {ATTN: rec}
                     fused_roof = native_fused_timing(step, args.steps)
+                    ws_roof = native_ws_timing(step, args.steps)
                     # the fused MLP launches (the step's largest kernel group) alone, same one-stream schedule
                     with ops.KernelTimer(only=['hfl_ln_mlp_fused']) as t_mlp:
                         for _ in range(args.steps):
@@ -559,6 +561,8 @@ def main():
             line['roofline_fp32'] = roof32
         if fused_roof:
             line['roofline_fused'] = fused_roof
+        if ws_roof:
+            line['roofline_ws'] = ws_roof
         if mlp_roof:
             line['roofline_mlp'] = mlp_roof
         if per_rank is not None:
@@ -730,6 +734,48 @@ def native_fused_timing(step, steps):
                     'note': 'x in + split2 out = 8 B per (row, channel) + 8 B of metadata per token; the two launches it '
                             'replaces move 24 B per (row, channel)'},
             'mfma_busy_pmc': pmc_mfma_busy('r05_fused_counters.txt') or pmc_mfma_busy('r04_fused_counters.txt'),
+            'timing': 'HIP event pair around every launch, recorded by the library, serialised schedule, after the timed region'}
+
+
+def native_ws_timing(step, steps):
+    """HIP-event timing of the hfl_attn_ws_fwd launches (LN -> qkv -> window attention with relay tokens in one kernel: the
+    finest pyramid level's blocks) of `steps` steps; None when the step issues none."""
+    import ctypes
+    import torch
+    from hotformerloc_amd import _native
+    lib = _native.load()
+    lib.hfl_internal_ws_timing.argtypes = [ctypes.c_int]
+    lib.hfl_internal_ws_timing_read.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int]
+    lib.hfl_internal_ws_timing(1)
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        cap = 1 << 14
+        ms, nb, fg, fa = ((ctypes.c_double * cap)() for _ in range(4))
+        n = lib.hfl_internal_ws_timing_read(ms, nb, fg, fa, cap)
+    finally:
+        lib.hfl_internal_ws_timing(0)
+    if n <= 0:
+        return None
+    n = min(n, cap)
+    t = sum(ms[i] for i in range(n)) * 1e-3
+    useful = sum(fg[i] + fa[i] for i in range(n))
+    issued = sum(3.0 * fg[i] + 3.5 * fa[i] for i in range(n))
+    nbytes = sum(nb[i] for i in range(n))
+    return {'kernel': 'hfl_attn_ws_fwd', 'what': 'LayerNorm -> qkv -> window attention (48 tokens + the relay token per window) in '
+            'ONE kernel with specialised GEMM / attention waves, q / k / v never in HBM (pyramid blocks of the finest level: '
+            'C = 256, 16 heads); token rows bitwise equal to hfl_ln_qkv_fused + the fp16 window kernel', 'bound': 'mfma',
+            'unit': 'TFLOP/s', 'peak': MFMA_F16_PEAK_TFLOPS, 'achieved': round(issued / t / 1e12, 1),
+            'frac': round(issued / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            'useful_tflops_fp32_equivalent': round(useful / t / 1e12, 2),
+            'useful_over_f32_mfma_peak': round(useful / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
+            'hbm': {'algorithmic_bytes_per_launch': int(nbytes / n), 'GBps': round(nbytes / t / 1e9, 1),
+                    'frac_of_8TBps': round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+                    'note': 'x in + split2 out = 8 B per (row, channel) + metadata + the relay rows\' operands; the two '
+                            'launches it replaces move 24 B per (row, channel)'},
+            'mfma_busy_pmc': pmc_mfma_busy('r05_ws_counters.txt'),
             'timing': 'HIP event pair around every launch, recorded by the library, serialised schedule, after the timed region'}
 
 

@@ -103,8 +103,9 @@ _DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-d
 _RTSA_SEGMENTS = os.environ.get('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
 _TRAIN_CPE_FUSED = os.environ.get('HFL_TRAIN_CPE_FUSED', '1') != '0'  # training CPE forward as the fused launch (autograd.CpeFn)
 _RELAY_IN_PLACE = os.environ.get('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
-_ATTN_WS = os.environ.get('HFL_ATTN_WS', '0') != '0'
+_ATTN_WS = os.environ.get('HFL_ATTN_WS', '1') != '0'
 _ATTN_WS_MIN_ROWS = int(os.environ.get('HFL_ATTN_WS_MIN_ROWS', '40000'))
+_ATTN_WS_EARLY = os.environ.get('HFL_ATTN_WS_EARLY', '0') != '0'   # keep the early-phase schedule beside it (A/B, tests)
 _MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
 
 
@@ -881,6 +882,12 @@ def _native_block_static(block, device):
     return res
 
 
+def _attn_ws_wanted(att, rows: int, nt: int, n_windows: int, depth: int) -> bool:
+    """Whether a relay-token block of this shape takes the one-launch LN1 -> qkv -> window attention (csrc/attn_ws.hip)."""
+    return (_ATTN_WS and att.rpe is not None and rows > nt >= _ATTN_WS_MIN_ROWS and att.dilation == 1
+            and att.rt_per_window == 1 and ops.attn_ws_ok(nt, n_windows, att.patch_size, att.num_heads, depth, att.dim))
+
+
 def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     """A prepared native call for the block's inference forward (ops.BlockCall), or None when this block / launch is not
     eligible (then the Python sequence of the same kernels runs).  Same kernels, same order, same results; only the host
@@ -910,9 +917,7 @@ def _native_block_call(block, x_in, plan: WindowPlan, depth: int):
     w.qkv_pack = None if qpack is None else qpack.data_ptr()
     w.fuse_attention = (1 if _ATTN_FUSED else 0) | (0 if _RELAY_IN_PLACE else 4)
     tables3 = None
-    if (_ATTN_WS and qpack is not None and table is not None and rows > nt >= _ATTN_WS_MIN_ROWS
-            and att.dilation == 1 and att.rt_per_window == 1
-            and ops.attn_ws_ok(nt, plan.n_windows[depth], att.patch_size, att.num_heads, depth, C)):
+    if qpack is not None and _attn_ws_wanted(att, rows, nt, plan.n_windows[depth], depth):
         tables3 = ops.rpe_expand(table, att.num_heads, bnd, depth, 2)
         w.fuse_attention |= 2
     w.rpe_tables3 = None if tables3 is None else tables3.data_ptr()
@@ -1309,7 +1314,25 @@ class HOTFormerStage(nn.Module):
             return out, (self.up_projections[j][i](out[nt:]) if proj else out[nt:])
 
         early = _EARLY_PHASE and _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda and not ckpt
+        if early and not _ATTN_WS_EARLY and self._finest_level_fuses_attention(bufs[depths[0]], plan, depths[0]):
+            # The finest level's LN1 -> qkv -> window attention is ONE launch there (csrc/attn_ws.hip) and needs the relay
+            # rows: nothing but its CPE could run beside the relay-token block, and the persistent launch starves the coarse
+            # levels' early phases.  RTSA first, then the levels side by side: +2-4 % on three boxes
+            # (profiles/r05_w_ab_attn_ws_default.log); with the early phases kept the one-launch form gains nothing.
+            early = False
         return self._iterations(data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa)
+
+    def _finest_level_fuses_attention(self, buf, plan: WindowPlan, depth: int) -> bool:
+        """The conditions under which _native_block_call gives the finest level's blocks the one-launch attention branch
+        (without preparing a call)."""
+        blk = self.hosa_blocks[0][0]
+        att = blk.attention
+        nt = plan.n_tokens[depth]
+        if not (_NATIVE_BLOCK and _GEMM_MODE == 'x3' and _ATTN_F16 and _split_path(buf) and ops.KernelTimer.active is None
+                and not blk.use_layer_scale and not _drops(blk) and not blk.cpe.xcpe and buf.dtype == torch.float32
+                and _attn_f16_ok(buf.shape[0], att, depth)):
+            return False
+        return _attn_ws_wanted(att, buf.shape[0], nt, plan.n_windows[depth], depth) and _qkv_pack(att, nt) is not None
 
     def _iterations(self, data, plan, depths, bufs, rts, nts, proj, ckpt, early, hosa):
         done = None          # early schedule: per-level end-of-iteration events of the previous iteration

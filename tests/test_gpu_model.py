@@ -462,10 +462,12 @@ def test_early_phase_schedule_equals_the_sequential_one():
 
 @pytest.mark.gpu
 def test_attn_ws_block_path_matches_the_two_launch_path():
-    """HFL_ATTN_WS: LN1 -> qkv -> window attention of the relay-token blocks' token rows as ONE launch (hfl_attn_ws_fwd behind
-    hfl_block_forward_x3, phase 1 = the CPE alone) against the default two launches, in the early-phase schedule and the
-    sequential one: the same arithmetic per score except the relative-position term (three 1-D tables summed per score
-    against the two-lookup form), so the descriptors agree to rounding; early and sequential are bitwise equal to each other."""
+    """LN1 -> qkv -> window attention of the relay-token blocks' token rows as ONE launch (hfl_attn_ws_fwd behind
+    hfl_block_forward_x3, phase 1 = the CPE alone; the default for the finest level from 40 k token rows, here forced on every
+    level) against the two launches: the same arithmetic per score except the relative-position term (three 1-D tables summed
+    per score against the two-lookup form), so the descriptors agree to rounding.  The stage leaves the early-phase schedule
+    by itself when the finest level takes the one-launch form; forced to keep it (block phases 1 / 2) the result is bitwise
+    the sequential one."""
     from hotformerloc_amd import model as M
     params, depth = load_config('wild-places')
     model = model_factory(params)
@@ -473,14 +475,24 @@ def test_attn_ws_block_path_matches_the_two_launch_path():
     model = model.cuda().eval()
     octree = build_batch_octree(syn.make_clouds(93, 4, 2500, params.coordinates), depth, 2, 'cuda')
     out = {}
-    for ws, early in ((False, True), (True, True), (True, False)):
-        M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE = ws, 0, early
-        try:
+    saved = (M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE, M._ATTN_WS_EARLY)
+    calls = []
+    orig = M.HOTFormerStage._iterations
+    M.HOTFormerStage._iterations = lambda self, *a: (calls.append(a[8]), orig(self, *a))[1]      # a[8] = `early`
+    try:
+        # (two launches, early) | (one launch, early phases forced: block phases 1 / 2 with the CPE alone in phase 1) |
+        # (one launch, sequential) | (one launch, default: the stage leaves the early-phase schedule by itself)
+        for key, ws, early, keep in (((False, True), False, True, False), ((True, True), True, True, True),
+                                     ((True, False), True, False, False), ('auto', True, True, False)):
+            M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE, M._ATTN_WS_EARLY = ws, 0, early, keep
             with torch.no_grad():
-                out[ws, early] = model({'octree': octree})['global']
+                out[key] = model({'octree': octree})['global']
             torch.cuda.synchronize()
-        finally:
-            M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE = False, 40000, True
+    finally:
+        M._ATTN_WS, M._ATTN_WS_MIN_ROWS, M._EARLY_PHASE, M._ATTN_WS_EARLY = saved
+        M.HOTFormerStage._iterations = orig
+    assert calls == [True, True, False, False], calls
+    assert torch.equal(out['auto'], out[True, False])
     assert torch.equal(out[True, True], out[True, False])
     a, b = out[False, True].double(), out[True, True].double()
     rel = ((a - b).norm(dim=1) / a.norm(dim=1)).max().item()

@@ -79,12 +79,12 @@ def main(cfg):
             return (v[:, :, 0] + v[:, :, 1]).reshape(W, C)
         rerr = (val(a) - val(f)).abs().max().item()
         t2, t1, tr = timeit(two), timeit(one), timeit(relay_qkv)
-        lib.hfl_set_variant(b'ws_map', 1)             # attention waves on the SIMDs that carry one GEMM wave
+        lib.hfl_set_variant(b'ws_map', 0)             # attention waves two per SIMD (map 1, the default: where the GEMM waves are not)
         f1 = one()
         same = torch.equal(f1.view(torch.int16), f.view(torch.int16))
         t1b = timeit(one)
-        lib.hfl_set_variant(b'ws_map', 0)
-        print('   wave map 1: %.1f us (map 0: %.1f), output identical: %s' % (t1b, t1, same), flush=True)
+        lib.hfl_set_variant(b'ws_map', 1)
+        print('   wave map 0: %.1f us (map 1: %.1f), output identical: %s' % (t1b, t1, same), flush=True)
         if os.environ.get('HFL_WS_ABLATE', '0') != '0':        # timing ablations (wrong results): see WsParams::dbg
             abl = []
             for dbg in (1, 2, 3, 4, 7, 8):
