@@ -11,6 +11,9 @@ tools/pmc_survey2.sh r05_fused attn_fused_kernel tools/attn_fused_probe.py > $ou
 tools/pmc_survey2.sh r05_mlp ln_mlp_fused_kernel tools/mlp_fused_one.py 65536 256 > $out/r05_mlp_counters.txt 2>&1
 rm -rf $out/survey_r05_attn_g* $out/survey_r05_fused_g* $out/survey_r05_mlp_g*
 python tools/stamp_sources.py hotformerloc_amd/csrc/attention.hip >> $out/r05_attn_counters.txt
+tools/attn_ws_counters.sh r05 > $out/r05_ws_counters.log 2>&1
+mv $out/r05_attn_ws_counters.txt $out/r05_ws_counters.txt
+python tools/stamp_sources.py hotformerloc_amd/csrc/attn_ws.hip >> $out/r05_ws_counters.txt
 python tools/stamp_sources.py hotformerloc_amd/csrc/attn_fused.hip >> $out/r05_fused_counters.txt
 python tools/stamp_sources.py hotformerloc_amd/csrc/mlp_fused.hip >> $out/r05_mlp_counters.txt
 tools/prof_train.sh r05_train_cs --config cs-wild-places > $out/r05_train_prof.log 2>&1
