@@ -33,7 +33,8 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
   unpinned_host  the headline step with the CPU affinity left alone, in a child process (the headline itself runs on its rank's
                  eighth of the host's logical CPUs: --pin-cores); every leg's `host_issue` = host time to queue the K steps vs
                  their wall time
-and then, outside any timed value: the `roofline` legs (HIP events per launch: the fp16 window kernel, `roofline_fused` for the
+and then, outside any timed value: the `roofline` legs (HIP events per launch: `roofline` = the step's dominant kernel, the
+fused MLP launch; `roofline_window` the fp16 window kernel, `roofline_fused` for the
 one-kernel LayerNorm -> qkv -> attention launch of the OctFormer stage, `roofline_ws` for the one with relay tokens of the
 finest pyramid level, `roofline_fp32` for the fp32 leg) and the `cpu_baseline`
 (the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol) whose descriptors are also the
@@ -555,6 +556,8 @@ def main():
                        'host_affinity': getattr(args, 'host_affinity', 'not set'),
                        'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
                                      ('rccl all_gather at world size 1' if collective else 'none')},
+            # the step's dominant kernel (26-28 % of its kernel time: profiles/r05_summary_table.md) is the fused MLP launch;
+            # `roofline` describes it when the leg ran (below), `roofline_window` the fp16 window-attention kernel
             'roofline': roof,
         }
         if roof32:
@@ -564,7 +567,8 @@ def main():
         if ws_roof:
             line['roofline_ws'] = ws_roof
         if mlp_roof:
-            line['roofline_mlp'] = mlp_roof
+            line['roofline_window'] = line['roofline']
+            line['roofline'] = mlp_roof
         if per_rank is not None:
             line['per_rank_ms_per_step'] = {'min': min(per_rank), 'max': max(per_rank), 'ranks': per_rank}
         if allgather_ms is not None:
@@ -798,8 +802,21 @@ def rowtile_roofline(groups, total):
             'frac': round(issued / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
             'useful_tflops_fp32_equivalent': round(flops / (ms * 1e-3) / 1e12, 2), 'launches': n,
             'avg_launch_us': round(ms / n * 1e3, 2), 'by_launch_size': by,
+            'algorithmic_bytes_per_launch': int(nbytes / n),
+            'algorithmic_bytes': 'SURVEY 8(d): 8 B x (row, channel) = read x + write out in f32; 2 M 8 C^2 useful FLOP',
+            'traffic': pmc_traffic('ln_mlp_fused_kernel'), 'traffic_source': 'profiles/r05_pmc_traffic.json (2 x FETCH_SIZE + '
+            'WRITE_SIZE per launch, averaged over the launches of the step: separate rocprofv3 --pmc passes of this command)',
             'mfma_busy_pmc': pmc_mfma_busy('r05_mlp_counters.txt') or pmc_mfma_busy('r04_mlp_counters.txt'),
             'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of a kernel from the committed PMC passes of the default command (tools/pmc_summary.py), or None."""
+    path = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    v = json.load(open(path)).get(kernel)
+    return v.get('hbm_bytes_per_launch') if isinstance(v, dict) else None
 
 
 def pmc_mfma_busy(name):

@@ -1438,7 +1438,7 @@ class HOTFormerStage(nn.Module):
             else:
                 rt_all = self.rtsa_blocks[i].forward_parts([rts[d] for d in depths], plan)
             fresh = {d: rt_all[plan.rt_offset[d]:plan.rt_offset[d] + plan.n_windows[d]] for d in depths}
-            if _PYRAMID_STREAMS and not _grad_path(data) and data.is_cuda:
+            if _PYRAMID_STREAMS and not _SERIAL_STREAMS and not _grad_path(data) and data.is_cuda:
                 # the three depths are independent inside an iteration (the reference runs them on
                 # three CUDA streams too, hotformerloc_backbone.py:604-633): the coarse depths'
                 # small GEMMs and kernels overlap the fine depth's.  Fork/join discipline: side
