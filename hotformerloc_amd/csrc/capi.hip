@@ -59,8 +59,8 @@ int hfl_block_forward_x3(const hfl_block_weights* w, const hfl_block_io* io, con
   // holds them only on the unfused path, whose LayerNorm reads it.
   const float* relay_src = io->relay != nullptr ? io->relay : io->x_in + nt * C;
   const bool relay_in_place = rows > nt && w->qkv_pack != nullptr && (w->fuse_attention & 4) == 0;
-  const bool part1 = phase <= 1, part3 = phase == 0 || phase == 2 || phase == 3, part_att = phase == 0 || phase == 2,
-             part4 = phase == 0 || phase == 2 || phase == 4;
+  const bool part1 = phase <= 1, part3 = phase == 0 || phase == 2 || phase == 3, part_att = phase == 0 || phase == 2;
+  // (what follows the attention -- proj, MLP -- runs in phases 0, 2 and 4: every phase that gets past the two returns below)
   auto ln_qkv = [&](int64_t r0, int64_t nr, const float* src) -> int {       // rows [r0, r0 + nr) of qkv from src (nr x C)
     if (nr <= 0) return HFL_OK;
     if (w->qkv_pack != nullptr)
