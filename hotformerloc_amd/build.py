@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libhotformerloc_hip.so'
 ARCH = 'gfx950'
-SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'gemm_x3.hip', 'mlp_fused.hip', 'qkv_fused.hip', 'attn_fused.hip', 'attn_ws.hip', 'attn_pool.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
+SOURCES = ['capi.hip', 'dwconv.hip', 'octree.hip', 'preprocess.hip', 'window_misc.hip', 'attention.hip', 'gemm_x3.hip', 'gemm_x6.hip', 'mlp_fused.hip', 'qkv_fused.hip', 'attn_fused.hip', 'attn_ws.hip', 'attn_pool.hip', 'wgrad_x3.hip', 'tapconv.hip', 'gemm_lt.hip', 'loss.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
          '-Wall', '-Wno-unused-function']
 # hipBLASLt for hfl_gemm_bf16 (the ROCm copy that matches the headers; rpath so the loader finds it)
@@ -76,6 +76,8 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
+    for stale in set(os.listdir(objdir)) - {os.path.basename(o) for o in objs}:      # objects whose source is gone
+        os.remove(os.path.join(objdir, stale))
     lib = os.path.join(LIBDIR, LIBNAME)
     if force or jobs or not os.path.exists(lib):
         cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs + LINK_FLAGS

@@ -1634,6 +1634,7 @@ int hfl_internal_attn_timing_read(double* ms, double* bytes, double* flops, int 
   }
   return (int)g_attn_recs.size();
 }
+#if HFL_ATT_TRACE          // (probe build only: tools/attn_trace.py)
 int hfl_internal_read_att_trace(unsigned long long* host, int n) {
   if (n > 16 * 8) n = 16 * 8;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_att_trace), (size_t)n * 8);
@@ -1642,6 +1643,7 @@ int hfl_internal_read_att_wg(unsigned long long* host, int n) {
   if (n > 4096 * 2) n = 4096 * 2;
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_att_wg), (size_t)n * 8);
 }
+#endif
 int hfl_set_variant(const char* key, int value) {
   if (key == nullptr) return HFL_EINVAL;
   auto is = [key](const char* name) { return strcmp(key, name) == 0; };
@@ -1656,7 +1658,7 @@ int hfl_set_variant(const char* key, int value) {
     hfl_internal_set_window_bwd(2);
     hfl_internal_set_x3_dbg(0);
     hfl_internal_set_x3_dbg(0x100);
-    hfl_internal_set_cpe_chunk(0);
+    hfl_internal_set_cpe_chunk(-1);
     hfl_internal_set_mlp_stagger(1 | (8 << 8));
 #ifdef HFL_PROBES
     hfl_internal_set_mlp_dbg(0);

@@ -261,11 +261,21 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, f
   // iteration space: `it` enumerates groups of RPB rows.  chunk_rows == 0: group it of block b is
   // b + it*gridDim (interleaved).  chunk_rows > 0: a block owns chunk_rows consecutive rows at a time
   // (z-order neighbours -> its gathers revisit lines still in L1/L2), chunks dealt round-robin.
+  // chunk_rows < 0 (default): XCD-contiguous.  Workgroups b and b + 8 share an XCD (round-robin dispatch), so XCD
+  // x = b & 7 walks its own contiguous eighth of the z-ordered rows with its gridDim / 8 workgroups interleaved inside it:
+  // a row's 27 neighbours are z-order neighbours of the same cloud, so the lines a gather touches are (re)used through ONE
+  // L2 instead of being fetched into all eight (the interleaved map: L2 hit 47 %, 3.7x the algorithmic fabric traffic).
   const int64_t groups = (n_rows + RPB - 1) / RPB;
   const int64_t gpc = chunk_rows > 0 ? (chunk_rows + RPB - 1) / RPB : 1;     // groups per chunk
+  const int64_t per_xcd = (groups + 7) >> 3;
+  const int64_t xg0 = (int64_t)(blockIdx.x & 7) * per_xcd;
+  const int64_t xg1 = xg0 + per_xcd < groups ? xg0 + per_xcd : groups;
   for (int64_t it = 0;; ++it) {
     int64_t grp;
-    if (chunk_rows > 0) {
+    if (chunk_rows < 0) {
+      grp = xg0 + (blockIdx.x >> 3) + it * (gridDim.x >> 3);
+      if (grp >= xg1) break;
+    } else if (chunk_rows > 0) {
       const int64_t chunk = (it / gpc) * gridDim.x + blockIdx.x;
       grp = chunk * gpc + it % gpc;
       if (chunk * gpc >= groups) break;
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(256) cpe_fwd_kernel(float* __restrict__ out, f
 }
 
 
-static int g_cpe_chunk_rows = 0;   // 0: rows interleaved over blocks; >0: contiguous chunk per block
+static int g_cpe_chunk_rows = -1;  // < 0: XCD-contiguous (default); 0: rows interleaved over blocks; > 0: contiguous chunk per block
 
 template <int TPR, bool NORM>
 static int launch_cpe(float* out, float* conv_out, const float* x, const float* add, const float* w, const float* gamma,
@@ -368,7 +378,8 @@ static int launch_cpe(float* out, float* conv_out, const float* x, const float* 
   constexpr int RPB = 256 / TPR;
   const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * (sizeof(int32_t) + 1) + 16;
   const int64_t need = hfl_cdiv(n, RPB);
-  const int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
+  int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
+  if (g_cpe_chunk_rows < 0) blocks = (blocks + 7) & ~7;          // the XCD map deals whole groups of eight workgroups
   cpe_fwd_kernel<TPR, NORM><<<blocks, 256, lds, s>>>(out, conv_out, x, add, w, gamma, beta, neigh, n, K, eps, residual,
                                                      g_cpe_chunk_rows);
   HFL_RETURN_LAST_ERROR();

@@ -80,6 +80,10 @@ def _add_ln(x, y, m: nn.LayerNorm):
 # (hi|hi|lo) x (hi|lo|hi) operands with fp32 accumulation/output (include/hotformerloc_hip.h section 9).
 # 'x3' = the same split arithmetic on the hand-written kernel (csrc/gemm_x3.hip: pre-split "split2" operands, bias /
 # GELU / residual / re-split fused into the epilogue) for the Linear layers of the transformer blocks.
+# 'x6' = MATCHED PRECISION: fp32-grade products on the hand-written kernel csrc/gemm_x6.hip (three bf16 planes per operand,
+# six plane products, fp32 accumulation: as accurate as an fp32 GEMM), fp32 LayerNorm / softmax / GELU, window attention
+# on the fp32 matrix cores -- the reference's own arithmetic (models/layers/octformer_layers.py:53-59,
+# models/octformer_backbone.py:52-93) without a library GEMM in the transformer blocks.
 _GEMM_MODE = os.environ.get('HFL_GEMM', 'x3')
 _PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
 _SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
@@ -143,7 +147,7 @@ _W3_CACHE = {}          # id(weight) -> (weakref to weight, version, W3)
 
 def set_gemm_mode(mode: str):
     global _GEMM_MODE
-    assert mode in ('fp32', 'bf16x3', 'x3')
+    assert mode in ('fp32', 'bf16x3', 'x3', 'x6')
     _GEMM_MODE = mode
 
 
@@ -169,6 +173,39 @@ def _w2(lin: nn.Linear):
         hit = (weakref.ref(w), w._version, ops.split2_weight(w), w.data_ptr())
         _W3_CACHE[key] = hit
     return hit[2]
+
+
+def _w6(lin: nn.Linear):
+    """The three bf16 planes of a Linear weight for `ops.linear_x6`, cached like `_w2`."""
+    w = lin.weight
+    key = ('x6', id(w))
+    hit = _W3_CACHE.get(key)
+    if hit is None or hit[0]() is not w or hit[1] != w._version or hit[3] != w.data_ptr():
+        if hit is None or hit[0]() is not w:
+            weakref.finalize(w, _W3_CACHE.pop, key, None)
+        hit = (weakref.ref(w), w._version, ops.x6_pack(w), w.data_ptr())
+        _W3_CACHE[key] = hit
+    return hit[2]
+
+
+def _x6_lin_ok(lin: nn.Linear) -> bool:
+    return ops.linear_x6_ok(lin.in_features, lin.out_features)
+
+
+def _x6_path(x, *linears) -> bool:
+    """Matched-precision inference path: GEMM mode 'x6', no autograd, fp32 rows on the GPU, every Linear a shape the kernel
+    takes (in_features % 32 == 0, out_features % 128 == 0)."""
+    return (_GEMM_MODE == 'x6' and x.is_cuda and not _grad_path() and x.dtype == torch.float32 and x.numel() > 0
+            and all(_x6_lin_ok(l) for l in linears))
+
+
+def _block_tail_x6(x, attn_out, proj: nn.Linear, norm2: nn.LayerNorm, mlp: 'MLP'):
+    """x + proj(attn_out) -> x + fc2(gelu(fc1(LN2(x)))) with fp32-grade products: bias + residual ride in the proj / fc2
+    launches, bias + GELU in fc1's (four launches: proj, LayerNorm, fc1, fc2)."""
+    x = ops.linear_x6(attn_out, _w6(proj), bias=proj.bias, residual=x)
+    h = ops.layer_norm(x, norm2.weight, norm2.bias, norm2.eps)
+    g = ops.linear_x6(h, _w6(mlp.fc1), bias=mlp.fc1.bias, gelu=True)
+    return ops.linear_x6(g, _w6(mlp.fc2), bias=mlp.fc2.bias, residual=x)
 
 
 # LN2 -> fc1 -> GELU -> fc2 -> residual as ONE launch (csrc/mlp_fused.hip) from this many rows on.  (Rounds 3-4: 24 576 -- below
@@ -286,6 +323,9 @@ class SplitLinear(nn.Linear):
         if (_GEMM_MODE == 'bf16x3' and _TRAIN_SPLIT and x.is_cuda and _grad_path()
                 and self.in_features % 8 == 0 and self.out_features % 8 == 0 and x.numel() > 0):
             return ag.linear_split(x, self.weight, self.bias)
+        if _x6_path(x, self):
+            y = ops.linear_x6(x.reshape(-1, self.in_features), _w6(self), bias=self.bias)
+            return y.view(*x.shape[:-1], self.out_features)
         return F.linear(x, self.weight, self.bias)
 
 
@@ -675,6 +715,8 @@ class MLP(nn.Module):
                 and f1.bias is not None and f2.bias is not None
                 and ag.linear_x3_ok(f1.in_features, f1.out_features) and ag.linear_x3_ok(f2.in_features, f2.out_features)):
             return ag.mlp_x3(x, f1.weight, f1.bias, f2.weight, f2.bias)      # GELU and its gradient inside the GEMMs
+        if _x6_path(x, f1, f2) and x.dim() == 2:
+            return ops.linear_x6(ops.linear_x6(x, _w6(f1), bias=f1.bias, gelu=True), _w6(f2), bias=f2.bias)
         return self.fc2(F.gelu(self.fc1(x)))
 
 
@@ -974,6 +1016,10 @@ class OctFormerBlock(nn.Module):
             return _mlp_branch(x, self.norm2, self.mlp, self.drop_path.row_scale(bid, plan.B, x))
         if _grad_path(x):
             return _mlp_branch(self.attention.residual_branch(x, self.norm1, plan, depth), self.norm2, self.mlp)
+        att = self.attention
+        if _x6_path(x, att.qkv, att.proj, self.mlp.fc1, self.mlp.fc2) and x.shape[-1] in ops._LN_CHANNELS:
+            o = att.core(att.qkv(_ln(x, self.norm1)), plan, depth)
+            return _block_tail_x6(x, o, att.proj, self.norm2, self.mlp)
         x, h = _add_ln(x, self.attention(_ln(x, self.norm1), plan, depth), self.norm2)
         return x + self.mlp(h)
 
@@ -1060,6 +1106,10 @@ class HOTFormerBlock(nn.Module):
             return _mlp_branch(buf, self.norm2, self.mlp, self.drop_path.row_scale(bid, plan.B, buf))
         if _grad_path(buf):
             return _mlp_branch(self.attention.residual_branch(buf, self.norm1, plan, depth), self.norm2, self.mlp)
+        att = self.attention
+        if _x6_path(buf, att.qkv, att.proj, self.mlp.fc1, self.mlp.fc2) and buf.shape[-1] in ops._LN_CHANNELS:
+            o = att.core(att.qkv(_ln(buf, self.norm1)), plan, depth)
+            return _block_tail_x6(buf, o, att.proj, self.norm2, self.mlp)
         buf, h = _add_ln(buf, self.attention(_ln(buf, self.norm1), plan, depth), self.norm2)
         return buf + self.mlp(h)
 
@@ -1164,6 +1214,11 @@ class RelayTokenTransformerBlock(nn.Module):
             bid = plan.relay_cloud()
             rt = rt + self.drop_path(self.gamma1 * self.rt_attention(_ln(rt, self.norm1), plan), bid, plan.B)
             return rt + self.drop_path(self.gamma2 * self.mlp(_ln(rt, self.norm2)), bid, plan.B)
+        att = self.rt_attention
+        if _x6_path(rt, att.qkv, att.proj, self.mlp.fc1, self.mlp.fc2) and rt.shape[-1] in ops._LN_CHANNELS:
+            o = ops.relay_attention(att.qkv(_ln(rt, self.norm1)), plan.seq_rows, plan.seq_off, plan.B, att.num_heads,
+                                    plan.max_seq_len)
+            return _block_tail_x6(rt, o, att.proj, self.norm2, self.mlp)
         rt, h = _add_ln(rt, self.rt_attention(_ln(rt, self.norm1), plan), self.norm2)
         return rt + self.mlp(h)
 

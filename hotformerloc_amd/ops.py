@@ -471,6 +471,50 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
     return out
 
 
+def x6_pack(w: torch.Tensor) -> torch.Tensor:
+    """(N, K) fp32 Linear weight -> its three bf16 planes (3, N, K) for `linear_x6` (hfl_linear_x6_pack, once per parameter)."""
+    _dev(w)
+    wc = _f32c(w.detach())
+    n, k = wc.shape
+    assert k % 32 == 0 and n % 128 == 0
+    w3 = torch.empty((3, n, k), dtype=torch.bfloat16, device=w.device)
+    check(_native.load().hfl_linear_x6_pack(w3.data_ptr(), wc.data_ptr(), n, k, _stream()), 'hfl_linear_x6_pack')
+    return w3
+
+
+def linear_x6_ok(in_features: int, out_features: int) -> bool:
+    return in_features % 32 == 0 and out_features % 128 == 0 and 6 * in_features * out_features < 2 ** 32
+
+
+def linear_x6(x: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, gelu: bool = False, out=None,
+              row_scale=None) -> torch.Tensor:
+    """y = x W^T [+ bias] [gelu] [* row_scale] [+ residual], fp32 in and out, fp32-grade products (hfl_linear_x6: three
+    bf16 planes per operand, six plane products with fp32 accumulation).  x (M, K) f32, w3 = x6_pack(W)."""
+    _dev(x, w3, bias, residual, row_scale)
+    assert w3.dtype == torch.bfloat16 and w3.is_contiguous() and w3.dim() == 3 and w3.shape[0] == 3
+    xc = _f32c(x)
+    m, k = xc.shape
+    n = w3.shape[1]
+    assert w3.shape[2] == k
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (m, n)
+    if residual is not None:
+        residual = _f32c(residual)
+        assert tuple(residual.shape) == (m, n)
+    if row_scale is not None:
+        row_scale = _f32c(row_scale)
+        assert tuple(row_scale.shape) == (m,)
+    with _timed('hfl_linear_x6', m * k * 4 + m * n * (8 if residual is not None else 4), 2 * m * k * n):
+        check(_native.load().hfl_linear_x6(out.data_ptr(), xc.data_ptr(), w3.data_ptr(),
+                                           None if bias is None else _f32c(bias).data_ptr(),
+                                           None if residual is None else residual.data_ptr(),
+                                           None if row_scale is None else row_scale.data_ptr(), m, k, n, int(bool(gelu)),
+                                           _stream()), 'hfl_linear_x6')
+    return out
+
+
 def linear_x3_gelu_fwd(x2: torch.Tensor, w2: torch.Tensor, bias):
     """(split2(gelu(x W^T + b)), x W^T + b as f32) in one launch (hfl_linear_x3_gelu_fwd): training forward of fc1."""
     _dev(x2, w2, bias)

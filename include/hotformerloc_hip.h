@@ -470,6 +470,21 @@ int hfl_layer_norm_split2(uint16_t* out, const float* x, const float* gamma, con
 int hfl_layer_norm_relu(float* out_f32, uint16_t* out_split2, const float* x, const float* gamma, const float* beta,
                         int64_t n_rows, int64_t channels, float eps, hfl_stream_t stream);
 
+/* 9b'. MATCHED-PRECISION Linear (csrc/gemm_x6.hip): y = x W^T [+ bias] [GELU] [* row_scale] [+ residual], all f32 in memory,
+ * with fp32-grade products on the bf16 matrix cores: every operand is the EXACT sum of three bf16 planes (h, m, l) and the six
+ * plane products >= 2^-16 are accumulated smallest first in fp32 (what is dropped, m l + l m + l l <= 2^-23 |x w|, is the size of
+ * one fp32 rounding of the product).  Replaces torch.nn.Linear (fp32) and the element-wise op after it in the transformer blocks
+ * (models/octformer_backbone.py:70,91,275-278; models/layers/octformer_layers.py:53-59; models/hotformerloc_backbone.py:213-216)
+ * for callers that want the reference's own arithmetic rather than the 16-bit-operand split of section 9b.
+ *   w3 (3, out_features, in_features) bf16 = hfl_linear_x6_pack(w (out_features, in_features) f32), once per parameter;
+ *   x (n_rows, in_features) f32 as any producer left it (the split happens on the way into LDS);
+ *   gelu = 1: out = gelu(acc + bias), exact-erf GELU (residual and row_scale must be NULL);
+ *   gelu = 0: out = (acc + bias) [* row_scale[row]] [+ residual] (residual may alias out).
+ * in_features % 32 == 0, out_features % 128 == 0. */
+int hfl_linear_x6_pack(uint16_t* w3, const float* w, int64_t out_features, int64_t in_features, hfl_stream_t stream);
+int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
+                  const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream);
+
 /* 9e'. norm1 -> attention.qkv -> window attention of a RELAY-TOKEN block (models/hotformerloc_backbone.py:197-216,
  *      models/octformer_backbone.py:52-93: C = 256, 16 heads, K = 48 tokens + 1 relay token per window, dilation 1) as ONE launch
  *      with specialised waves (csrc/attn_ws.hip: six waves run the qkv GEMM of 96 rows head pair by head pair, six run the

@@ -50,7 +50,12 @@ CASES = {
 WORKLOAD_CASES = {
     'wild_places_b32':       ('wild-places', 7, 'init', 2, 32, 4096, None),        # config 2 = the bench's timed batch
     'cs_wild_places_b8_var': ('cs-wild-places', 7, 'init', 3, 8, 4096, 32768),     # config 3's generator, 8 clouds
+    'cs_wild_places_b64_var': ('cs-wild-places', 7, 'init', 3, 64, 4096, 32768),   # config 3 itself: 64 clouds, 1.1 M points
 }
+# cases whose fixture does not carry its points (13 MB for config 3): cartesian clouds come out of integer hashes and exactly
+# rounded arithmetic (hotformerloc_amd/synthetic.py), the fixture keeps their SHA-256 and the per-depth node counts so that
+# a test can tell "different input" from "different result"
+DESCRIPTORS_ONLY = {'cs_wild_places_b64_var'}
 
 
 def workload_clouds(coordinates, cid, batch, n_points, n_points_max):
@@ -111,14 +116,20 @@ def build_case(case):
                nnum_nempty=octree.nnum_nempty.numpy())
     # (the points themselves, also for the generated workloads: the cylindrical transform's float64 chain is not
     # bit-reproducible across host CPUs, and one point that changes its depth-7 cell changes the octree)
-    out['points'] = np.concatenate(clouds, 0).astype(np.float32)
+    pts = np.ascontiguousarray(np.concatenate(clouds, 0).astype(np.float32))
+    if case in DESCRIPTORS_ONLY:
+        import hashlib
+        out['points_sha256'] = np.array(hashlib.sha256(pts.tobytes()).hexdigest())
+    else:
+        out['points'] = pts
     if workload:      # the generator's arguments (bench.py::bench_clouds) and the weight profile
         out['workload'] = np.array([cid, batch, n_points, n_points_max or 0], dtype=np.int64)
         out['profile'] = np.array(profile)
 
     def put(name, t):
         t = t.detach().double()
-        out[name + '_head'] = t[:32].float().numpy()
+        if case not in DESCRIPTORS_ONLY:
+            out[name + '_head'] = t[:32].float().numpy()
         out[name + '_sum'] = np.array([t.sum().item(), (t * t).sum().item()])
     put('patch_embed', cap['patch_embed'])
     put('octf_out', cap['octf_out'])
