@@ -23,8 +23,11 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
                  hand-written MFMA GEMM (`--gemm x3`), window attention on fp16 (hi, lo) pairs
   resident_plan  the same step with the plan / tap tables kept on the octree between steps (what a caller that
                  re-submits one octree sees; round 2's headline)
-  fp32_linear    the boundary-faithful step with every Linear as an fp32 GEMM and fp32-MFMA attention -- the
-                 reference's arithmetic
+  matched_precision   the boundary-faithful step at the REFERENCE'S ARITHMETIC on hand-written kernels: every
+                 transformer-block Linear on hfl_linear_x6 (fp32-grade products: three bf16 planes per operand, six plane
+                 products, f32 accumulation; csrc/gemm_x6.hip), f32 LayerNorm / softmax / GELU, f32-MFMA window attention;
+                 with its own roofline (hfl_linear_x6), its parity against the reference golden, and, as context, the same
+                 step on the fp32 library GEMM (`fp32_library_gemm`).  Repeated under config.matched_precision
   e2e            a FRESH octree per step from device-resident points: device build + neighbour tables + forward
   train_cs       BASELINE config 3 (CS-Wild-Places cfg, B = 64, forward + backward), in a child process; activations kept
                  (checkpoint policy 'auto': they fit) -- train_cs_checkpointed = the same with the reference's
@@ -36,7 +39,7 @@ What one default run times (same W-warm-up / K-step / barrier protocol for every
 and then, outside any timed value: the `roofline` legs (HIP events per launch: `roofline` = the step's dominant kernel, the
 fused MLP launch; `roofline_window` the fp16 window kernel, `roofline_fused` for the
 one-kernel LayerNorm -> qkv -> attention launch of the OctFormer stage, `roofline_ws` for the one with relay tokens of the
-finest pyramid level, `roofline_fp32` for the fp32 leg) and the `cpu_baseline`
+finest pyramid level, `roofline_fp32` for the f32-MFMA window kernel of the matched-precision leg) and the `cpu_baseline`
 (the CPU oracle, a port of the reference forward, BASELINE.md section 3 protocol) whose descriptors are also the
 `parity` reference of the timed workload's GPU descriptors (BASELINE metric: "descriptor L2 vs ref").
 """
@@ -76,10 +79,11 @@ def parse():
     ap.add_argument('--points-max', type=int, default=None,
                     help='variable density: per-cloud point count ~ U{points..points_max}, forest / unit-ball mix '
                          '(default for cs-wild-places: 32768, BASELINE config 3)')
-    ap.add_argument('--gemm', default='x3', choices=['x3', 'bf16x3', 'fp32'],
+    ap.add_argument('--gemm', default='x3', choices=['x3', 'bf16x3', 'fp32', 'x6'],
                     help="Linear layers of the headline `value`: 'x3' = hand-written split-bf16 MFMA GEMM with fused "
                          "bias/GELU/residual epilogues (default); 'bf16x3' = the same three-term split as one hipBLASLt bf16 "
-                         "GEMM over K-concatenated operands; 'fp32' = hipBLASLt fp32 GEMMs")
+                         "GEMM over K-concatenated operands; 'fp32' = hipBLASLt fp32 GEMMs; 'x6' = matched precision: hand-written "
+                         "fp32-grade GEMM on three bf16 planes per operand (csrc/gemm_x6.hip) + fp32-MFMA attention")
     ap.add_argument('--resident-plan', action='store_true',
                     help='headline step keeps the window plan / tap tables cached on the octree (round-2 behaviour)')
     ap.add_argument('--no-streams', action='store_true', help='pyramid depths on one stream')
@@ -419,6 +423,7 @@ def main():
 
     extras = world == 1 and not args.train and not args.no_extras
     resident_line = fp32_line = e2e_line = kern_iso = kern_all = iso_sizes = kern_iso32 = fused_roof = ws_roof = mlp_roof = None
+    lib_line = x6_sizes = None
     with (torch.enable_grad() if args.train else torch.inference_mode()):
         # ---- the headline: W warm-ups, K timed steps, nothing instrumented inside the timed region
         elapsed = timed(step, args.steps, args.warmup, tag='value')
@@ -431,23 +436,33 @@ def main():
             resident_line['what'] = ('window plan, tap lists and tile tables %s between steps'
                                      % ('rebuilt' if args.resident_plan else 'kept on the octree'))
             log('resident-plan leg: %.3f s' % dt)
-            other = 'fp32' if args.gemm != 'fp32' else 'x3'
+            # ---- the MATCHED-PRECISION leg: the reference's own arithmetic (fp32-grade Linear products, fp32 LayerNorm / softmax
+            # / GELU, fp32-MFMA window attention) on hand-written kernels -- no library GEMM in the transformer blocks
+            other = 'x6' if args.gemm != 'x6' else 'x3'
             set_gemm_mode(other)
             dt = timed(step, args.steps, args.warmup, tag='other')
             fp32_line = leg(dt)
             fp32_line['gemm'] = other
             log('%s Linear leg: %.3f s' % (other, dt))
-            if other == 'fp32':
-                # roofline of the fp32-MFMA window kernel this leg runs (v4), pyramid depths serialised
-                set_pyramid_streams(False)
+            if other == 'x6':
+                # roofline of the leg's dominant kernel (hfl_linear_x6) and of the fp32-MFMA window kernel it runs (v4), the
+                # step's schedule on one stream: a launch's events then bracket the kernel alone
+                set_pyramid_streams('serial' if not args.no_streams else False)
                 step()
                 torch.cuda.synchronize()
-                with ops.KernelTimer(only=[ATTN]) as t32:
+                with ops.KernelTimer(only=[ATTN, 'hfl_linear_x6']) as t32:
                     for _ in range(args.steps):
                         step()
                     torch.cuda.synchronize()
                 kern_iso32 = t32.summary()
+                x6_sizes = t32.by_size('hfl_linear_x6')
                 set_pyramid_streams(not args.no_streams)
+                # context: the same step with the fp32 library GEMM (hipBLASLt through F.linear) where hfl_linear_x6 runs
+                set_gemm_mode('fp32')
+                dt = timed(step, args.steps, args.warmup, tag='lib')
+                lib_line = leg(dt)
+                lib_line['gemm'] = 'fp32'
+                log('fp32 library-GEMM leg: %.3f s' % dt)
             set_gemm_mode(args.gemm)
             dt = timed(step_e2e, args.steps, args.warmup)
             e2e_line = leg(dt)
@@ -521,8 +536,9 @@ def main():
         roof = roofline_block(kern_iso or kern_all, kern_all, iso_sizes, args,
                               'hand-written fp16 (hi, lo) MFMA window kernel (v5)' if args.gemm != 'fp32'
                               else 'fp32-MFMA window kernel (v4)', MFMA_F32_PEAK_TFLOPS, bool(kern_iso))
-        roof32 = roofline_block(kern_iso32, None, None, args, 'fp32-MFMA window kernel (v4), fp32_linear leg',
-                                MFMA_F32_PEAK_TFLOPS, True) if kern_iso32 else None
+        roof32 = roofline_block({ATTN: kern_iso32[ATTN]}, None, None, args, 'fp32-MFMA window kernel (v4), matched-precision leg',
+                                MFMA_F32_PEAK_TFLOPS, True) if (kern_iso32 and ATTN in kern_iso32) else None
+        roof_x6 = x6_roofline(x6_sizes, kern_iso32.get('hfl_linear_x6')) if kern_iso32 else None
         others = {}
         for name, (kn, kms, kb, kf, kmv) in (kern_all or {}).items():
             others[name] = {'launches_per_step': kn // args.steps,
@@ -531,7 +547,12 @@ def main():
         split_txt = ('f32 storage and accumulation; Linear products as 3-term bf16 (hi, lo) split (16 significant bits per '
                      'operand); window-attention QK^T / PV on fp16 (hi, lo) pairs (22 significant bits), softmax in f32; '
                      'fp32_linear leg = f32 GEMMs + f32-MFMA attention (the reference\'s arithmetic)')
-        mode_txt = {'fp32': 'f32', 'bf16x3': split_txt, 'x3': split_txt}
+        split_txt = split_txt.replace('fp32_linear leg = f32 GEMMs + f32-MFMA attention', 'matched_precision leg = fp32-grade '
+                                      'Linear products (3 bf16 planes per operand, 6 plane products) + f32-MFMA attention')
+        x6_txt = ('f32 storage and accumulation; Linear products fp32-grade: every operand the exact sum of three bf16 planes, six '
+                  'plane products with f32 accumulation (error vs fp64 below the fp32 library GEMM\'s); LayerNorm / softmax / GELU '
+                  'in f32; window-attention QK^T / PV on the f32 matrix cores')
+        mode_txt = {'fp32': 'f32', 'bf16x3': split_txt, 'x3': split_txt, 'x6': x6_txt}
         plan_txt = ('window plan + tap tables cached on the octree' if args.resident_plan else
                     'window plan + tap tables rebuilt inside every step (reference boundary)')
         line = {
@@ -553,6 +574,9 @@ def main():
                                        if args.multistaged else ('forward+backward, stochastic depth %s' % ('off' if args.no_drop_path else 'on (drop_path = %.2f, as the config trains)' % params.drop_path))) if args.train else 'forward-only',
                                       plan_txt),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world, 'gemm': args.gemm,
+                       'value_leg': ('split precision (16-bit-operand products; inside the 1e-3 tolerance, narrower than the '
+                                     'reference): the matched-precision figure is matched_precision.value' if args.gemm in ('x3', 'bf16x3')
+                                     else 'matched precision (the reference\'s arithmetic)'),
                        'host_affinity': getattr(args, 'host_affinity', 'not set'),
                        'collective': 'rccl all_gather (B_local,256) f32' if collective and world > 1 else
                                      ('rccl all_gather at world size 1' if collective else 'none')},
@@ -575,8 +599,25 @@ def main():
             line['allgather_ms'] = allgather_ms
         if resident_line:
             line['boundary_plan' if args.resident_plan else 'resident_plan'] = resident_line
-        if fp32_line:
-            line['fp32_linear' if fp32_line['gemm'] == 'fp32' else 'split_linear'] = fp32_line
+        if fp32_line and fp32_line['gemm'] == 'x6':
+            mp = dict(fp32_line)
+            mp['what'] = ('the same step at the reference\'s arithmetic: every transformer-block Linear on hfl_linear_x6 (hand-'
+                          'written; three bf16 planes per operand, six plane products, f32 accumulation; bias / GELU / residual '
+                          'in its epilogue), f32 LayerNorm, f32-MFMA window attention (v4), f32 relay attention; stem '
+                          'convolutions and pooling head f32')
+            mp['dtype'] = x6_txt
+            if roof_x6:
+                mp['roofline'] = roof_x6
+            if lib_line:
+                mp['fp32_library_gemm'] = dict(lib_line, what='context: hipBLASLt fp32 GEMMs (F.linear) in place of hfl_linear_x6, '
+                                                               'everything else the same')
+            line['matched_precision'] = mp
+            # (the driver's record keeps `config` and `roofline` whole: the figure is repeated there)
+            line['config']['matched_precision'] = {'value': mp['value'], 'unit': 'clouds/s', 'ms_per_step': mp['ms_per_step'],
+                                                   'gemm': 'x6 (hfl_linear_x6, hand-written)',
+                                                   'roofline_frac': None if not roof_x6 else roof_x6['frac']}
+        elif fp32_line:
+            line['split_linear'] = fp32_line
         if e2e_line:
             line['e2e'] = e2e_line
         cpe = cpe_l1_bound() if (args.config == 'wild-places' and not args.train) else None
@@ -649,10 +690,15 @@ def main():
                   args.gemm: parity_record(last['value'], ref)}
             if 'other' in last and fp32_line:
                 pr[fp32_line['gemm']] = parity_record(last['other'], ref)
+            if 'lib' in last:
+                pr['fp32'] = parity_record(last['lib'], ref)
             line['parity_reference'] = pr
+            if 'matched_precision' in line and 'x6' in pr:
+                line['matched_precision']['parity_reference'] = pr['x6']
+                line['config']['matched_precision']['parity_reference_max_rel_l2'] = pr['x6'].get('max_rel_l2')
         # the keys a truncated record must keep come first
         head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-                'vs_baseline', 'parity_reference', 'parity', 'fp32_linear', 'roofline', 'cpu_baseline', 'gpu_over_cpu')
+                'vs_baseline', 'matched_precision', 'parity_reference', 'parity', 'roofline', 'cpu_baseline', 'gpu_over_cpu')
         line = {**{k: line[k] for k in head if k in line}, **{k: v for k, v in line.items() if k not in head}}
         print(json.dumps(line), flush=True)
     if use_dist:
@@ -810,13 +856,39 @@ def rowtile_roofline(groups, total):
             'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
 
 
+def x6_roofline(groups, total):
+    """MFMA roofline of the matched-precision leg's dominant kernel, hfl_linear_x6 (csrc/gemm_x6.hip): every transformer-block
+    Linear of the step.  Issued FLOP = 6 bf16 MFMA plane products per fp32 product of the 2 M K N useful ones; algorithmic bytes
+    = x once + out once (+ residual once), f32."""
+    if not total:
+        return None
+    n, ms, nbytes, flops, _ = total
+    issued = 6.0 * flops
+    by = [{'algorithmic_bytes': int(b), 'launches': c, 'avg_launch_us': round(t / c * 1e3, 2)} for b, c, t in (groups or [])[:8]]
+    return {'kernel': 'hfl_linear_x6', 'what': 'fp32-grade Linear on the bf16 matrix cores: operands split into three bf16 planes '
+            '(x on the way into LDS, W once per parameter), six plane products per k-step, f32 accumulation, bias / GELU / '
+            'residual in the epilogue; every launch of the matched-precision step',
+            'bound': 'mfma', 'unit': 'TFLOP/s', 'peak': MFMA_F16_PEAK_TFLOPS, 'achieved': round(issued / (ms * 1e-3) / 1e12, 1),
+            'frac': round(issued / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+            'useful_tflops_fp32_equivalent': round(flops / (ms * 1e-3) / 1e12, 2),
+            'useful_over_f32_mfma_peak': round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
+            'largest_launches': by, 'algorithmic_bytes_per_launch': int(nbytes / n),
+            'algorithmic_bytes': 'x (M K 4 B) + out (M N 4 B) [+ residual (M N 4 B)]; 2 M K N useful FLOP',
+            'traffic': pmc_traffic('gemm_x6_kernel'), 'traffic_source': 'profiles/r06_pmc_traffic.json when present (2 x FETCH_SIZE + '
+            'WRITE_SIZE per launch, separate rocprofv3 --pmc passes)',
+            'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of a kernel from the committed PMC passes of the default command (tools/pmc_summary.py), or None."""
-    path = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    v = json.load(open(path)).get(kernel)
-    return v.get('hbm_bytes_per_launch') if isinstance(v, dict) else None
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            v = json.load(open(path)).get(kernel)
+            if isinstance(v, dict):
+                return v.get('hbm_bytes_per_launch')
+    return None
 
 
 def pmc_mfma_busy(name):

@@ -554,7 +554,7 @@ def mlp_x3(h, w1, b1, w2, b2):
 
 
 # ------------------------------------------------ conditional position encoding, training forward as one launch
-_CPE_BWD_GATHER = os.environ.get('HFL_TRAIN_CPE_BWD_GATHER', '1') != '0'
+_CPE_BWD_GATHER = (os.environ.get('HFL_TRAIN_CPE_BWD_GATHER', '1') if os.environ.get('HFL_PROBES', '0') == '1' else '1') != '0'   # probe knob
 
 
 class CpeFn(torch.autograd.Function):

@@ -16,13 +16,14 @@
 // Rate: 6 bf16 MFMA products per fp32 product = 2.5 PF / 6 = 416 TF/s fp32-equivalent peak, 2.6x the fp32 matrix rate
 // (157 TF/s, v_mfma_f32_16x16x4_f32).
 //
-// Kernel: 256 (rows) x 128 (features) tile per 512-lane workgroup, 4 x 2 waves of 64 x 64, K step 32, ONE workgroup per CU
-// (two waves per SIMD, <= 256 VGPRs), two 72-KiB LDS stages (separate __shared__ arrays: hipcc tracks LDS-DMA per array, so
-// the fragment reads of the current stage do not wait for the DMA that fills the other one), one barrier per k-step.
-//  * x arrives as plain f32: global -> registers (issued one k-step ahead) -> split into the three planes -> ds_write_b64
-//    into the next stage.  No producer has to know the operand layout.
-//  * W is pre-split once per parameter (hfl_linear_x6_pack: (3, N, K) bf16) and moves global -> LDS by
-//    `global_load_lds_dwordx4` (16 rows x 64 B of one plane per wave-instruction).
+// Kernel: 256 (rows) x 128 (features) tile per 512-lane workgroup, 4 x 2 waves of 64 x 64, K step 32, ONE persistent
+// workgroup per CU (two waves per SIMD, <= 256 VGPRs), two 72-KiB LDS stages (separate __shared__ arrays: hipcc tracks
+// LDS-DMA per array, so the fragment reads of the current stage do not wait for the DMA that fills the other one); the two
+// waves of a SIMD run half a k-step apart (see the kernel), so one of them is always in its MFMA phase.
+//  * x arrives as plain f32: global -> registers (requested one MFMA phase ahead) -> split into the three planes ->
+//    ds_write_b64 into the next stage.  No producer has to know the operand layout.
+//  * W is pre-split once per parameter (hfl_linear_x6_pack: (3, N, Kp) bf16, Kp = K rounded up to 64 with zeros) and moves
+//    global -> LDS by `global_load_lds_dwordx4` (16 rows x 64 B of one plane per wave-instruction).
 //  * LDS images: per plane [row][32 k] = 64 B per row; the 16-B chunk q of row r sits at slot q ^ f((r >> 2) & 3),
 //    f = (0, 2, 3, 1): a ds_read_b128 fragment read (16 rows x one chunk per 16-lane group) touches all 64 banks once.
 //    For the DMA the permutation is applied to the SOURCE address (LDS-DMA writes are lane-linear).
@@ -34,16 +35,28 @@
 #include "hfl_common.h"
 #include "x3_math.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int X6_BM = 256, X6_BN = 128;
-constexpr int X6_APLANE = X6_BM * 64;                       // bytes of one plane of the x tile
-constexpr int X6_WPLANE = X6_BN * 64;
-constexpr int X6_WBASE = 3 * X6_APLANE;
-constexpr int X6_STAGE = 3 * X6_APLANE + 3 * X6_WPLANE;     // 73 728 B
+// Tile geometry: 8 waves as (8 / NWN) x NWN blocks of (16 MT) rows x 64 features: NWN = 2 -> (64 MT) rows x 128 features,
+// NWN = 4 -> (32 MT) rows x 256 features.  The wide tile halves the x rows a workgroup splits per MFMA (the split's ~28
+// vector instructions per four values compete with the partner wave's MFMAs for the SIMD's issue slots: with 256 x 128
+// tiles the non-MFMA half-step took ~2400 cycles against the 1536 of the MFMA half) and re-splits a row tile N / 256 times
+// instead of N / 128 times.  LDS stage: three planes of the x tile, three of the W tile.
+template <int MT, int NWN> struct X6Geo {
+  static constexpr int NWM = 8 / NWN;
+  static constexpr int BM = NWM * 16 * MT;
+  static constexpr int BN = NWN * 64;
+  static constexpr int MTL = BM / 64;                          // float4 of x per lane and k-step
+  static constexpr int APLANE = BM * 64;                       // bytes of one plane of the x tile
+  static constexpr int WPLANE = BN * 64;
+  static constexpr int WPIECES = 3 * BN / 16;                  // 1-KiB LDS-DMA pieces of a W stage
+  static_assert(BM % 64 == 0, "the x tile is loaded 64 rows per pass of the workgroup");
+};
 
 struct X6Params {
   float* out;               // (M, N) f32
@@ -55,7 +68,9 @@ struct X6Params {
   int64_t M;
   int N, K;
   int tiles_n;
-  int64_t n_wg;
+  int64_t n_wg;             // tiles of the launch
+  int nk;                   // k-steps of 32 (even: W's K is zero-padded to a multiple of 64)
+  int64_t w_plane_bytes;    // bytes of one W plane: N x 32 nk x 2
 };
 
 __device__ __forceinline__ int x6_swz(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -77,11 +92,21 @@ __device__ __forceinline__ void x6_split4(const float4 v, uint2& h, uint2& m, ui
   l = make_uint2(l01, l23);
 }
 
-// acc[i][j]: features 16 i + 4 fq .. +3 (registers) of row 16 j + frow of the 64 x 64 tile at (m_tile, n_tile) one wavefront
-// owns; ep = that wavefront's private 8-KiB LDS region.  The wave transposes 32 rows at a time (16-B chunks XOR-swizzled by
-// the row: conflict-free both ways) so that 16 consecutive lanes hold 256 contiguous bytes of one output row.
-template <int GELU>
-__device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][4], unsigned char* ep, int64_t m_tile, int n_tile,
+// a wave's private 4-KiB transpose region of the epilogue (16 rows x 256 B).  It lies in the arrays of stage 1: a wave that is
+// already in the NEXT tile's prologue writes stage 0 only, and nobody writes stage 1 before the next tile's first barrier, which
+// every wave passes after its epilogue.
+template <int MT, int NWN>
+__device__ __forceinline__ unsigned char* x6_ep_region(unsigned char* sx1, unsigned char* sw1, int wave) {
+  constexpr int in_x = (3 * X6Geo<MT, NWN>::APLANE) / 4096;       // regions in the x stage (>= 3), >= 6 more in the W stage
+  return wave < in_x ? sx1 + wave * 4096 : sw1 + (wave - in_x) * 4096;
+}
+
+// acc[i][j]: features 16 i + 4 fq .. +3 (registers) of row 16 j + frow of the (16 MT) x 64 tile at (m_tile, n_tile) one
+// wavefront owns.  The wave transposes 16 rows at a time through its LDS region (16-B chunks XOR-swizzled by the row:
+// conflict-free both ways) so that 16 consecutive lanes hold 256 contiguous bytes of one output row: every store instruction
+// writes whole 128-B lines.
+template <int GELU, int MT>
+__device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][MT], unsigned char* ep, int64_t m_tile, int n_tile,
                                             int lane) {
   const int frow = lane & 15, fq = lane >> 4;
   const int N = p.N;
@@ -91,31 +116,30 @@ __device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][4
   if (p.bias != nullptr) b = *reinterpret_cast<const float4*>(p.bias + nbase);
   // every residual value of the tile is requested before the first store (`residual` may be `out`: a load behind a store of
   // the same lane's element would otherwise wait for it, one round trip per 4 rows)
-  float4 rs[GELU ? 1 : 2][GELU ? 1 : 8];
+  float4 rs[GELU ? 1 : MT][GELU ? 1 : 4];
+  float rsc[GELU ? 1 : MT][GELU ? 1 : 4];
   if (!GELU) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int j = 0; j < MT; ++j)
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int64_t m = m_tile + h * 32 + it * 4 + fq;
-        rs[h][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.residual != nullptr && m < p.M) rs[h][it] = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+      for (int it = 0; it < 4; ++it) {
+        const int64_t m = m_tile + j * 16 + it * 4 + fq;
+        rs[j][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rsc[j][it] = 1.0f;
+        if (p.residual != nullptr && m < p.M) rs[j][it] = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+        if (p.row_scale != nullptr && m < p.M) rsc[j][it] = p.row_scale[m];
       }
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int j = 0; j < MT; ++j) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(ep + frow * 256 + (((i * 4 + fq) ^ frow) << 4)) = acc[i][j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = jj * 16 + frow;
-        *reinterpret_cast<f32x4*>(ep + r * 256 + (((i * 4 + fq) ^ frow) << 4)) = acc[i][2 * h + jj];
-      }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 4; ++it) {
       const int r = it * 4 + fq;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ (r & 15)) << 4));
-      const int64_t m = m_tile + h * 32 + r;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ r) << 4));
+      const int64_t m = m_tile + j * 16 + r;
       if (m >= p.M) continue;
       float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
       if (GELU) {
@@ -123,11 +147,11 @@ __device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][4
         v = make_float4(g01[0], g01[1], g23[0], g23[1]);
       } else {
         if (p.row_scale != nullptr) {
-          const float rsc = p.row_scale[m];
-          v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+          const float sc = rsc[GELU ? 0 : j][GELU ? 0 : it];
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
         }
         if (p.residual != nullptr) {
-          const float4 r4 = rs[GELU ? 0 : h][GELU ? 0 : it];
+          const float4 r4 = rs[GELU ? 0 : j][GELU ? 0 : it];
           v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
         }
       }
@@ -136,136 +160,321 @@ __device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][4
   }
 }
 
-template <int GELU>
+// probe build (-DHFL_X6_STAMPS): s_memtime of wave 0 (group A) and wave 4 (group B) of workgroup 0 at every barrier arrival and
+// release of its first tile (tools/x6_stamps.py)
+#ifdef HFL_X6_STAMPS
+__device__ unsigned long long g_x6_stamps[2][512];
+#define X6_STAMP()                                                                                         \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4) && stamp_n < 512)                         \
+      g_x6_stamps[wave >> 2][stamp_n++] = __builtin_amdgcn_s_memtime();                                    \
+  } while (0)
+#else
+#define X6_STAMP() do { } while (0)
+#endif
+
+// s_waitcnt with the gfx9 immediate: vmcnt(v) lgkmcnt(l), no wait on expcnt
+#define X6_WAIT(v, l) __builtin_amdgcn_s_waitcnt(((v) & 15) | (((v) >> 4) << 14) | (7 << 4) | ((l) << 8))
+#define X6_WAIT_LGKM0() X6_WAIT(63, 0)
+#define X6_WAIT_ALL() X6_WAIT(0, 0)
+
+// Kernel: persistent, one 512-lane workgroup per CU, tiles of (64 MT) rows x 128 features dealt round-robin; wave w owns the
+// (16 MT) x 64 block (w & 3, w >> 2).  The two waves of a SIMD (w and w + 4) work HALF A K-STEP APART: while group A (waves
+// 0-3) runs the 24 MT MFMAs of step t from fragments it holds in registers, group B (waves 4-7) reads its fragments of step t
+// from LDS, splits its share of x (t + 1) into the other stage and -- half a step later -- runs its own MFMAs while group A
+// reads, splits and issues the LDS-DMA of W (t + 1).  Two barriers per k-step; the matrix pipe of every SIMD always has one
+// of its two waves in an MFMA phase (in lock-step, as one barrier per k-step has them, the fragment reads, the split and the
+// barrier skew of BOTH waves lie between the MFMA phases: the pipe was 34 % busy, PMC).
+template <int GELU, int MT, int NWN>
 __global__ void __launch_bounds__(512, 2)
 gemm_x6_kernel(const X6Params p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char s0[X6_STAGE];
-  __shared__ __attribute__((aligned(1024))) unsigned char s1[X6_STAGE];
+  using G = X6Geo<MT, NWN>;
+  constexpr int MTL = G::MTL;
+  // four arrays: hipcc orders LDS accesses against pending LDS-DMA per ARRAY, so the x planes (written by ds_write) and the W
+  // planes (written by LDS-DMA) of the two stages are separate objects
+  __shared__ __attribute__((aligned(1024))) unsigned char sx0[3 * G::APLANE];
+  __shared__ __attribute__((aligned(1024))) unsigned char sx1[3 * G::APLANE];
+  __shared__ __attribute__((aligned(1024))) unsigned char sw0[3 * G::WPLANE];
+  __shared__ __attribute__((aligned(1024))) unsigned char sw1[3 * G::WPLANE];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 3, wn = wave >> 2;
-
-  // XCD-aware tile assignment (bijective remap: consecutive new ids share an XCD)
-  int64_t wg = blockIdx.x;
-  {
-    const int64_t q = p.n_wg >> 3, r = p.n_wg & 7;
-    const int64_t xcd = wg & 7, loc = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int64_t m0 = (wg / p.tiles_n) * X6_BM;
-  const int n0 = (int)(wg % p.tiles_n) * X6_BN;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % G::NWM, wn = wave / G::NWM;
+  const bool grp_a = wave < 4;                                       // (wave-uniform)
   const int K = p.K;
-  const int nk = K >> 5;
+  const int nk = p.nk;                                               // even, >= 2 (W is zero-padded to a multiple of 64)
+  const int64_t kw = (int64_t)nk * 32;                               // row stride of the W planes (elements)
 
-  // ---- x: lane -> (row within 8, 16-B chunk); instruction i covers rows wave * 32 + 8 i .. + 7
+  // ---- x: lane -> (row within 8, 16-B chunk); instruction i covers rows wave * 8 MTL + 8 i .. + 7 of the tile
   const int arow = lane >> 3, ac = lane & 7;
-  const float* xrow[4];
-  int a_lds[4];
+  int a_lds[MTL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + arow;
-    int64_t m = m0 + r;
-    if (m >= p.M) m = p.M - 1;                                   // tail rows read the last valid row, never stored
-    xrow[i] = p.x + m * K + ac * 4;
+  for (int i = 0; i < MTL; ++i) {
+    const int r = wave * (8 * MTL) + i * 8 + arow;
     a_lds[i] = r * 64 + (((ac >> 1) ^ x6_swz(r)) << 4) + (ac & 1) * 8;
   }
-  // ---- W: three 1-KiB pieces per wave and k-step; piece P = wave * 3 + t: plane P >> 3, rows 16 (P & 7) .. + 15
-  uint32_t w_src[3];
-  int w_lds[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int P = wave * 3 + t;
-    const int plane = P >> 3, rblk = P & 7;
-    const int row = rblk * 16 + (lane >> 2);
-    const int q = (lane & 3) ^ x6_swz(row);
-    w_src[t] = (uint32_t)(((int64_t)plane * p.N + n0 + row) * K * 2 + q * 16);      // (the launcher checked 3 N K 2 < 2^32)
-    w_lds[t] = X6_WBASE + plane * X6_WPLANE + rblk * 1024;
-  }
+  // ---- W (group A): six 1-KiB pieces per wave and k-step; piece P = wave * 6 + t: plane P >> 3, rows 16 (P & 7) .. + 15.
+  // The lane's part of the source offset is the same for every piece (row lane >> 2 of the piece, chunk q: the swizzle term
+  // depends on (row >> 2) & 3 = (lane >> 4) & 3 only); plane and row block are wave-uniform.
+  const uint32_t w_lane = (uint32_t)((lane >> 2) * kw * 2 + (((lane & 3) ^ x6_swz(lane >> 2)) << 4));
   const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(p.w3);
 
   // ---- fragment addresses (bytes inside a stage)
   const int frow = lane & 15, fq = lane >> 4;
   const int fsw = (fq ^ x6_swz(frow)) << 4;
-  const int offx = (wm * 64 + frow) * 64 + fsw;                    // + plane * X6_APLANE + j * 1024
-  const int offw = X6_WBASE + (wn * 64 + frow) * 64 + fsw;         // + plane * X6_WPLANE + i * 1024
+  const int offx = (wm * (16 * MT) + frow) * 64 + fsw;             // + plane * APLANE + j * 1024
+  const int offw = (wn * 64 + frow) * 64 + fsw;                    // + plane * WPLANE + i * 1024
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // persistent tile loop; XCD-aware: the workgroups of one XCD (blockIdx.x & 7) take consecutive tiles, i.e. the feature tiles
+  // of one row tile, in every round
+  const int64_t grid = gridDim.x;
+  int64_t slot = blockIdx.x;
+  if ((grid & 7) == 0) slot = (int64_t)(blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3);
 
-  float4 av[4];
+  f32x4 acc[4][MT];
+  f32x4 av[MTL];
+  bf16x8 xf[3][MT], wf[3][4];
+  const float* xrow[MTL];
+  const unsigned char* wtile = wbytes;
+  int64_t m0 = 0;
+  int n0 = 0;
+
+  auto tile_setup = [&](int64_t tile) {
+    m0 = (tile / p.tiles_n) * G::BM;
+    n0 = (int)(tile % p.tiles_n) * G::BN;
+#pragma unroll
+    for (int i = 0; i < MTL; ++i) {
+      int64_t m = m0 + wave * (8 * MTL) + i * 8 + arow;
+      if (m >= p.M) m = p.M - 1;                                   // tail rows read the last valid row, never stored
+      xrow[i] = p.x + m * K + ac * 4;
+    }
+    wtile = wbytes + (int64_t)n0 * kw * 2;
+  };
+  // x (kt + 2) is requested at the END of a group's non-MFMA half, travels during that group's MFMA phase and is split at the
+  // top of its next non-MFMA half.  What keeps hipcc from undoing that: the requests cannot cross the s_barrier that follows
+  // them (sched_barrier + the barrier's memory semantics); pin_a() -- an empty asm that "rewrites" the registers, placed behind
+  // the NEXT step's barrier -- keeps everything computed from the data below that barrier (unpinned, the split arithmetic is
+  // hoisted up to the loads and both sink into the MFMA phase behind a vmcnt(0)); the barriers in between wait with
+  // vmcnt(MT), which leaves exactly these MT requests in flight.
   auto load_a = [&](int kt) {
+    // (a k-step of W's zero padding: any valid address will do, the products vanish)
+    const int ko = kt * 32 + 32 <= K ? kt * 32 : K - 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const float4*>(xrow[i] + kt * 32);
+    for (int i = 0; i < MTL; ++i) av[i] = *reinterpret_cast<const f32x4*>(xrow[i] + ko);
+  };
+  auto pin_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < MTL; ++i) asm volatile("" : "+v"(av[i]));
   };
   auto dma_w = [&](unsigned char* st, int kt) {
+    constexpr int PPW = G::WPIECES / 4;                                        // pieces per wave of group A
+    constexpr int RB = G::BN / 16;                                             // 16-row blocks of the W tile
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbytes + w_src[t] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(st + w_lds[t]), 16, 0, 0);
+    for (int t = 0; t < PPW; ++t) {
+      const int P = (wave & 3) * PPW + t;                                      // (wave-uniform)
+      const int plane = P / RB, rblk = P % RB;
+      const unsigned char* src = wtile + (int64_t)plane * p.w_plane_bytes + (int64_t)rblk * 16 * kw * 2 + kt * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + w_lane),
+                                       (__attribute__((address_space(3))) void*)(st + plane * G::WPLANE + rblk * 1024), 16, 0, 0);
+    }
   };
   auto store_a = [&](unsigned char* st) {
+    pin_a();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MTL; ++i) {
       uint2 h, m, l;
-      x6_split4(av[i], h, m, l);
+      x6_split4(make_float4(av[i][0], av[i][1], av[i][2], av[i][3]), h, m, l);
       *reinterpret_cast<uint2*>(st + a_lds[i]) = h;
-      *reinterpret_cast<uint2*>(st + X6_APLANE + a_lds[i]) = m;
-      *reinterpret_cast<uint2*>(st + 2 * X6_APLANE + a_lds[i]) = l;
+      *reinterpret_cast<uint2*>(st + G::APLANE + a_lds[i]) = m;
+      *reinterpret_cast<uint2*>(st + 2 * G::APLANE + a_lds[i]) = l;
     }
   };
-  auto compute = [&](const unsigned char* st) {
-    bf16x8 xf[3][4];
+  auto read_frags = [&](const unsigned char* stx, const unsigned char* stw) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[pl][j] = *reinterpret_cast<const bf16x8*>(st + offx + pl * X6_APLANE + j * 1024);
+      for (int j = 0; j < MT; ++j) xf[pl][j] = *reinterpret_cast<const bf16x8*>(stx + offx + pl * G::APLANE + j * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16x8 wh = *reinterpret_cast<const bf16x8*>(st + offw + i * 1024);
-      const bf16x8 wmid = *reinterpret_cast<const bf16x8*>(st + offw + X6_WPLANE + i * 1024);
-      const bf16x8 wl = *reinterpret_cast<const bf16x8*>(st + offw + 2 * X6_WPLANE + i * 1024);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xf[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xf[2][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xf[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmid, xf[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xf[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xf[0][j], acc[i][j], 0, 0, 0);
-      }
+      for (int i = 0; i < 4; ++i) wf[pl][i] = *reinterpret_cast<const bf16x8*>(stw + offw + pl * G::WPLANE + i * 1024);
     }
+  };
+  auto mfma_all = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2][i], xf[0][j], acc[i][j], 0, 0, 0);     // l h
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[2][j], acc[i][j], 0, 0, 0);     // h l
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[1][j], acc[i][j], 0, 0, 0);     // m m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], xf[0][j], acc[i][j], 0, 0, 0);     // m h
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[1][j], acc[i][j], 0, 0, 0);     // h m
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], xf[0][j], acc[i][j], 0, 0, 0);     // h h
+      }
+  };
+  // Barrier forms.  FULL: every memory operation of this wave done (its LDS-DMA pieces have landed, its LDS writes are
+  // visible).  LDS: only the LDS operations -- group A leaves its LDS-DMA of the next W tile in flight across the half-step.
+  // (sched_barrier: the MFMAs are register-only instructions, hipcc's scheduler would otherwise move them across the
+  // s_barrier into the other half-step, where the SIMD's partner wave has ITS MFMA phase)
+  // Priority: the wave in its read / split half runs beside its SIMD partner's back-to-back MFMAs and, at equal priority, gets
+  // about ONE instruction issued per MFMA (16 cycles): its ~180 instructions took ~2900 cycles against the partner's 1536
+  // (s_memtime stamps, probe build).  Raised to priority 1 for that half it issues at once; the MFMA stream needs one issue slot
+  // per 16 cycles and loses nothing.
+  auto prio_hi = [&]() { __builtin_amdgcn_s_setprio(1); };
+  auto prio_lo = [&]() { __builtin_amdgcn_s_setprio(0); };
+  int stamp_n = 0;
+  (void)stamp_n;
+  auto bar_full = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    X6_WAIT_ALL();
+    X6_STAMP();
+    __builtin_amdgcn_s_barrier();
+    X6_STAMP();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar_lds = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    X6_WAIT_LGKM0();
+    X6_STAMP();
+    __builtin_amdgcn_s_barrier();
+    X6_STAMP();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // all but this wave's MTL youngest vector-memory operations done (its x requests stay in flight, its LDS-DMA has landed)
+  auto bar_keep = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    X6_WAIT(MTL, 0);
+    X6_STAMP();
+    __builtin_amdgcn_s_barrier();
+    X6_STAMP();
+    __builtin_amdgcn_sched_barrier(0);
   };
 
-  // One barrier per k-step: step kt computes from its stage while x (kt + 1) is on its way to registers and W (kt + 1) to the
-  // other stage; the split of x (kt + 1) is written behind the MFMAs.
-  load_a(0);
-  dma_w(s0, 0);
-  store_a(s0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 1 < nk) { load_a(kt + 1); dma_w(s1, kt + 1); }
-    compute(s0);
-    if (kt + 1 < nk) store_a(s1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 2 < nk) { load_a(kt + 2); dma_w(s0, kt + 2); }
-    compute(s1);
-    if (kt + 2 < nk) store_a(s0);
-    __syncthreads();
+  const int64_t n_tiles = p.n_wg;
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  // Both groups pass 2 nk + 1 barriers per tile: B1 (t) "stage t complete", B2 (t) between the half-steps, and one after the
+  // last step ("every fragment is in registers, both stages are free").
+  int64_t tile = slot;
+  if (grp_a) {
+    // ------------------------------------------------------------------ group A: [fragment reads, split | W DMA, x request, MFMA]
+    // (the LDS-DMA pieces and the x requests leave at the TOP of the MFMA phase: among MFMAs an LDS-DMA piece costs ~60 issue
+    // cycles, inside the read / split half 100-185, and six of them in front of the fragment reads made that half -- a chain of
+    // latencies, not of throughputs -- twice as long as the partner's MFMA phase)
+    auto mfma_phase = [&](unsigned char* stw_next, int kt_next_w, int kt_next_x) {
+      if (kt_next_w >= 0) dma_w(stw_next, kt_next_w);
+      // (the x requests must be the wave's YOUNGEST vector-memory operations: the next barrier waits with vmcnt(MTL))
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt_next_x >= 0) load_a(kt_next_x);
+      // no MFMA above this point (each reads an accumulator), no request below it
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]) : : "memory");
+      mfma_all();
+    };
+    for (; tile < n_tiles; tile += grid) {
+      tile_setup(tile);
+      zero_acc();
+      dma_w(sw0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(0);
+      store_a(sx0);
+      load_a(1);
+      for (int kt = 0; kt + 2 < nk; kt += 2) {
+        bar_keep();                              // B1 (kt): W (kt) has landed
+        prio_hi();
+        read_frags(sx0, sw0);
+        store_a(sx1);                            // x (kt + 1)
+        prio_lo();
+        bar_lds();                               // B2 (kt)
+        mfma_phase(sw1, kt + 1, kt + 2);         // W (kt + 1) -> stage 1 (free since B1 (kt)), wanted at B1 (kt + 1)
+        bar_keep();                              // B1 (kt + 1)
+        prio_hi();
+        read_frags(sx1, sw1);
+        store_a(sx0);                            // x (kt + 2)
+        prio_lo();
+        bar_lds();                               // B2 (kt + 1)
+        mfma_phase(sw0, kt + 2, kt + 3);
+      }
+      bar_keep();                                // B1 (nk - 2)
+      prio_hi();
+      read_frags(sx0, sw0);
+      store_a(sx1);                              // x (nk - 1)
+      prio_lo();
+      bar_lds();                                 // B2 (nk - 2)
+      mfma_phase(sw1, nk - 1, -1);
+      bar_full();                                // B1 (nk - 1)
+      prio_hi();
+      read_frags(sx1, sw1);
+      prio_lo();
+      bar_lds();                                 // B2 (nk - 1)
+      mfma_all();
+      bar_full();                                // end of tile
+      x6_epilogue<GELU, MT>(p, acc, x6_ep_region<MT, NWN>(sx1, sw1, wave), m0 + wm * (16 * MT), n0 + wn * 64, lane);
+    }
+  } else {
+    // ------------------------------------------------------------------ group B: [MFMA of the step before | reads, split, x request]
+    for (; tile < n_tiles; tile += grid) {
+      tile_setup(tile);
+      zero_acc();
+      load_a(0);
+      store_a(sx0);
+      load_a(1);
+      bar_keep();                                // B1 (0)
+      bar_keep();                                // B2 (0)
+      prio_hi();
+      read_frags(sx0, sw0);
+      store_a(sx1);                              // x (1)
+      load_a(2);
+      prio_lo();
+      for (int kt = 1; kt + 2 < nk; kt += 2) {
+        bar_keep();                              // B1 (kt), kt odd: stage 1
+        mfma_all();                              // step kt - 1
+        bar_keep();                              // B2 (kt)
+        prio_hi();
+        read_frags(sx1, sw1);
+        store_a(sx0);                            // x (kt + 1)
+        load_a(kt + 2);
+        prio_lo();
+        bar_keep();                              // B1 (kt + 1): stage 0
+        mfma_all();                              // step kt
+        bar_keep();                              // B2 (kt + 1)
+        prio_hi();
+        read_frags(sx0, sw0);
+        store_a(sx1);                            // x (kt + 2)
+        load_a(kt + 3);                          // (kt + 3 <= nk - 1; at nk - 1 ... nk the requests repeat the last block)
+        prio_lo();
+      }
+      bar_keep();                                // B1 (nk - 1)
+      mfma_all();                                // step nk - 2
+      bar_full();                                // B2 (nk - 1)
+      prio_hi();
+      read_frags(sx1, sw1);
+      prio_lo();
+      bar_full();                                // end of tile
+      mfma_all();                                // step nk - 1
+      x6_epilogue<GELU, MT>(p, acc, x6_ep_region<MT, NWN>(sx1, sw1, wave), m0 + wm * (16 * MT), n0 + wn * 64, lane);
+    }
   }
-  // the stages are free after the last barrier: every wave transposes through its own 8 KiB of s0
-  x6_epilogue<GELU>(p, acc, s0 + wave * 8192, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
-// (N, K) f32 -> (3, N, K) bf16 planes
+// (N, K) f32 -> (3, N, Kp) bf16 planes, Kp = K rounded up to a multiple of 64, the padding zero
 __global__ void __launch_bounds__(256)
-x6_pack_kernel(uint16_t* __restrict__ w3, const float* __restrict__ w, int64_t total4, int64_t plane_elems) {
+x6_pack_kernel(uint16_t* __restrict__ w3, const float* __restrict__ w, int64_t n_rows, int K, int Kp) {
+  const int64_t per_row = Kp / 4;
+  const int64_t total4 = n_rows * per_row;
+  const int64_t plane_elems = n_rows * Kp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row;
+    const int k = (int)(i % per_row) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) v = *reinterpret_cast<const float4*>(w + r * K + k);
     uint2 h, m, l;
-    x6_split4(reinterpret_cast<const float4*>(w)[i], h, m, l);
+    x6_split4(v, h, m, l);
     *reinterpret_cast<uint2*>(w3 + i * 4) = h;
     *reinterpret_cast<uint2*>(w3 + plane_elems + i * 4) = m;
     *reinterpret_cast<uint2*>(w3 + 2 * plane_elems + i * 4) = l;
@@ -274,34 +483,78 @@ x6_pack_kernel(uint16_t* __restrict__ w3, const float* __restrict__ w, int64_t t
 
 }  // namespace
 
+static int g_x6_mt = 0;      // 0: tile shape chosen per launch; probe: 1 .. 4 = (64 MT) x 128, 12 / 14 = 64 / 128 rows x 256
+
 extern "C" {
 
+void hfl_internal_set_x6_mt(int v) { g_x6_mt = v; }
+#ifdef HFL_X6_STAMPS
+int hfl_internal_x6_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x6_stamps), sizeof(g_x6_stamps));
+}
+#endif
+
+int64_t hfl_linear_x6_padded_k(int64_t in_features) { return (in_features + 63) / 64 * 64; }
+
 int hfl_linear_x6_pack(uint16_t* w3, const float* w, int64_t out_features, int64_t in_features, hfl_stream_t stream) {
-  if (w3 == nullptr || w == nullptr || out_features <= 0 || in_features <= 0 || in_features % 4 != 0) return HFL_EINVAL;
-  const int64_t total4 = out_features * in_features / 4;
-  const int64_t need = hfl_cdiv(total4, 256);
-  x6_pack_kernel<<<(int)(need < 4096 ? need : 4096), 256, 0, static_cast<hipStream_t>(stream)>>>(w3, w, total4,
-                                                                                                 out_features * in_features);
+  if (w3 == nullptr || w == nullptr || out_features <= 0 || in_features <= 0 || in_features % 32 != 0) return HFL_EINVAL;
+  const int64_t kp = hfl_linear_x6_padded_k(in_features);
+  const int64_t need = hfl_cdiv(out_features * kp / 4, 256);
+  x6_pack_kernel<<<(int)(need < 4096 ? need : 4096), 256, 0, static_cast<hipStream_t>(stream)>>>(w3, w, out_features,
+                                                                                                 (int)in_features, (int)kp);
   HFL_RETURN_LAST_ERROR();
 }
 
 int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
                   const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream) {
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
-  if (in_features % 32 != 0 || out_features % X6_BN != 0) return HFL_EINVAL;
+  if (in_features % 32 != 0 || out_features % 128 != 0) return HFL_EINVAL;
   if (out == nullptr || x == nullptr || w3 == nullptr) return HFL_EINVAL;
   if (gelu && (residual != nullptr || row_scale != nullptr)) return HFL_EINVAL;
-  if ((int64_t)3 * out_features * in_features * 2 >= ((int64_t)1 << 32)) return HFL_ECAPACITY;   // 32-bit DMA source offsets
+  const int64_t kp = hfl_linear_x6_padded_k(in_features);
+  if ((int64_t)out_features * kp * 2 >= ((int64_t)1 << 31)) return HFL_ECAPACITY;          // 32-bit offsets inside a W plane
   if (n_rows == 0) return HFL_OK;
   X6Params p;
   p.out = out; p.x = x; p.w3 = w3; p.bias = bias; p.residual = residual; p.row_scale = row_scale;
   p.M = n_rows; p.N = out_features; p.K = in_features;
-  p.tiles_n = out_features / X6_BN;
-  p.n_wg = hfl_cdiv(n_rows, X6_BM) * p.tiles_n;
+  p.nk = (int)(kp / 32);
+  p.w_plane_bytes = (int64_t)out_features * kp * 2;
+  // Tile shape per launch.  Wide tiles (256 features) where the feature count allows: half the x rows to split per MFMA.  Row
+  // tiles of 16 MT x (8 / NWN) rows, one persistent workgroup per CU: a launch costs ceil(tiles / CUs) rounds of (rows + c)
+  // units; a taller tile re-uses the W tile over more rows, a shorter one wastes less of the last round.
+  const int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
+  int shape = g_x6_mt;                   // probe: 1 .. 4 = 64 MT x 128, 12 / 14 = 64 / 128 x 256
+  static const int kShapes[6][3] = {{4, 2, 256}, {3, 2, 192}, {2, 2, 128}, {1, 2, 64}, {4, 4, 128}, {2, 4, 64}};   // MT, NWN, rows
+  int pick = -1;
+  if (shape >= 1 && shape <= 4) pick = 4 - shape;
+  else if (shape == 14) pick = 4;
+  else if (shape == 12) pick = 5;
+  if (pick >= 4 && out_features % 256 != 0) pick = -1;
+  if (pick < 0) {
+    double best = 0.0;
+    for (int c = 0; c < 6; ++c) {
+      const int bn = kShapes[c][1] * 64, bm = kShapes[c][2];
+      if (out_features % bn != 0) continue;
+      const int64_t tiles = hfl_cdiv(n_rows, bm) * (out_features / bn);
+      // units of 64 rows x 128 features; the narrow tiles pay the split twice per unit of MFMA work
+      const double cost = (double)hfl_cdiv(tiles, cus) * ((bm / 64.0) * (bn / 128.0) * (bn == 128 ? 1.25 : 1.0) + 0.6);
+      if (pick < 0 || cost < best) { best = cost; pick = c; }
+    }
+  }
+  const int mt = kShapes[pick][0], nwn = kShapes[pick][1];
+  p.tiles_n = out_features / (nwn * 64);
+  p.n_wg = hfl_cdiv(n_rows, kShapes[pick][2]) * p.tiles_n;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
+  const unsigned grid = (unsigned)(p.n_wg < cus ? p.n_wg : cus);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (gelu) gemm_x6_kernel<1><<<(unsigned)p.n_wg, 512, 0, s>>>(p);
-  else gemm_x6_kernel<0><<<(unsigned)p.n_wg, 512, 0, s>>>(p);
+#define HFL_X6_LAUNCH(G, M, W) gemm_x6_kernel<G, M, W><<<grid, 512, 0, s>>>(p)
+#define HFL_X6_SHAPES(G)                                                                            \
+  if (nwn == 4) { if (mt == 4) HFL_X6_LAUNCH(G, 4, 4); else HFL_X6_LAUNCH(G, 2, 4); }                \
+  else if (mt == 4) HFL_X6_LAUNCH(G, 4, 2); else if (mt == 3) HFL_X6_LAUNCH(G, 3, 2);               \
+  else if (mt == 2) HFL_X6_LAUNCH(G, 2, 2); else HFL_X6_LAUNCH(G, 1, 2);
+  if (gelu) { HFL_X6_SHAPES(1) } else { HFL_X6_SHAPES(0) }
+#undef HFL_X6_SHAPES
+#undef HFL_X6_LAUNCH
   HFL_RETURN_LAST_ERROR();
 }
 

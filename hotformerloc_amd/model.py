@@ -39,6 +39,19 @@ from .plan import WindowPlan
 
 _FORCE_TRAIN_PATH = False
 
+# Configuration surface.  PRODUCT switches (read from the environment at import, each selects a tested mode):
+#   HFL_GEMM = x3 | x6 | fp32 | bf16x3     Linear arithmetic (set_gemm_mode): split precision (default), matched precision, ...
+#   HFL_CHECKPOINT = auto | always | never activation checkpointing policy of the training path (set_checkpoint_policy)
+#   HFL_CHECKPOINT_FREE_FRACTION           its memory threshold
+# Everything else below is a PROBE knob of the A/B scripts under tools/ (profiles/*_ab_*.log): the schedule and fusion choices
+# those measurements settled.  They keep their measured defaults unless HFL_PROBES=1 is set in the environment.
+_PROBES = os.environ.get('HFL_PROBES', '0') == '1'
+
+
+def _knob(name: str, default: str) -> str:
+    return os.environ.get(name, default) if _PROBES else default
+
+
 
 def _grad_path(x=None) -> bool:
     """True when autograd must see the op (training / fine-tuning): route through the
@@ -85,32 +98,32 @@ def _add_ln(x, y, m: nn.LayerNorm):
 # on the fp32 matrix cores -- the reference's own arithmetic (models/layers/octformer_layers.py:53-59,
 # models/octformer_backbone.py:52-93) without a library GEMM in the transformer blocks.
 _GEMM_MODE = os.environ.get('HFL_GEMM', 'x3')
-_PYRAMID_STREAMS = os.environ.get('HFL_PYRAMID_STREAMS', '1') != '0'
-_SIDE_STREAM_MAX_ROWS = int(os.environ.get('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
+_PYRAMID_STREAMS = _knob('HFL_PYRAMID_STREAMS', '1') != '0'
+_SIDE_STREAM_MAX_ROWS = int(_knob('HFL_SIDE_STREAM_MAX_ROWS', '32768'))
 # training-path Linear layers on split-bf16 GEMMs (autograd.LinearSplitFn).  Off by default: parity-tested, but
 # at 191 ms/step (B=32, Wild-Places) still slower than the fp32 hipBLASLt route (145 ms) because the operand
 # splits of the backward are torch element-wise passes; needs fused split kernels to pay off.
-_TRAIN_SPLIT = os.environ.get('HFL_TRAIN_SPLIT', '0') != '0'
+_TRAIN_SPLIT = _knob('HFL_TRAIN_SPLIT', '0') != '0'
 # training-path Linear layers on the hand-written split GEMMs (autograd.LinearX3Fn: forward + dx on hfl_linear_x3, dW / db
 # on hfl_wgrad_x3)
-_TRAIN_X3 = os.environ.get('HFL_TRAIN_X3', '1') != '0'
-_ATTN_F16 = os.environ.get('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
-_TRAIN_LN = os.environ.get('HFL_TRAIN_LN', '1') != '0'    # training-path LayerNorm: HIP forward + backward kernels
-_TRAIN_MLP = os.environ.get('HFL_TRAIN_MLP', '1') != '0'          # fused fc1 -> GELU -> fc2 autograd Function
-_GROUPED_TAPS = os.environ.get('HFL_GROUPED_TAPS', '1') != '0'     # live-tap convolutions: one grouped x3 launch for all taps
-_SPARSE_CONV = os.environ.get('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
-_GATHER_IN_GEMM = os.environ.get('HFL_GATHER_IN_GEMM', '1') != '0'   # grouped tap GEMM gathers its A rows itself
-_LT_EPILOGUE = os.environ.get('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
-_EARLY_PHASE = os.environ.get('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
-_DROP_POOL = os.environ.get('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
+_TRAIN_X3 = _knob('HFL_TRAIN_X3', '1') != '0'
+_ATTN_F16 = _knob('HFL_ATTN_F16', '1') != '0'   # fp16 (hi, lo) MFMA window attention where eligible (A/B switch)
+_TRAIN_LN = _knob('HFL_TRAIN_LN', '1') != '0'    # training-path LayerNorm: HIP forward + backward kernels
+_TRAIN_MLP = _knob('HFL_TRAIN_MLP', '1') != '0'          # fused fc1 -> GELU -> fc2 autograd Function
+_GROUPED_TAPS = _knob('HFL_GROUPED_TAPS', '1') != '0'     # live-tap convolutions: one grouped x3 launch for all taps
+_SPARSE_CONV = _knob('HFL_SPARSE_CONV', '1') != '0'    # large 3x3x3 convs over live taps only
+_GATHER_IN_GEMM = _knob('HFL_GATHER_IN_GEMM', '1') != '0'   # grouped tap GEMM gathers its A rows itself
+_LT_EPILOGUE = _knob('HFL_LT_EPILOGUE', '1') != '0'      # proj / fc2: bias + residual in the GEMM launch
+_EARLY_PHASE = _knob('HFL_EARLY_PHASE', '1') != '0'      # token-row half of a block issued before / beside RTSA
+_DROP_POOL = _knob('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draws of a forward in one batch of launches
 # LN1 -> qkv -> window attention of a relay-token block's token rows as one launch (csrc/attn_ws.hip) from this many token rows
-_RTSA_SEGMENTS = os.environ.get('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
-_TRAIN_CPE_FUSED = os.environ.get('HFL_TRAIN_CPE_FUSED', '1') != '0'  # training CPE forward as the fused launch (autograd.CpeFn)
-_RELAY_IN_PLACE = os.environ.get('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
-_ATTN_WS = os.environ.get('HFL_ATTN_WS', '1') != '0'
-_ATTN_WS_MIN_ROWS = int(os.environ.get('HFL_ATTN_WS_MIN_ROWS', '40000'))
-_ATTN_WS_EARLY = os.environ.get('HFL_ATTN_WS_EARLY', '0') != '0'   # keep the early-phase schedule beside it (A/B, tests)
-_MERGED_ATTN = os.environ.get('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
+_RTSA_SEGMENTS = _knob('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
+_TRAIN_CPE_FUSED = _knob('HFL_TRAIN_CPE_FUSED', '1') != '0'  # training CPE forward as the fused launch (autograd.CpeFn)
+_RELAY_IN_PLACE = _knob('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
+_ATTN_WS = _knob('HFL_ATTN_WS', '1') != '0'
+_ATTN_WS_MIN_ROWS = int(_knob('HFL_ATTN_WS_MIN_ROWS', '40000'))
+_ATTN_WS_EARLY = _knob('HFL_ATTN_WS_EARLY', '0') != '0'   # keep the early-phase schedule beside it (A/B, tests)
+_MERGED_ATTN = _knob('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
 
 
 def set_train_split(enabled: bool):
@@ -212,8 +225,8 @@ def _block_tail_x6(x, attn_out, proj: nn.Linear, norm2: nn.LayerNorm, mlp: 'MLP'
 # that the three-launch form is as fast ALONE.  In the step the coarse pyramid levels' chains are launch-bound: with them on the
 # fused launches too -- hidden / feature dimension split over the chip -- three alternating runs gave 2952-2975 clouds/s against
 # 2914-2947, profiles/r05_g_ab.log.)
-_MLP_FUSED = os.environ.get('HFL_MLP_FUSED', '1') != '0'
-_MLP_FUSED_MIN_ROWS = int(os.environ.get('HFL_MLP_FUSED_MIN_ROWS', '1000'))
+_MLP_FUSED = _knob('HFL_MLP_FUSED', '1') != '0'
+_MLP_FUSED_MIN_ROWS = int(_knob('HFL_MLP_FUSED_MIN_ROWS', '1000'))
 
 
 def _mlp_pack(mlp: 'MLP', rows: int):
@@ -241,25 +254,25 @@ def _mlp_pack(mlp: 'MLP', rows: int):
 # was less than half full (66 775 rows, 2.04 rounds: three passes, 153 vs 127 us); since the left-over rows are computed with
 # the output features split over the workgroups (round 4) that shape takes 101 us and the restriction is gone
 # (HFL_QKV_FUSED_MIN_FILL restores it).
-_QKV_FUSED = os.environ.get('HFL_QKV_FUSED', '1') != '0'
-_QKV_FUSED_MIN_ROWS = int(os.environ.get('HFL_QKV_FUSED_MIN_ROWS', '1000'))
-_RTSA_MLP_FUSED = os.environ.get('HFL_RTSA_MLP_FUSED', '1') != '0'
+_QKV_FUSED = _knob('HFL_QKV_FUSED', '1') != '0'
+_QKV_FUSED_MIN_ROWS = int(_knob('HFL_QKV_FUSED_MIN_ROWS', '1000'))
+_RTSA_MLP_FUSED = _knob('HFL_RTSA_MLP_FUSED', '1') != '0'
 # relay-token block: LN1 -> qkv as ONE launch (csrc/qkv_fused.hip, output features split over the chip for the ~2 k rows) and
 # the ragged attention reading its fp16 (hi, lo) rows and writing attention.proj's split2 operand itself
 # (hfl_relay_attention_f16_fwd): LayerNorm, qkv GEMM, memset, attention, split2 -> two launches.  The block is a chain of tiny
 # launches on the cycle every H-OSA iteration waits for.
-_RTSA_SLIM = os.environ.get('HFL_RTSA_SLIM', '1') != '0'
+_RTSA_SLIM = _knob('HFL_RTSA_SLIM', '1') != '0'
 # LN1 -> qkv -> window attention of the blocks without relay tokens (OctFormer stage) as one launch (csrc/attn_fused.hip)
-_ATTN_FUSED = os.environ.get('HFL_ATTN_FUSED', '1') != '0'
+_ATTN_FUSED = _knob('HFL_ATTN_FUSED', '1') != '0'
 # attentional pooling of the head as one launch per level (csrc/attn_pool.hip) instead of GEMM + segment softmax + two
 # padding copies + batched GEMM
-_ATTN_POOL = os.environ.get('HFL_ATTN_POOL', '1') != '0'
+_ATTN_POOL = _knob('HFL_ATTN_POOL', '1') != '0'
 # join every pyramid stream at the end of every H-OSA iteration (the schedule of rounds 2-3); 0: only the true dependencies
-_ITER_JOIN = os.environ.get('HFL_ITER_JOIN', '0') != '0'
-_PLAN_LATE = os.environ.get('HFL_PLAN_LATE', '1') != '0'           # window plan built after the stem has been issued
+_ITER_JOIN = _knob('HFL_ITER_JOIN', '0') != '0'
+_PLAN_LATE = _knob('HFL_PLAN_LATE', '1') != '0'           # window plan built after the stem has been issued
 # relay-token self-attention on a stream of its own (1) or on the finest level's, behind that level's CPE / LN1 / qkv (0)
-_RTSA_STREAM = os.environ.get('HFL_RTSA_STREAM', '1') != '0'
-_QKV_FUSED_MIN_FILL = float(os.environ.get('HFL_QKV_FUSED_MIN_FILL', '0.0'))
+_RTSA_STREAM = _knob('HFL_RTSA_STREAM', '1') != '0'
+_QKV_FUSED_MIN_FILL = float(_knob('HFL_QKV_FUSED_MIN_FILL', '0.0'))
 
 
 def _qkv_pack(att: 'OctreeAttention', rows: int):
@@ -329,7 +342,7 @@ class SplitLinear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
-_TAP_STREAMS = int(os.environ.get('HFL_TAP_STREAMS', '1'))       # >1: per-tap GEMMs on a stream pool (measured neutral)
+_TAP_STREAMS = int(_knob('HFL_TAP_STREAMS', '1'))       # >1: per-tap GEMMs on a stream pool (measured neutral)
 _TAP_POOLS = {}
 
 
@@ -874,7 +887,7 @@ def _init_layer_scale(block, dim, layer_scale):
         block.gamma1 = block.gamma2 = 1
 
 
-_NATIVE_BLOCK = os.environ.get('HFL_NATIVE_BLOCK', '1') != '0'     # inference blocks as one native call (hfl_block_forward_x3)
+_NATIVE_BLOCK = _knob('HFL_NATIVE_BLOCK', '1') != '0'     # inference blocks as one native call (hfl_block_forward_x3)
 
 
 _F16_OK_CACHE = {}
@@ -1671,7 +1684,7 @@ class FeatureMixerLayer(nn.Module):
         return x + self.mix(x)
 
 
-_MIXER_FUSED = os.environ.get('HFL_MIXER_FUSED', '1') != '0'
+_MIXER_FUSED = _knob('HFL_MIXER_FUSED', '1') != '0'
 
 
 def _mixer_pack(fc1: nn.Linear, fc2: nn.Linear):

@@ -472,18 +472,19 @@ def linear_x3(x2: torch.Tensor, w2: torch.Tensor, bias=None, residual=None, gelu
 
 
 def x6_pack(w: torch.Tensor) -> torch.Tensor:
-    """(N, K) fp32 Linear weight -> its three bf16 planes (3, N, K) for `linear_x6` (hfl_linear_x6_pack, once per parameter)."""
+    """(N, K) fp32 Linear weight -> its three bf16 planes (3, N, Kp) for `linear_x6` (hfl_linear_x6_pack, once per parameter;
+    Kp = K rounded up to a multiple of 64, zero-padded)."""
     _dev(w)
     wc = _f32c(w.detach())
     n, k = wc.shape
     assert k % 32 == 0 and n % 128 == 0
-    w3 = torch.empty((3, n, k), dtype=torch.bfloat16, device=w.device)
+    w3 = torch.empty((3, n, (k + 63) // 64 * 64), dtype=torch.bfloat16, device=w.device)
     check(_native.load().hfl_linear_x6_pack(w3.data_ptr(), wc.data_ptr(), n, k, _stream()), 'hfl_linear_x6_pack')
     return w3
 
 
 def linear_x6_ok(in_features: int, out_features: int) -> bool:
-    return in_features % 32 == 0 and out_features % 128 == 0 and 6 * in_features * out_features < 2 ** 32
+    return in_features % 32 == 0 and out_features % 128 == 0 and 2 * (in_features + 32) * out_features < 2 ** 31
 
 
 def linear_x6(x: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, gelu: bool = False, out=None,
@@ -495,7 +496,7 @@ def linear_x6(x: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, gelu:
     xc = _f32c(x)
     m, k = xc.shape
     n = w3.shape[1]
-    assert w3.shape[2] == k
+    assert w3.shape[2] == (k + 63) // 64 * 64
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     else:

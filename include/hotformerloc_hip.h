@@ -476,11 +476,13 @@ int hfl_layer_norm_relu(float* out_f32, uint16_t* out_split2, const float* x, co
  * one fp32 rounding of the product).  Replaces torch.nn.Linear (fp32) and the element-wise op after it in the transformer blocks
  * (models/octformer_backbone.py:70,91,275-278; models/layers/octformer_layers.py:53-59; models/hotformerloc_backbone.py:213-216)
  * for callers that want the reference's own arithmetic rather than the 16-bit-operand split of section 9b.
- *   w3 (3, out_features, in_features) bf16 = hfl_linear_x6_pack(w (out_features, in_features) f32), once per parameter;
+ *   w3 (3, out_features, Kp) bf16 = hfl_linear_x6_pack(w (out_features, in_features) f32), once per parameter;
+ *      Kp = hfl_linear_x6_padded_k(in_features) = in_features rounded up to a multiple of 64 (zero padding);
  *   x (n_rows, in_features) f32 as any producer left it (the split happens on the way into LDS);
  *   gelu = 1: out = gelu(acc + bias), exact-erf GELU (residual and row_scale must be NULL);
  *   gelu = 0: out = (acc + bias) [* row_scale[row]] [+ residual] (residual may alias out).
  * in_features % 32 == 0, out_features % 128 == 0. */
+int64_t hfl_linear_x6_padded_k(int64_t in_features);
 int hfl_linear_x6_pack(uint16_t* w3, const float* w, int64_t out_features, int64_t in_features, hfl_stream_t stream);
 int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
                   const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream);

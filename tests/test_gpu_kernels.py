@@ -1,6 +1,7 @@
 """GPU parity tests, kernel by kernel: HIP path (through the C-ABI) vs the CPU oracle on the
 same seeded inputs.  Bit-exact for integer/index work, stated tolerances for fp32."""
 
+import ctypes
 import os
 
 import numpy as np
@@ -777,6 +778,69 @@ def test_linear_x3_matches_fp64_linear():
         # the same (hi, lo) pairs as the K-concatenated producer
         a3 = ops.layer_norm_split3(x.to(DEV), w.to(DEV), b.to(DEV)).float().cpu()
         assert torch.equal(got, a3[:, :C] + a3[:, 2 * C:])
+
+
+def test_linear_x6_planes_are_exact_and_layout():
+    """hfl_linear_x6_pack: the three bf16 planes of a weight sum to the fp32 value EXACTLY (h = RNE(v), m = RNE(v - h),
+    l = RNE(v - h - m); 3 x 8 significand bits cover fp32's 24), laid out (3, N, K); and the product of small integers is exact
+    with every epilogue (bias, residual in place, row scale) at every row-tile height incl. ragged tails."""
+    g = torch.Generator().manual_seed(61)
+    w = torch.randn(256, 192, generator=g) * torch.logspace(-6, 3, 192)          # nine decades of magnitude
+    w3 = ops.x6_pack(w.to(DEV)).float().cpu()
+    assert tuple(w3.shape) == (3, 256, 192)
+    w96 = ops.x6_pack(w[:, :96].contiguous().to(DEV)).float().cpu()            # K = 96: padded to 128 with zeros
+    assert tuple(w96.shape) == (3, 256, 128) and torch.equal(w96[:, :, :96], w3[:, :, :96]) and (w96[:, :, 96:] == 0).all()
+    assert torch.equal(w3[0].double() + w3[1].double() + w3[2].double(), w.double())
+    assert (w3[1].abs() <= w3[0].abs() * 2.0 ** -8 + 1e-45).all() and (w3[2].abs() <= w3[0].abs() * 2.0 ** -16 + 1e-45).all()
+    lib = ops._native.load()
+    lib.hfl_internal_set_x6_mt.argtypes = [ctypes.c_int]
+    try:
+        for mt in (0, 1, 2, 3, 4, 12, 14):      # tile shapes: chosen per launch, (64 mt) x 128, 64 x 256, 128 x 256
+            lib.hfl_internal_set_x6_mt(mt)
+            for n, cin, cout in ((1, 64, 128), (63, 32, 128), (257, 96, 384), (700, 256, 256), (2100, 128, 512)):
+                x = torch.randint(-8, 9, (n, cin), generator=g).float()
+                wi = torch.randint(-8, 9, (cout, cin), generator=g).float()
+                b = torch.randint(-8, 9, (cout,), generator=g).float()
+                r = torch.randint(-64, 65, (n, cout), generator=g).float()
+                sc = torch.randint(0, 3, (n,), generator=g).float()
+                ref = x @ wi.t()
+                w6 = ops.x6_pack(wi.to(DEV))
+                assert torch.equal(ops.linear_x6(x.to(DEV), w6).cpu(), ref), (mt, n, cin, cout)
+                assert torch.equal(ops.linear_x6(x.to(DEV), w6, bias=b.to(DEV), residual=r.to(DEV)).cpu(), ref + b + r)
+                assert torch.equal(ops.linear_x6(x.to(DEV), w6, bias=b.to(DEV), residual=r.to(DEV),
+                                                 row_scale=sc.to(DEV)).cpu(), (ref + b) * sc[:, None] + r)
+                buf = r.to(DEV).clone()                                   # x += Linear(.): residual aliases out
+                ops.linear_x6(x.to(DEV), w6, bias=b.to(DEV), residual=buf, out=buf)
+                assert torch.equal(buf.cpu(), ref + b + r)
+    finally:
+        lib.hfl_internal_set_x6_mt(0)
+
+
+def test_linear_x6_is_as_accurate_as_the_fp32_library_gemm():
+    """The matched-precision Linear (three bf16 planes per operand, six plane products, fp32 accumulation) against fp64 on
+    real-valued data, next to torch's fp32 GEMM (hipBLASLt) on the same inputs: relative L2 error not above the library's
+    (+ 10 % slack for the accumulation order) on the row counts of the model's step, and <= 1e-6 absolutely everywhere; GELU
+    epilogue <= 1e-6 of fp64's exact-erf GELU.  (A short, deep product -- 500 x 1024 -- is the one shape class where the
+    library is closer to fp64 than a sequential fp32 dot product, 2.9e-7 against 4.9e-7: it splits K over workgroups there;
+    at 70 000 rows it accumulates like this kernel and reads 5.7e-7.)
+    Reference: torch.nn.Linear in fp32 (models/octformer_backbone.py:70,91; models/layers/octformer_layers.py:53-59)."""
+    g = torch.Generator().manual_seed(62)
+    for n, cin, cout in ((30000, 256, 768), (30000, 128, 512), (30000, 1024, 256), (2049, 256, 1024), (70000, 256, 256),
+                         (500, 1024, 256), (1234, 96, 128)):
+        x = torch.randn(n, cin, generator=g) * 1.3
+        w = torch.randn(cout, cin, generator=g) * 0.05
+        b = torch.randn(cout, generator=g) * 0.1
+        ref = x.double() @ w.double().t() + b.double()
+        xd, w6 = x.to(DEV), ops.x6_pack(w.to(DEV))
+        e6 = ((ops.linear_x6(xd, w6, bias=b.to(DEV)).cpu().double() - ref).norm() / ref.norm()).item()
+        e32 = ((torch.nn.functional.linear(xd, w.to(DEV), b.to(DEV)).cpu().double() - ref).norm() / ref.norm()).item()
+        print('x6 %.2e  fp32 library %.2e  (M %d K %d N %d)' % (e6, e32, n, cin, cout))
+        assert e6 < 1e-6, (e6, e32, n, cin, cout)
+        if n >= 2000:
+            assert e6 <= 1.1 * e32, (e6, e32, n, cin, cout)
+        gl = torch.nn.functional.gelu(ref)
+        eg = ((ops.linear_x6(xd, w6, bias=b.to(DEV), gelu=True).cpu().double() - gl).norm() / gl.norm()).item()
+        assert eg < 1e-6, eg
 
 
 def test_linear_x3_grouped_matches_per_block_products():

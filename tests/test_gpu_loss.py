@@ -107,5 +107,5 @@ def test_multistaged_step_on_the_encoder_matches_oracle_chain():
         gref = sd[n].grad
         err = (p.grad.cpu() - gref).norm().item() / max(gref.norm().item(), 1e-12)
         worst = max(worst, err if gref.norm().item() > 1e-9 else 0.0)
-        assert err < 2e-3 or gref.norm().item() < 1e-9, (n, err, gref.norm().item())
+        assert err < 1e-3 or gref.norm().item() < 1e-9, (n, err, gref.norm().item())      # the forward's bar (north star: 1e-3)
     print('multistaged step: loss', stats['loss'], want.item(), 'worst param-grad rel-L2 vs oracle', worst)

@@ -18,6 +18,7 @@ from oracle import hotformer_ref
 from oracle.testing import load_case, oracle_octree, synthetic_state_dict
 
 REL_TOL = 1e-3
+GRAD_TOL = 1e-3         # parameter gradients: relative L2 per tensor against autograd through the CPU oracle (worst observed 8.5e-4)
 CASES = ['wild_places_b1', 'wild_places_b3', 'wild_places_ragged', 'cs_wild_places_b2', 'oxford_b2', 'cs_campus3d_b2']
 
 
@@ -246,7 +247,7 @@ def test_forward_backward_matches_oracle_autograd(cfg, sizes, linear):
         err = (p.grad.cpu() - gref).norm().item() / max(gref.norm().item(), 1e-12)
         kind = name.split('.')[-1] if 'rpe_table' not in name else 'rpe_table'
         worst[kind] = max(worst.get(kind, 0.0), err)
-        assert err < 2e-3 or gref.norm().item() < 1e-9, (name, err, gref.norm().item())
+        assert err < GRAD_TOL or gref.norm().item() < 1e-9, (name, err, gref.norm().item())
     print(cfg, linear, 'forward rel', rel, 'worst grad rel-L2 per kind', worst)
 
 

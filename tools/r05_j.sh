@@ -1,4 +1,5 @@
 set -x
+export HFL_PROBES=1   # the HFL_* schedule knobs below are probe switches (hotformerloc_amd/model.py)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 300 python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "early_phase or native_block" 2>&1 | tail -3 > gpurun_out/r05_j_test.log

@@ -1,4 +1,5 @@
 set -x
+export HFL_PROBES=1   # the HFL_* schedule knobs below are probe switches (hotformerloc_amd/model.py)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rm -f gpurun_out/r05_u_ab.log

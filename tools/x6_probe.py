@@ -3,7 +3,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
-from hotformerloc_amd import ops
+from hotformerloc_amd import ops, _native
+lib = _native.load()
+lib.hfl_internal_set_x6_mt.argtypes = [__import__('ctypes').c_int]
 
 torch.manual_seed(0)
 dev = 'cuda'
@@ -29,7 +31,7 @@ def rel(a, b):
 shapes = [(68167, 256, 768, 'qkv d4'), (68167, 256, 256, 'proj d4'), (68167, 256, 1024, 'fc1 d4'), (68167, 1024, 256, 'fc2 d4'),
           (118096, 128, 384, 'qkv d5'), (118096, 128, 512, 'fc1 d5'), (118096, 512, 128, 'fc2 d5'),
           (14310, 256, 1024, 'fc1 d3'), (2100, 256, 1024, 'fc1 d2'), (1733, 1024, 256, 'fc2 rt'), (300, 256, 256, 'tiny'),
-          (257, 32, 128, 'edge')]
+          (257, 32, 128, 'edge'), (5000, 96, 128, 'k96')]
 for m, k, n, name in shapes:
     x = torch.randn(m, k, device=dev) * 1.3
     w = torch.randn(n, k, device=dev) * 0.05
@@ -49,6 +51,12 @@ for m, k, n, name in shapes:
     ops.linear_x6(x, w3, bias=b, residual=r2, out=r2)
     ei = rel(r2, ref + r.double())
     t6 = timeit(lambda: ops.linear_x6(x, w3, bias=b))
+    tmt = []
+    for mt in (1, 2, 3, 4, 12, 14):
+        lib.hfl_internal_set_x6_mt(mt)
+        tmt.append(timeit(lambda: ops.linear_x6(x, w3, bias=b, residual=r)))
+    lib.hfl_internal_set_x6_mt(0)
+    tres = timeit(lambda: ops.linear_x6(x, w3, bias=b, residual=r))
     t6g = timeit(lambda: ops.linear_x6(x, w3, bias=b, gelu=True))
     t32 = timeit(lambda: F.linear(x, w, b))
     x2 = ops.split2(x) if k % 32 == 0 else None
@@ -57,3 +65,4 @@ for m, k, n, name in shapes:
     fl = 2.0 * m * k * n
     print('%-8s M=%6d K=%4d N=%4d | err vs fp64: x6 %.2e  fp32 lib %.2e | +res %.2e  gelu %.2e  inplace %.2e | x6 %7.1f us (%5.1f TF, %4.2f of 2.5 PF issued)  x6+gelu %7.1f  fp32 lib %7.1f us (%5.1f TF)  x3 %7.1f us'
           % (name, m, k, n, e6, e32, er, eg, ei, t6, fl / t6 / 1e6, 6 * fl / t6 / 1e6 / 2500.0, t6g, t32, fl / t32 / 1e6, t3))
+    print('         +residual: auto %.1f us; forced tile 64/128/192/256 x 128, 64/128 x 256: %s us' % (tres, ' '.join('%.1f' % t for t in tmt)))
