@@ -795,7 +795,7 @@ def test_linear_x6_planes_are_exact_and_layout():
     lib = ops._native.load()
     lib.hfl_internal_set_x6_mt.argtypes = [ctypes.c_int]
     try:
-        for mt in (0, 1, 2, 3, 4, 12, 14):      # tile shapes: chosen per launch, (64 mt) x 128, 64 x 256, 128 x 256
+        for mt in (0, 2, 4, 12, 14):      # tile shapes: chosen per launch, 128 / 256 rows x 128, 64 / 128 rows x 256
             lib.hfl_internal_set_x6_mt(mt)
             for n, cin, cout in ((1, 64, 128), (63, 32, 128), (257, 96, 384), (700, 256, 256), (2100, 128, 512)):
                 x = torch.randint(-8, 9, (n, cin), generator=g).float()
