@@ -850,7 +850,7 @@ def rowtile_roofline(groups, total):
             'avg_launch_us': round(ms / n * 1e3, 2), 'by_launch_size': by,
             'algorithmic_bytes_per_launch': int(nbytes / n),
             'algorithmic_bytes': 'SURVEY 8(d): 8 B x (row, channel) = read x + write out in f32; 2 M 8 C^2 useful FLOP',
-            'traffic': pmc_traffic('ln_mlp_fused_kernel'), 'traffic_source': 'profiles/r05_pmc_traffic.json (2 x FETCH_SIZE + '
+            'traffic': pmc_traffic('ln_mlp_fused_kernel'), 'traffic_source': 'profiles/r06_pmc_traffic.json (2 x FETCH_SIZE + '
             'WRITE_SIZE per launch, averaged over the launches of the step: separate rocprofv3 --pmc passes of this command)',
             'mfma_busy_pmc': pmc_mfma_busy('r05_mlp_counters.txt') or pmc_mfma_busy('r04_mlp_counters.txt'),
             'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
@@ -875,6 +875,7 @@ def x6_roofline(groups, total):
             'launches': n, 'avg_launch_us': round(ms / n * 1e3, 2),
             'largest_launches': by, 'algorithmic_bytes_per_launch': int(nbytes / n),
             'algorithmic_bytes': 'x (M K 4 B) + out (M N 4 B) [+ residual (M N 4 B)]; 2 M K N useful FLOP',
+            'mfma_busy_pmc': pmc_mfma_busy('r06_x6_counters.txt'),
             'traffic': pmc_traffic('gemm_x6_kernel'), 'traffic_source': 'profiles/r06_pmc_traffic.json when present (2 x FETCH_SIZE + '
             'WRITE_SIZE per launch, separate rocprofv3 --pmc passes)',
             'timing': 'HIP event pair around every launch (ops.KernelTimer), one-stream schedule, after the timed region'}
@@ -933,9 +934,9 @@ def source_sha1(rel):
 def cpe_l1_bound():
     """What bounds hfl_cpe_forward (the depth-wise octree conv + LayerNorm + residual, libs/dwconv/csrc/dwconv.cu:24-42 +
     models/layers/octformer_layers.py:138-142), from the committed L1 / TA / L2 counter survey of its depth-4 launch
-    (tools/cpe_counters.sh -> profiles/r05_cpe_counters.txt): the vector L1 moves one 64-B line per clock and CU, so
+    (tools/cpe_counters.sh -> profiles/r06_cpe_counters.txt): the vector L1 moves one 64-B line per clock and CU, so
     TCP_TOTAL_CACHE_ACCESSES / 256 CUs clocks is the launch's floor; `frac_of_l1_bound` = that floor / the kernel's clocks."""
-    path = os.path.join(ROOT, 'profiles', 'r05_cpe_counters.txt')
+    path = os.path.join(ROOT, 'profiles', 'r06_cpe_counters.txt')
     if not os.path.exists(path):
         return None
     vals, stamps = {}, []
@@ -954,7 +955,7 @@ def cpe_l1_bound():
         return None
     clk = vals['GRBM_GUI_ACTIVE'] / 8.0
     fresh = bool(stamps) and all(source_sha1(rel) == sha for rel, sha in stamps)
-    return {'bound': 'vector L1 line rate (64 B / clock / CU)', 'source': 'profiles/r05_cpe_counters.txt',
+    return {'bound': 'vector L1 line rate (64 B / clock / CU)', 'source': 'profiles/r06_cpe_counters.txt',
             'fresh': fresh,
             'frac_of_l1_bound': round(vals['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256.0 / clk, 3),
             'l1_hit_rate': round(1.0 - vals['TCP_TCC_READ_REQ_sum'] / vals['TCP_TOTAL_CACHE_ACCESSES_sum'], 3),
@@ -970,7 +971,7 @@ def roofline_block(kern, kern_overlapped, sizes, args, kernel_txt, mfma_peak_f32
     n, ms, nbytes, flops, moved = rec
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for cand in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for cand in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         pmc = os.path.join(ROOT, 'profiles', cand)
         if os.path.exists(pmc) and args.config == 'wild-places' and args.batch == 32:
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
