@@ -128,6 +128,8 @@ SIGNATURES = {
     'hfl_relay_token_init_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                                          c_int64, c_void_p]),
     'hfl_linear_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    'hfl_linear_x6_grouped_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                     c_void_p]),
     'hfl_linear_x6_padded_k': (c_int64, [c_int64]),
     'hfl_linear_x6_pack': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'hfl_linear_x6': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -79,7 +79,13 @@ struct X6Params {
   int tiles_n;
   int64_t n_wg;             // tiles of the launch
   int nk;                   // k-steps of 32 (even: W's K is zero-padded to a multiple of 64)
-  int64_t w_plane_bytes;    // bytes of one W plane: N x 32 nk x 2
+  int64_t w_plane_bytes;    // bytes of one W plane: (rows of W) x 32 nk x 2
+  // grouped launch (the per-tap products of an octree convolution over its live (row, tap) pairs): per row tile {first row,
+  // rows (<= the tile height), first row of its W block}; row m of the x operand is x[gather[m]]; n_valid <= 128 features
+  // of the (zero-padded) 128-row W blocks are stored
+  const int32_t* tiles;
+  const int32_t* gather;
+  int n_valid;
 };
 
 __device__ __forceinline__ int x6_swz(int row) { return (0x1320 >> (((row >> 2) & 3) << 2)) & 3; }
@@ -116,7 +122,7 @@ __device__ __forceinline__ unsigned char* x6_ep_region(unsigned char* sx1, unsig
 // writes whole 128-B lines.
 template <int GELU, int MT>
 __device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][MT], unsigned char* ep, int64_t m_tile, int n_tile,
-                                            int lane) {
+                                            int lane, int64_t m_end) {
   const int frow = lane & 15, fq = lane >> 4;
   const int N = p.N;
   const int ecol = lane & 15;
@@ -135,8 +141,8 @@ __device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][M
         const int64_t m = m_tile + j * 16 + it * 4 + fq;
         rs[j][it] = make_float4(0.f, 0.f, 0.f, 0.f);
         rsc[j][it] = 1.0f;
-        if (p.residual != nullptr && m < p.M) rs[j][it] = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
-        if (p.row_scale != nullptr && m < p.M) rsc[j][it] = p.row_scale[m];
+        if (p.residual != nullptr && m < m_end) rs[j][it] = *reinterpret_cast<const float4*>(p.residual + m * N + nbase);
+        if (p.row_scale != nullptr && m < m_end) rsc[j][it] = p.row_scale[m];
       }
   }
 #pragma unroll
@@ -149,7 +155,7 @@ __device__ __forceinline__ void x6_epilogue(const X6Params& p, f32x4 (&acc)[4][M
       const int r = it * 4 + fq;
       const f32x4 a = *reinterpret_cast<const f32x4*>(ep + r * 256 + ((ecol ^ r) << 4));
       const int64_t m = m_tile + j * 16 + r;
-      if (m >= p.M) continue;
+      if (m >= m_end || nbase >= p.n_valid) continue;
       float4 v = make_float4(a[0] + b.x, a[1] + b.y, a[2] + b.z, a[3] + b.w);
       if (GELU) {
         const f32x2 g01 = x3_gelu2((f32x2){v.x, v.y}), g23 = x3_gelu2((f32x2){v.z, v.w});
@@ -248,16 +254,25 @@ gemm_x6_kernel(const X6Params p) {
   int64_t m0 = 0;
   int n0 = 0;
 
+  int64_t m_end = p.M;
   auto tile_setup = [&](int64_t tile) {
     m0 = (tile / p.tiles_n) * G::BM;
     n0 = (int)(tile % p.tiles_n) * G::BN;
+    int64_t w_row0 = n0;
+    if (p.tiles != nullptr) {                                      // grouped launch: this row tile's rows and weight block
+      const int32_t* tt = p.tiles + 3 * (tile / p.tiles_n);
+      m0 = tt[0];
+      m_end = m0 + tt[1];
+      w_row0 = (int64_t)tt[2] + n0;
+    }
 #pragma unroll
     for (int i = 0; i < MTL; ++i) {
       int64_t m = m0 + wave * (8 * MTL) + i * 8 + arow;
-      if (m >= p.M) m = p.M - 1;                                   // tail rows read the last valid row, never stored
+      if (m >= m_end) m = m_end - 1;                               // tail rows read the last valid row, never stored
+      if (p.gather != nullptr) m = p.gather[m];                    // the pair's input row
       xrow[i] = p.x + m * K + ac * 4;
     }
-    wtile = wbytes + (int64_t)n0 * kw * 2;
+    wtile = wbytes + w_row0 * kw * 2;
   };
   // x (kt + 2) is requested at the END of a group's non-MFMA half, travels during that group's MFMA phase and is split at the
   // top of its next non-MFMA half.  What keeps hipcc from undoing that: the requests cannot cross the s_barrier that follows
@@ -423,7 +438,7 @@ gemm_x6_kernel(const X6Params p) {
       bar_lds();                                 // B2 (nk - 1)
       mfma_all();
       bar_full();                                // end of tile
-      x6_epilogue<GELU, MT>(p, acc, x6_ep_region<MT, NWN>(sx1, sw1, wave), m0 + wm * (16 * MT), n0 + wn * 64, lane);
+      x6_epilogue<GELU, MT>(p, acc, x6_ep_region<MT, NWN>(sx1, sw1, wave), m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
     }
   } else {
     // ------------------------------------------------------------------ group B: [MFMA of the step before | reads, split, x request]
@@ -466,7 +481,7 @@ gemm_x6_kernel(const X6Params p) {
       prio_lo();
       bar_full();                                // end of tile
       mfma_all();                                // step nk - 1
-      x6_epilogue<GELU, MT>(p, acc, x6_ep_region<MT, NWN>(sx1, sw1, wave), m0 + wm * (16 * MT), n0 + wn * 64, lane);
+      x6_epilogue<GELU, MT>(p, acc, x6_ep_region<MT, NWN>(sx1, sw1, wave), m0 + wm * (16 * MT), n0 + wn * 64, lane, m_end);
     }
   }
 }
@@ -514,28 +529,34 @@ int hfl_linear_x6_pack(uint16_t* w3, const float* w, int64_t out_features, int64
   HFL_RETURN_LAST_ERROR();
 }
 
-int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
-                  const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream) {
+static int x6_launch(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
+                     const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream,
+                     const int32_t* tiles, int64_t n_tiles, const int32_t* gather, int64_t w_rows) {
   if (n_rows < 0 || in_features <= 0 || out_features <= 0) return HFL_EINVAL;
-  if (in_features % 32 != 0 || out_features % 128 != 0) return HFL_EINVAL;
+  const bool grouped = tiles != nullptr;
+  const bool narrow = grouped && out_features == 64;                 // W blocks padded to 128 rows by the caller
+  if (in_features % 32 != 0 || (out_features % 128 != 0 && !narrow)) return HFL_EINVAL;
   if (out == nullptr || x == nullptr || w3 == nullptr) return HFL_EINVAL;
   if (gelu && (residual != nullptr || row_scale != nullptr)) return HFL_EINVAL;
   const int64_t kp = hfl_linear_x6_padded_k(in_features);
-  if ((int64_t)out_features * kp * 2 >= ((int64_t)1 << 31)) return HFL_ECAPACITY;          // 32-bit offsets inside a W plane
-  if (n_rows == 0) return HFL_OK;
+  if (!grouped) w_rows = out_features;
+  if (w_rows * kp * 2 >= ((int64_t)1 << 31)) return HFL_ECAPACITY;          // 32-bit offsets inside a W plane
+  if (n_rows == 0 || (grouped && n_tiles == 0)) return HFL_OK;
   X6Params p;
   p.out = out; p.x = x; p.w3 = w3; p.bias = bias; p.residual = residual; p.row_scale = row_scale;
+  p.tiles = tiles; p.gather = gather; p.n_valid = out_features;
   p.M = n_rows; p.N = out_features; p.K = in_features;
   p.nk = (int)(kp / 32);
-  p.w_plane_bytes = (int64_t)out_features * kp * 2;
-  // Tile shape per launch.  Wide tiles (256 features) where the feature count allows: half the x rows to split per MFMA.  Row
-  // tiles of 16 MT x (8 / NWN) rows, one persistent workgroup per CU: a launch costs ceil(tiles / CUs) rounds of (rows + c)
-  // units; a taller tile re-uses the W tile over more rows, a shorter one wastes less of the last round.
+  p.w_plane_bytes = w_rows * kp * 2;
+  // Tile shape per launch.  Row tiles of 16 MT x (8 / NWN) rows, one persistent workgroup per CU: a launch costs
+  // ceil(tiles / CUs) rounds of (rows + c) units; a taller tile re-uses the W tile over more rows, a shorter one wastes less of
+  // the last round.  (Grouped launches: the caller's tile table is cut for 128-row tiles.)
   const int cus = hfl_stream_cus(static_cast<hipStream_t>(stream));
   int shape = g_x6_mt;                   // probe: 1 .. 4 = 64 MT x 128, 12 / 14 = 64 / 128 x 256
   static const int kShapes[6][3] = {{4, 2, 256}, {3, 2, 192}, {2, 2, 128}, {1, 2, 64}, {4, 4, 128}, {2, 4, 64}};   // MT, NWN, rows
   int pick = -1;
-  if (shape >= 1 && shape <= 4) pick = 4 - shape;
+  if (grouped) pick = 2;
+  else if (shape >= 1 && shape <= 4) pick = 4 - shape;
   else if (shape == 14) pick = 4;
   else if (shape == 12) pick = 5;
   if (pick >= 4 && out_features % 256 != 0) pick = -1;
@@ -544,16 +565,16 @@ int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* b
     for (int c = 0; c < 6; ++c) {
       const int bn = kShapes[c][1] * 64, bm = kShapes[c][2];
       if (out_features % bn != 0) continue;
-      const int64_t tiles = hfl_cdiv(n_rows, bm) * (out_features / bn);
+      const int64_t tiles_c = hfl_cdiv(n_rows, bm) * (out_features / bn);
       // units of 64 rows x 128 features (measured: a round of 64 MT x 128 tiles costs ~(MT + 0.6) units, a 256-feature tile as
       // much as the 128-feature tile of twice its rows; ties go to the narrow tile, listed first)
-      const double cost = (double)hfl_cdiv(tiles, cus) * ((bm / 64.0) * (bn / 128.0) + 0.6);
+      const double cost = (double)hfl_cdiv(tiles_c, cus) * ((bm / 64.0) * (bn / 128.0) + 0.6);
       if (pick < 0 || cost < best) { best = cost; pick = c; }
     }
   }
   const int mt = kShapes[pick][0], nwn = kShapes[pick][1];
-  p.tiles_n = out_features / (nwn * 64);
-  p.n_wg = hfl_cdiv(n_rows, kShapes[pick][2]) * p.tiles_n;
+  p.tiles_n = narrow ? 1 : out_features / (nwn * 64);
+  p.n_wg = (grouped ? n_tiles : hfl_cdiv(n_rows, kShapes[pick][2])) * p.tiles_n;
   if (p.n_wg > 0x7fffffffLL) return HFL_ECAPACITY;
   const unsigned grid = (unsigned)(p.n_wg < cus ? p.n_wg : cus);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -566,6 +587,21 @@ int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* b
 #undef HFL_X6_SHAPES
 #undef HFL_X6_LAUNCH
   HFL_RETURN_LAST_ERROR();
+}
+
+int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
+                  const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream) {
+  return x6_launch(out, x, w3, bias, residual, row_scale, n_rows, in_features, out_features, gelu, stream, nullptr, 0, nullptr, 0);
+}
+
+/* Grouped form with the gather done by the tile loader (see include/hotformerloc_hip.h): the per-tap products of an octree
+ * convolution over its live (row, tap) pairs at matched precision. */
+int hfl_linear_x6_grouped_gather(float* out, const float* x, const int32_t* gather, const uint16_t* w3, int64_t w_rows,
+                                 const int32_t* tiles, int64_t n_tiles, int64_t n_rows, int in_features, int out_features,
+                                 hfl_stream_t stream) {
+  if (tiles == nullptr || gather == nullptr || n_tiles < 0 || w_rows <= 0 || w_rows % 128 != 0) return HFL_EINVAL;
+  return x6_launch(out, x, w3, nullptr, nullptr, nullptr, n_rows, in_features, out_features, 0, stream, tiles, n_tiles, gather,
+                   w_rows);
 }
 
 }  // extern "C"

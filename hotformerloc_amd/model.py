@@ -124,6 +124,7 @@ _ATTN_WS = _knob('HFL_ATTN_WS', '1') != '0'
 _ATTN_WS_MIN_ROWS = int(_knob('HFL_ATTN_WS_MIN_ROWS', '40000'))
 _ATTN_WS_EARLY = _knob('HFL_ATTN_WS_EARLY', '0') != '0'   # keep the early-phase schedule beside it (A/B, tests)
 _MERGED_ATTN = _knob('HFL_MERGED_ATTN', '1') != '0'      # window attention of an iteration's levels as one launch
+_MAIN_HI = _knob('HFL_MAIN_HI', '0') != '0'             # probe: the inference forward on a high-priority stream
 
 
 def set_train_split(enabled: bool):
@@ -592,6 +593,15 @@ class OctreeConv(nn.Module):
                                              octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
             out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
             return out if self.bias is None else out + self.bias
+        if (_GEMM_MODE == 'x6' and _GROUPED_TAPS and not _grad_path() and data.dtype == torch.float32 and edges[-1] > 0
+                and self.in_channels % 32 == 0 and (self.out_channels % 128 == 0 or self.out_channels == 64)):
+            # matched precision: the same grouped launch on hfl_linear_x6 (fp32-grade products; the tile loader gathers the pairs'
+            # input rows from the f32 rows themselves)
+            npad = max(self.out_channels, 128)
+            part = ops.linear_x6_grouped_gather(data, src, self._tap_weights_x6(npad),
+                                                octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
+            out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
+            return out if self.bias is None else out + self.bias
         g = ops.octree_gather(data, src)                                  # (P, Cin)
         part = torch.empty((g.shape[0], self.out_channels), dtype=torch.float32, device=data.device)
         w = self.weights
@@ -620,6 +630,19 @@ class OctreeConv(nn.Module):
             ones = torch.ones((self.kdim, 1, self.out_channels), dtype=torch.float32, device=device)
             self.__dict__['_unit_taps'] = ones
         return ones
+
+    def _tap_weights_x6(self, npad: int):
+        """The three bf16 planes of the per-tap weight blocks W[k]^T (Cout x Cin), each padded to `npad` rows, cached per
+        parameter version: (3, kdim * npad, Kp) bf16 (`ops.x6_pack`)."""
+        w = self.weights
+        hit = self.__dict__.get('_w_taps6')
+        if hit is None or hit[0] != w._version or hit[1] != w.data_ptr() or hit[2] != npad:
+            wt = w.detach().transpose(1, 2)                                   # (kdim, Cout, Cin)
+            if npad > self.out_channels:
+                wt = torch.cat([wt, wt.new_zeros(self.kdim, npad - self.out_channels, self.in_channels)], 1)
+            hit = (w._version, w.data_ptr(), npad, ops.x6_pack(wt.reshape(self.kdim * npad, self.in_channels).contiguous()))
+            self.__dict__['_w_taps6'] = hit
+        return hit[3]
 
     def _tap_weights_split2(self, npad: int):
         """split2 layout of the per-tap weight blocks W[k]^T (Cout x Cin), each padded to `npad` rows, cached per parameter
@@ -1965,6 +1988,23 @@ class HOTFormerLoc(nn.Module):
         if octree.device.type != 'cuda':
             raise RuntimeError('HOTFormerLoc (MI355X build) needs the octree on a GPU; '
                                'call to_device(batch, "cuda") first -- there is no CPU path')
+        if _MAIN_HI and not _grad_path() and not _SERIAL_STREAMS:
+            # probe (HFL_MAIN_HI=1): the whole inference forward on a HIGH-priority stream, so that the finest pyramid level's
+            # chain (which stays on it) wins the CUs against the coarse levels' side streams (normal priority)
+            hi = self.__dict__.get('_hi_stream')
+            if hi is None or hi.device != octree.device:
+                hi = self.__dict__['_hi_stream'] = torch.cuda.Stream(device=octree.device, priority=-1)
+            cur = torch.cuda.current_stream(octree.device)
+            hi.wait_stream(cur)
+            with torch.cuda.stream(hi):
+                out = self._forward(batch)
+            cur.wait_stream(hi)
+            out['global'].record_stream(cur)
+            return out
+        return self._forward(batch)
+
+    def _forward(self, batch):
+        octree = batch['octree']
         octree.construct_all_neigh()                     # no-op when misc/torch_utils.to_device did it
         data = octree.get_input_feature(self.input_features, nempty=True)
         armed = self.training and _DROP_POOL

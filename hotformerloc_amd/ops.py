@@ -516,6 +516,26 @@ def linear_x6(x: torch.Tensor, w3: torch.Tensor, bias=None, residual=None, gelu:
     return out
 
 
+def linear_x6_grouped_gather(x: torch.Tensor, src: torch.Tensor, w3: torch.Tensor, tiles: torch.Tensor,
+                             out_features: int) -> torch.Tensor:
+    """The per-tap products of an octree convolution over its live (row, tap) pairs at matched precision: row m of the
+    operand is x[src[m]] (x (n_src, Cin) f32), tiles (n_tiles, 3) int32 as `linear_x3_grouped`, w3 = x6_pack of the stacked
+    per-tap weight blocks (each padded to a multiple of 128 rows); returns (len(src), out_features) f32."""
+    _dev(x, src, w3, tiles)
+    xc = _f32c(x)
+    assert src.dtype == torch.int32 and src.is_contiguous() and tiles.dtype == torch.int32 and tiles.is_contiguous()
+    assert w3.dtype == torch.bfloat16 and w3.is_contiguous() and w3.dim() == 3 and w3.shape[0] == 3
+    k = xc.shape[1]
+    assert w3.shape[2] == (k + 63) // 64 * 64
+    m = src.shape[0]
+    out = torch.empty((m, out_features), dtype=torch.float32, device=x.device)
+    with _timed('hfl_linear_x6', m * k * 4 + m * out_features * 4, 2 * m * k * out_features):
+        check(_native.load().hfl_linear_x6_grouped_gather(out.data_ptr(), xc.data_ptr(), src.data_ptr(), w3.data_ptr(),
+                                                          w3.shape[1], tiles.data_ptr(), tiles.shape[0], m, k, out_features,
+                                                          _stream()), 'hfl_linear_x6_grouped_gather')
+    return out
+
+
 def linear_x3_gelu_fwd(x2: torch.Tensor, w2: torch.Tensor, bias):
     """(split2(gelu(x W^T + b)), x W^T + b as f32) in one launch (hfl_linear_x3_gelu_fwd): training forward of fc1."""
     _dev(x2, w2, bias)

@@ -487,6 +487,16 @@ int hfl_linear_x6_pack(uint16_t* w3, const float* w, int64_t out_features, int64
 int hfl_linear_x6(float* out, const float* x, const uint16_t* w3, const float* bias, const float* residual,
                   const float* row_scale, int64_t n_rows, int in_features, int out_features, int gelu, hfl_stream_t stream);
 
+/* Grouped form of hfl_linear_x6 with the gather done by the tile loader: the per-tap products of an octree convolution over
+ * its live (row, tap) pairs (models/layers/octformer_layers.py:89-95: ocnn's octree2col + mm) at matched precision -- the
+ * stem / downsample convolutions of the matched-precision step.  As hfl_linear_x3_grouped_gather: tiles (n_tiles, 3) int32 =
+ * {first row, rows (1..128), first row of the tile's weight block in w3}; row m of the x operand is x[gather[m]] (x: the
+ * convolution's input rows, f32, in_features wide); w3 = hfl_linear_x6_pack of the stacked per-tap blocks W[k]^T, each padded
+ * to a multiple of 128 rows (w_rows rows in all); out (n_rows, out_features) f32, out_features % 128 == 0 or == 64. */
+int hfl_linear_x6_grouped_gather(float* out, const float* x, const int32_t* gather, const uint16_t* w3, int64_t w_rows,
+                                 const int32_t* tiles, int64_t n_tiles, int64_t n_rows, int in_features, int out_features,
+                                 hfl_stream_t stream);
+
 /* 9e'. norm1 -> attention.qkv -> window attention of a RELAY-TOKEN block (models/hotformerloc_backbone.py:197-216,
  *      models/octformer_backbone.py:52-93: C = 256, 16 heads, K = 48 tokens + 1 relay token per window, dilation 1) as ONE launch
  *      with specialised waves (csrc/attn_ws.hip: six waves run the qkv GEMM of 96 rows head pair by head pair, six run the

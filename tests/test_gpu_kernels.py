@@ -843,6 +843,40 @@ def test_linear_x6_is_as_accurate_as_the_fp32_library_gemm():
         assert eg < 1e-6, eg
 
 
+def test_linear_x6_grouped_gather_matches_per_block_products():
+    """hfl_linear_x6_grouped_gather (the per-tap products of a live-tap octree convolution at matched precision): one launch
+    over row tiles with different weight blocks and a row index per operand row; exact on small integers, <= 3e-7 relative L2
+    of fp64 on real data; ragged tile heights, empty blocks, out_features = 64 on 128-row zero-padded blocks, Cin = 32."""
+    g = torch.Generator().manual_seed(63)
+    for cin, cout in ((64, 64), (128, 128), (32, 64), (64, 128), (128, 256)):
+        npad = max(cout, 128)
+        sizes = [0, 1, 127, 128, 129, 700, 0, 33, 2049]                    # rows per block ("tap")
+        nb = len(sizes)
+        edges = [0]
+        for n in sizes:
+            edges.append(edges[-1] + n)
+        tiles = [(a, min(128, edges[k + 1] - a), k * npad) for k in range(nb) for a in range(edges[k], edges[k + 1], 128)]
+        tiles_t = torch.tensor(tiles, dtype=torch.int32, device=DEV)
+        n_src = 1500
+        src = torch.randint(0, n_src, (edges[-1],), generator=g, dtype=torch.int32)
+        for integer in (True, False):
+            if integer:
+                x = torch.randint(-8, 9, (n_src, cin), generator=g).float()
+                w = torch.randint(-8, 9, (nb, cout, cin), generator=g).float()
+            else:
+                x = torch.randn(n_src, cin, generator=g)
+                w = torch.randn(nb, cout, cin, generator=g) * 0.1
+            wp = torch.cat([w, w.new_zeros(nb, npad - cout, cin)], 1) if npad > cout else w
+            w3 = ops.x6_pack(wp.reshape(nb * npad, cin).contiguous().to(DEV))
+            got = ops.linear_x6_grouped_gather(x.to(DEV), src.to(DEV), w3, tiles_t, cout).cpu()
+            xs = x[src.long()]
+            ref = torch.cat([xs[edges[k]:edges[k + 1]].double() @ w[k].double().t() for k in range(nb)], 0)
+            if integer:
+                assert torch.equal(got.double(), ref), (cin, cout)
+            else:
+                assert ((got.double() - ref).norm() / ref.norm()).item() < 3e-7, (cin, cout)
+
+
 def test_linear_x3_grouped_matches_per_block_products():
     """One launch over row tiles with different weight blocks (hfl_linear_x3_grouped, the per-tap products of a live-tap
     octree convolution): exact on small integers, <= 1e-5 relative L2 on real data; ragged tile heights (1..128 rows), empty

@@ -56,10 +56,11 @@ def _stage_err(got, want) -> float:
     return float(np.abs(got.astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-12))
 
 
-@pytest.fixture(params=['x3', 'bf16x3', 'fp32'])
+@pytest.fixture(params=['x3', 'bf16x3', 'fp32', 'x6'])
 def gemm_mode(request):
-    """Linear layers on the hand-written split-bf16 GEMM (default), as one hipBLASLt split-bf16 GEMM, or as hipBLASLt
-    fp32 GEMMs."""
+    """Linear layers on the hand-written split-bf16 GEMM (default), as one hipBLASLt split-bf16 GEMM, as hipBLASLt fp32
+    GEMMs, or at matched precision on the hand-written three-plane GEMM (hfl_linear_x6: transformer blocks, stem and
+    downsample convolutions)."""
     set_gemm_mode(request.param)
     yield request.param
     set_gemm_mode('x3')
@@ -103,7 +104,7 @@ def test_descriptors_match_reference_golden(golden_dir, case, gemm_mode):
 
 
 @pytest.mark.parametrize('case', ['wild_places_b32', 'cs_wild_places_b8_var'])
-@pytest.mark.parametrize('mode', ['x3', 'fp32'])
+@pytest.mark.parametrize('mode', ['x3', 'fp32', 'x6'])
 def test_full_size_workloads_match_reference_golden(golden_dir, case, mode):
     """BASELINE configs 2 and 3 at their real sizes against the REFERENCE's own output (oracle/gen_golden.py::WORKLOAD_CASES:
     the reference model files run in the build container on the bench's batch -- 32 clouds x 4096 points, Wild-Places cfg,
