@@ -121,6 +121,8 @@ SIGNATURES = {
     'hfl_window_attention_bwd_workspace': (c_int64, [ctypes.POINTER(WindowAttnDesc)]),
     'hfl_window_attention_bwd_det': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              ctypes.POINTER(WindowAttnDesc), c_void_p, c_void_p]),
+    'hfl_window_attention_bwd_split2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                ctypes.POINTER(WindowAttnDesc), c_void_p, c_void_p]),
     'hfl_relay_attention_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                         c_float, c_int, c_void_p]),
     'hfl_inverse_table': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
@@ -153,6 +155,8 @@ SIGNATURES = {
     'hfl_linear_x3_gelu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_tap_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                              c_void_p]),
+    'hfl_tap_wgrad_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                    c_int, c_void_p, c_void_p]),
     'hfl_wgrad_x3_workspace': (c_int64, [c_int64, c_int64, c_int64]),
     'hfl_wgrad_x3': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     'hfl_layer_norm_bwd_blocks': (c_int, [c_int64, c_int64]),

@@ -23,15 +23,21 @@ def _desc(n_tokens, n_windows, patch_size, dilation, n_relay, n_heads, batch_siz
                           scale=16 ** -0.5, depth=depth)
 
 
-def _window_attention_bwd(dqkv, dtable, qkv, dout, tok_meta, table, desc):
+def _window_attention_bwd(dqkv, dtable, qkv, dout, tok_meta, table, desc, split=False):
     """hfl_window_attention_bwd with the reproducible table gradient when the launch has one (partial tables in a workspace,
-    fixed-order sum), the float-atomic form otherwise (tables too large for the second-generation kernel)."""
+    fixed-order sum), the float-atomic form otherwise (tables too large for the second-generation kernel).  split: dqkv is the
+    (rows, 2 * 3C) bf16 split2 operand of the GEMMs behind it (hfl_window_attention_bwd_split2)."""
     lib = _native.load()
     tp = None if table is None else table.data_ptr()
     dp = None if dtable is None else dtable.data_ptr()
     nbytes = int(lib.hfl_window_attention_bwd_workspace(ctypes.byref(desc))) if dtable is not None else 0
-    if nbytes > 0:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device) if nbytes > 0 else None
+    if split:
+        assert dqkv.dtype == torch.bfloat16 and dqkv.shape[1] == 2 * qkv.shape[1]
+        check(lib.hfl_window_attention_bwd_split2(dqkv.data_ptr(), dp, qkv.data_ptr(), dout.data_ptr(), tok_meta.data_ptr(), tp,
+                                                  ctypes.byref(desc), None if ws is None else ws.data_ptr(), ops._stream()),
+              'hfl_window_attention_bwd_split2')
+    elif ws is not None:
         check(lib.hfl_window_attention_bwd_det(dqkv.data_ptr(), dp, qkv.data_ptr(), dout.data_ptr(), tok_meta.data_ptr(), tp,
                                                ctypes.byref(desc), ws.data_ptr(), ops._stream()), 'hfl_window_attention_bwd_det')
     else:
@@ -156,30 +162,50 @@ class LiveTapConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, data, weights, octree, depth, kernel, stride):
         src, slot, edges = octree.sparse_taps(depth, kernel, stride)
-        g = ops.octree_gather(data, src)
         kdim, cin, cout = weights.shape
-        grouped = _grouped_ok(cin, cout) and edges[-1] > 0
-        if grouped:            # one grouped split-precision launch over all taps (hfl_linear_x3_grouped)
+        x6 = _x6_taps_ok(cin, cout) and edges[-1] > 0 and data.dtype == torch.float32
+        grouped = not x6 and _grouped_ok(cin, cout) and edges[-1] > 0
+        if x6:
+            # one grouped launch at fp32-grade products (hfl_linear_x6_grouped_gather): the tile loader reads the pairs' input
+            # rows itself, so the (pairs, Cin) matrix is neither written here nor kept for the backward (it is re-gathered there)
             npad = max(cout, 128)
-            part = ops.linear_x3_grouped(ops.split2(g), _tap_blocks(weights, True, npad),
-                                         octree.tap_tiles(depth, kernel, stride, npad), cout)
+            part = ops.linear_x6_grouped_gather(data, src, _tap_blocks(weights, True, npad, x6=True),
+                                                octree.tap_tiles(depth, kernel, stride, npad), cout)
+            ctx.save_for_backward(data, weights)
         else:
-            part = torch.empty((g.shape[0], cout), dtype=torch.float32, device=data.device)
-            for k in range(kdim):
-                if edges[k + 1] > edges[k]:
-                    torch.mm(g[edges[k]:edges[k + 1]], weights[k], out=part[edges[k]:edges[k + 1]])
-        ctx.save_for_backward(g, weights)
-        ctx.octree, ctx.key, ctx.n_src, ctx.grouped = octree, (depth, kernel, stride), data.shape[0], grouped
+            g = ops.octree_gather(data, src)
+            if grouped:            # one grouped split-precision launch over all taps (hfl_linear_x3_grouped)
+                npad = max(cout, 128)
+                part = ops.linear_x3_grouped(ops.split2(g), _tap_blocks(weights, True, npad),
+                                             octree.tap_tiles(depth, kernel, stride, npad), cout)
+            else:
+                part = torch.empty((g.shape[0], cout), dtype=torch.float32, device=data.device)
+                for k in range(kdim):
+                    if edges[k + 1] > edges[k]:
+                        torch.mm(g[edges[k]:edges[k + 1]], weights[k], out=part[edges[k]:edges[k + 1]])
+            ctx.save_for_backward(g, weights)
+        ctx.octree, ctx.key, ctx.n_src, ctx.grouped, ctx.x6 = octree, (depth, kernel, stride), data.shape[0], grouped, x6
         return ops.dwconv_forward_backward(part, _unit_taps(kdim, cout, data.device), slot)
 
     @staticmethod
     def backward(ctx, dout):
         g, weights = ctx.saved_tensors
-        _, _, edges = ctx.octree.sparse_taps(*ctx.key)
+        src, _, edges = ctx.octree.sparse_taps(*ctx.key)
         rowof, inv_slot, chunks, tap_off = ctx.octree.sparse_taps_bwd(*ctx.key)
         kdim, cin, cout = weights.shape
-        dpart = ops.octree_gather(dout.contiguous(), rowof)
-        if cin % 64 == 0 and cout % 64 == 0:
+        dout = dout.contiguous()
+        if ctx.x6 and cin % 64 == 0 and cout % 64 == 0:
+            # neither pair-major copy exists: the weight-gradient kernel and the grouped GEMM below read the layer input
+            # (the saved tensor) and the output gradient through the pair tables
+            dw = ops.tap_wgrad(g, dout, chunks, tap_off, kdim, g_rows=src, d_rows=rowof)
+            dpart = None
+        else:
+            if ctx.x6:
+                g = ops.octree_gather(g, src)
+            dpart = ops.octree_gather(dout, rowof)
+        if dpart is None:
+            pass
+        elif cin % 64 == 0 and cout % 64 == 0:
             dw = ops.tap_wgrad(g, dpart, chunks, tap_off, kdim)       # long contractions into small matrices: own kernel
         else:
             dw = torch.zeros_like(weights)
@@ -188,7 +214,11 @@ class LiveTapConvFn(torch.autograd.Function):
                     torch.mm(g[edges[k]:edges[k + 1]].t(), dpart[edges[k]:edges[k + 1]], out=dw[k])
         ddata = None
         if ctx.needs_input_grad[0]:
-            if ctx.grouped:
+            if ctx.x6:
+                npad = max(cin, 128)
+                dg = ops.linear_x6_grouped_gather(dout, rowof, _tap_blocks(weights, False, npad, x6=True),
+                                                  ctx.octree.tap_tiles(*ctx.key, npad), cin)
+            elif ctx.grouped:
                 npad = max(cin, 128)
                 dg = ops.linear_x3_grouped(ops.split2(dpart), _tap_blocks(weights, False, npad),
                                            ctx.octree.tap_tiles(*ctx.key, npad), cin)
@@ -211,15 +241,25 @@ def _grouped_ok(cin, cout) -> bool:
 # gradient of the loss chain (first stem convolution, amplified by the 1/tau = 100 of the listwise loss) moved from 8.5e-4 to
 # 2.2e-3 of the oracle chain with it; the fp32 per-tap GEMMs stay (HFL_GROUPED_TAPS_TRAIN=1 switches it on)
 _GROUPED_TAPS = __import__('os').environ.get('HFL_GROUPED_TAPS_TRAIN', '0') != '0'
+# what the training path runs instead: the same grouped launch at fp32-grade products (hfl_linear_x6_grouped_gather; its
+# error is below the fp32 library GEMM's, so the gradient bar is untouched); HFL_X6_TAPS_TRAIN=0 (with HFL_PROBES=1) goes
+# back to the 27 fp32 library GEMMs per convolution
+_X6_TAPS = not (__import__('os').environ.get('HFL_PROBES', '0') == '1'
+                and __import__('os').environ.get('HFL_X6_TAPS_TRAIN', '1') == '0')
 _TAP_BLOCK_CACHE = {}
 
 
-def _tap_blocks(weights, transposed: bool, npad: int):
-    """split2 layout of the per-tap weight blocks of an octree convolution, every block padded to `npad` rows:
-    transposed = W[k]^T (Cout x Cin) for the forward product, else W[k] (Cin x Cout) for the input gradient; rebuilt when
-    the optimizer updates the parameter."""
+def _x6_taps_ok(cin, cout) -> bool:
+    return (cin % 32 == 0 and cout % 32 == 0 and (cout % 128 == 0 or cout == 64) and (cin % 128 == 0 or cin == 64)
+            and _X6_TAPS)
+
+
+def _tap_blocks(weights, transposed: bool, npad: int, x6: bool = False):
+    """split2 layout (x6: the three bf16 planes, `ops.x6_pack`) of the per-tap weight blocks of an octree convolution, every
+    block padded to `npad` rows: transposed = W[k]^T (Cout x Cin) for the forward product, else W[k] (Cin x Cout) for the
+    input gradient; rebuilt when the optimizer updates the parameter."""
     import weakref
-    key = (id(weights), transposed, npad)
+    key = (id(weights), transposed, npad, x6)
     hit = _TAP_BLOCK_CACHE.get(key)
     if hit is None or hit[0]() is not weights or hit[1] != weights._version or hit[3] != weights.data_ptr():
         w = weights.detach()
@@ -229,7 +269,8 @@ def _tap_blocks(weights, transposed: bool, npad: int):
             blocks = torch.cat([blocks, blocks.new_zeros(kdim, npad - rows, kk)], 1)
         if len(_TAP_BLOCK_CACHE) > 256:
             _TAP_BLOCK_CACHE.clear()
-        hit = (weakref.ref(weights), weights._version, ops.split2(blocks.reshape(kdim * npad, kk).contiguous()),
+        stacked = blocks.reshape(kdim * npad, kk).contiguous()
+        hit = (weakref.ref(weights), weights._version, ops.x6_pack(stacked) if x6 else ops.split2(stacked),
                weights.data_ptr())
         _TAP_BLOCK_CACHE[key] = hit
     return hit[2]
@@ -314,13 +355,59 @@ def relay_attention_torch(qkv, plan, n_heads: int):
     return out.index_put((idx[valid],), o[valid])
 
 
+class PadRowsFn(torch.autograd.Function):
+    """(B, nmax, C) zero-padded per-cloud copy of ragged rows (hfl_pad_rows); the gradient is the same rows read back -- every
+    input row has exactly one padded position -- where autograd over cat + index_select scatters with `index_add_` (2 ms of the
+    config-3 step)."""
+
+    @staticmethod
+    def forward(ctx, x, row_off, batch, nmax, live):
+        ctx.save_for_backward(live)
+        return ops.pad_rows(x, row_off, batch, nmax)
+
+    @staticmethod
+    def backward(ctx, dxp):
+        (live,) = ctx.saved_tensors
+        return dxp.reshape(-1, dxp.shape[-1]).index_select(0, live), None, None, None, None
+
+
+class PoolScoresFn(torch.autograd.Function):
+    """scale * query xp^T of the attentional pooling, (k, C) x (B, nmax, C) -> (B, k, nmax).  The query gradient is contracted
+    cloud by cloud (one batched product + a fixed-order sum over the clouds): autograd's single (k, B nmax) x (B nmax, C)
+    product runs on the handful of workgroups its (k, C) output gives (1.2 ms)."""
+
+    @staticmethod
+    def forward(ctx, query, xp, scale):
+        ctx.save_for_backward(query, xp)
+        ctx.scale = scale
+        return torch.matmul(query.unsqueeze(0), xp.transpose(1, 2)) * scale
+
+    @staticmethod
+    def backward(ctx, ds):
+        query, xp = ctx.saved_tensors
+        ds = ds * ctx.scale
+        dq = torch.bmm(ds, xp).sum(0) if ctx.needs_input_grad[0] else None
+        dxp = torch.matmul(ds.transpose(1, 2), query) if ctx.needs_input_grad[1] else None
+        return dq, dxp, None
+
+
 def attentional_pooling_torch(x, query, plan, depth: int, scale: float):
     """learned-query pooling over each cloud's tokens (training path): padded dense math."""
     idx = plan.pad_index[depth]
     B = plan.B
-    xp = torch.cat([x, x.new_zeros(1, x.shape[1])], 0).index_select(0, idx).view(B, -1, x.shape[1])
     valid = (idx != x.shape[0]).view(B, -1)
-    s = torch.matmul(query.unsqueeze(0), xp.transpose(1, 2)) * scale          # (B, k, Nmax)
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0:
+        live = plan.__dict__.setdefault('_pad_live', {}).get(depth)
+        if live is None:                       # padded position of every row (clouds are contiguous row ranges); no host sync
+            off = plan.cloud_off[depth]
+            rows = torch.arange(x.shape[0], device=x.device)
+            cloud = torch.searchsorted(off[1:].contiguous(), rows, right=True)
+            live = plan.__dict__['_pad_live'][depth] = rows + cloud * valid.shape[1] - off[cloud]
+        xp = PadRowsFn.apply(x, plan.cloud_off[depth], B, valid.shape[1], live)
+        s = PoolScoresFn.apply(query, xp, scale)
+    else:
+        xp = torch.cat([x, x.new_zeros(1, x.shape[1])], 0).index_select(0, idx).view(B, -1, x.shape[1])
+        s = torch.matmul(query.unsqueeze(0), xp.transpose(1, 2)) * scale          # (B, k, Nmax)
     s = s.masked_fill(~valid[:, None, :], float('-inf'))
     return torch.matmul(torch.softmax(s, dim=-1), xp)
 
@@ -532,12 +619,17 @@ class LnAttnResidualX3Fn(torch.autograd.Function):
         need = ctx.needs_input_grad    # (x, gamma, beta, eps, wqkv, bqkv, rpe_table, tok_meta, cfg, wp, bp, row_scale)
         do = ops.linear_x3(dys, _w2_cached(wp, True))
         dwp, dbp = _wgrad(dys, os_, need[9], need[10])
-        dqkv = torch.empty_like(qkv)
         dtable = torch.zeros_like(table) if ctx.has_table else None
         d = _desc(cfg['n_tokens'], cfg['n_windows'], cfg['patch_size'], cfg['dilation'], cfg['n_relay'],
                   cfg['n_heads'], cfg['batch_size'], cfg.get('rt_row0', 0), cfg.get('depth', 0))
-        _window_attention_bwd(dqkv, dtable, qkv, do, tok_meta, table if ctx.has_table else None, d)
-        dqs = ops.split2(dqkv)
+        # the attention backward writes dqkv as the split2 operand of the two GEMMs below (no f32 gradient, no split pass)
+        dqs = torch.empty((qkv.shape[0], 2 * qkv.shape[1]), dtype=torch.bfloat16, device=qkv.device)
+        _window_attention_bwd(dqs, dtable, qkv, do, tok_meta, table if ctx.has_table else None, d, split=True)
+        if cfg['n_relay']:
+            # relay rows of pure-padding windows are in no window: the kernel leaves them unwritten, the GEMMs below read them
+            live = cfg.get('rt_row0', 0) + -(-cfg['n_tokens'] // cfg['patch_size'])
+            if live < dqs.shape[0]:
+                dqs[live:].zero_()
         dh = ops.linear_x3(dqs, _w2_cached(wqkv, True))
         dwqkv, dbqkv = _wgrad(dqs, hs, need[4], ctx.has_qkv_bias and need[5])
         dx, dg, dbeta = ops.layer_norm_bwd(dh, x2, gamma, ctx.eps, dres=dout2)

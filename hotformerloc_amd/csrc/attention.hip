@@ -1921,7 +1921,24 @@ struct WinBwdParams {
   float scale;
   float* dtable_part;     // second-generation kernel: per (grid column, head) partial tables (gridDim.x, H, 3*nrpe) instead of
                           // float atomics into dtable (fixed-order reduction afterwards: reproducible); null = atomics
+  int out_split;          // 1: dqkv leaves as the split2 operand of the GEMMs behind it (hfl_window_attention_bwd_split2)
 };
+
+// one lane's four consecutive channels of a dqkv row.  split != 0: the row is written in the split2 layout of csrc/gemm_x3.hip
+// (per 32 channels 32 bf16 hi then 32 bf16 lo; a row keeps its 4 * width bytes) -- what hfl_split2 would make of the f32 row,
+// bit for bit, without the f32 row ever being in memory
+__device__ __forceinline__ void bwd_store4(float* row, int col, float a, float b, float c, float d, int split) {
+  if (!split) {
+    *reinterpret_cast<float4*>(row + col) = make_float4(a, b, c, d);
+    return;
+  }
+  uint2 hi, lo;
+  x3_split_pair_scalar(a, b, hi.x, lo.x);
+  x3_split_pair_scalar(c, d, hi.y, lo.y);
+  uint16_t* o = reinterpret_cast<uint16_t*>(row) + (col >> 5) * 64 + (col & 31);
+  *reinterpret_cast<uint2*>(o) = hi;
+  *reinterpret_cast<uint2*>(o + 32) = lo;
+}
 
 template <int T, int G>
 __global__ void __launch_bounds__(128)
@@ -2105,8 +2122,8 @@ window_attn_bwd_kernel(const WinBwdParams p) {
         }
       const int qrow = s_row[qi];
       if (qrow >= 0)
-        *reinterpret_cast<float4*>(p.dqkv + (int64_t)qrow * 3 * C + h * 16 + 4 * g) =
-            make_float4(dq[0] * p.scale, dq[1] * p.scale, dq[2] * p.scale, dq[3] * p.scale);
+        bwd_store4(p.dqkv + (int64_t)qrow * 3 * C, h * 16 + 4 * g, dq[0] * p.scale, dq[1] * p.scale, dq[2] * p.scale,
+                   dq[3] * p.scale, p.out_split);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -2166,10 +2183,10 @@ window_attn_bwd_kernel(const WinBwdParams p) {
     for (int kt = 0; kt < T; ++kt) {
       const int krow = s_row[kt * 16 + c];
       if (krow >= 0) {
-        float* base = p.dqkv + (int64_t)krow * 3 * C + h * 16 + 4 * g;
-        *reinterpret_cast<float4*>(base + C) =
-            make_float4(dk[kt][0] * p.scale, dk[kt][1] * p.scale, dk[kt][2] * p.scale, dk[kt][3] * p.scale);
-        *reinterpret_cast<float4*>(base + 2 * C) = make_float4(dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3]);
+        float* row = p.dqkv + (int64_t)krow * 3 * C;
+        bwd_store4(row, C + h * 16 + 4 * g, dk[kt][0] * p.scale, dk[kt][1] * p.scale, dk[kt][2] * p.scale, dk[kt][3] * p.scale,
+                   p.out_split);
+        bwd_store4(row, 2 * C + h * 16 + 4 * g, dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3], p.out_split);
       }
     }
   }
@@ -2500,8 +2517,8 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
         }
         const int qrow = s_row[qi];
         if (qrow >= 0)
-          *reinterpret_cast<float4*>(p.dqkv + (int64_t)qrow * 3 * C + h * 16 + 4 * g) =
-              make_float4(dq[0] * p.scale, dq[1] * p.scale, dq[2] * p.scale, dq[3] * p.scale);
+          bwd_store4(p.dqkv + (int64_t)qrow * 3 * C, h * 16 + 4 * g, dq[0] * p.scale, dq[1] * p.scale, dq[2] * p.scale,
+                     dq[3] * p.scale, p.out_split);
       }
 
       // ---- dK^T, dV^T: contraction over the 32 queries of the pair ---------------------------------------------------
@@ -2538,10 +2555,10 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
     for (int kt = 0; kt < T; ++kt) {
       const int krow = s_row[kt * 16 + c];
       if (krow >= 0) {
-        float* base = p.dqkv + (int64_t)krow * 3 * C + h * 16 + 4 * g;
-        *reinterpret_cast<float4*>(base + C) =
-            make_float4(dk[kt][0] * p.scale, dk[kt][1] * p.scale, dk[kt][2] * p.scale, dk[kt][3] * p.scale);
-        *reinterpret_cast<float4*>(base + 2 * C) = make_float4(dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3]);
+        float* row = p.dqkv + (int64_t)krow * 3 * C;
+        bwd_store4(row, C + h * 16 + 4 * g, dk[kt][0] * p.scale, dk[kt][1] * p.scale, dk[kt][2] * p.scale, dk[kt][3] * p.scale,
+                   p.out_split);
+        bwd_store4(row, 2 * C + h * 16 + 4 * g, dv[kt][0], dv[kt][1], dv[kt][2], dv[kt][3], p.out_split);
       }
     }
   }
@@ -2672,7 +2689,7 @@ extern "C" int64_t hfl_window_attention_bwd_workspace(const hfl_window_attn_desc
 
 static int window_attention_bwd_impl(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
                                      const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* d,
-                                     void* workspace, hfl_stream_t stream);
+                                     void* workspace, hfl_stream_t stream, int out_split = 0);
 
 extern "C" int hfl_window_attention_bwd(float* dqkv, float* drpe_table, const float* qkv,
                                         const float* dout, const uint32_t* tok_meta,
@@ -2688,9 +2705,19 @@ extern "C" int hfl_window_attention_bwd_det(float* dqkv, float* drpe_table, cons
   return window_attention_bwd_impl(dqkv, drpe_table, qkv, dout, tok_meta, rpe_table, d, workspace, stream);
 }
 
+/* dqkv written as the split2 operand (rows, 2 * 3C bf16) of the qkv layer's data- and weight-gradient GEMMs: the f32 gradient
+ * and the hfl_split2 pass over it are gone.  workspace as hfl_window_attention_bwd_det, or NULL for float atomics. */
+extern "C" int hfl_window_attention_bwd_split2(uint16_t* dqkv_split2, float* drpe_table, const float* qkv, const float* dout,
+                                               const uint32_t* tok_meta, const float* rpe_table,
+                                               const hfl_window_attn_desc* d, void* workspace, hfl_stream_t stream) {
+  if (d != nullptr && (3 * d->n_heads * 16) % 32 != 0) return HFL_EINVAL;
+  return window_attention_bwd_impl(reinterpret_cast<float*>(dqkv_split2), drpe_table, qkv, dout, tok_meta, rpe_table, d,
+                                   workspace, stream, 1);
+}
+
 static int window_attention_bwd_impl(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
                                      const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* d,
-                                     void* workspace, hfl_stream_t stream) {
+                                     void* workspace, hfl_stream_t stream, int out_split) {
   if (d == nullptr || d->n_windows < 0 || d->n_heads <= 0 || d->n_heads > 16) return HFL_EINVAL;
   if (d->patch_size % 16 != 0 || d->dilation < 1 || d->n_relay < 0 || d->n_relay > 1) return HFL_EINVAL;
   if (d->n_relay == 1 && d->dilation != 1) return HFL_EINVAL;
@@ -2701,6 +2728,7 @@ static int window_attention_bwd_impl(float* dqkv, float* drpe_table, const float
   p.K = d->patch_size; p.D = d->dilation; p.H = d->n_heads; p.bnd = d->pos_bnd; p.batch = d->batch_size;
   p.scale = d->scale;
   p.dtable_part = static_cast<float*>(workspace);
+  p.out_split = out_split;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int T = d->patch_size / 16 + d->n_relay;
   if (d->n_relay == 0) {

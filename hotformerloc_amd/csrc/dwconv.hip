@@ -121,7 +121,44 @@ static int launch_fwd(float* out, const float* data, const float* weight, const 
 
 // ---------------------------------------------------------- weight gradient
 // partial[(block*rpb+ty), k, c] = sum over the rows this lane-row visited.
-template <typename IdxT>
+// The 27 gathers of a row are issued nine at a time WITHOUT a branch around each (a missing neighbour reads row 0 and is
+// dropped by a select): with `if (ni >= 0) load; fma` every gather waited for the one before it and the launch ran at the
+// latency of 27 dependent L2 round trips per row (187 us at depth 4 against the forward's 65).  Rows are dealt like the
+// CPE's: XCD x = blockIdx & 7 walks its own contiguous eighth of the z-ordered rows, so that a row's neighbours are
+// re-used through one L2.
+// B taps of one row: gathers first, then the products (acc indices are compile-time: the 27 accumulators stay in VGPRs)
+template <typename IdxT, int B, int K0>
+__device__ __forceinline__ void wgrad_taps(float4 (&acc)[kMaxTaps], const float4 g, const float* __restrict__ data,
+                                           const IdxT* idx, int K, int C, int tx) {
+  constexpr int NB = K0 + B <= kMaxTaps ? B : kMaxTaps - K0;
+  float4 d[NB];
+  bool ok[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int64_t ni = K0 + j < K ? (int64_t)idx[K0 + j] : (int64_t)-1;
+    ok[j] = ni >= 0;
+    d[j] = reinterpret_cast<const float4*>(data + (ok[j] ? ni : (int64_t)0) * C)[tx];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const float4 a = hfl_fma4(d[j], g, acc[K0 + j]);          // (component selects: `ok ? a : acc` on the structs is a
+    acc[K0 + j].x = ok[j] ? a.x : acc[K0 + j].x;              //  select of ADDRESSES and sends the array to scratch)
+    acc[K0 + j].y = ok[j] ? a.y : acc[K0 + j].y;
+    acc[K0 + j].z = ok[j] ? a.z : acc[K0 + j].z;
+    acc[K0 + j].w = ok[j] ? a.w : acc[K0 + j].w;
+  }
+}
+
+template <typename IdxT, int B, int K0 = 0>
+__device__ __forceinline__ void wgrad_row(float4 (&acc)[kMaxTaps], const float4 g, const float* __restrict__ data,
+                                          const IdxT* idx, int K, int C, int tx) {
+  if constexpr (K0 < kMaxTaps) {
+    if (K0 < K) wgrad_taps<IdxT, B, K0>(acc, g, data, idx, K, C, tx);
+    wgrad_row<IdxT, B, K0 + B>(acc, g, data, idx, K, C, tx);
+  }
+}
+
+template <typename IdxT, int B>
 __global__ void __launch_bounds__(256) dwconv_wgrad_partial(float* __restrict__ partial, const float* __restrict__ grad,
                                      const float* __restrict__ data, const IdxT* __restrict__ neigh,
                                      int64_t n_rows, int C, int K, int tpr, int rpb) {
@@ -131,8 +168,14 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_partial(float* __restrict__ 
   float4 acc[kMaxTaps];
 #pragma unroll
   for (int k = 0; k < kMaxTaps; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t base = (int64_t)blockIdx.x * rpb; base < n_rows; base += (int64_t)gridDim.x * rpb) {
-    const int64_t h = base + ty;
+  const int64_t groups = (n_rows + rpb - 1) / rpb;
+  const int64_t per_xcd = (groups + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int64_t xg0 = (int64_t)xcd * per_xcd;
+  const int64_t xg1 = xg0 + per_xcd < groups ? xg0 + per_xcd : groups;
+  const int nb = ((int)gridDim.x - xcd + 7) >> 3;                  // workgroups of this launch on the XCD
+  for (int64_t grp = xg0 + (blockIdx.x >> 3); grp < xg1; grp += nb) {
+    const int64_t h = grp * rpb + ty;
     const bool live = h < n_rows;
     __syncthreads();
     if (live)
@@ -140,16 +183,7 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_partial(float* __restrict__ 
     __syncthreads();
     if (!live) continue;
     const float4 g = reinterpret_cast<const float4*>(grad + h * C)[tx];
-#pragma unroll
-    for (int k = 0; k < kMaxTaps; ++k) {
-      if (k < K) {
-        const int64_t ni = (int64_t)s_idx[ty * K + k];
-        if (ni >= 0) {
-          const float4 d = reinterpret_cast<const float4*>(data + ni * C)[tx];
-          acc[k] = hfl_fma4(d, g, acc[k]);
-        }
-      }
-    }
+    wgrad_row<IdxT, B>(acc, g, data, s_idx + ty * K, K, C, tx);
   }
   float4* dst = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * rpb + ty) * K * C);
 #pragma unroll
@@ -193,6 +227,8 @@ __global__ void dwconv_wgrad_scalar(float* __restrict__ out, const float* __rest
   out[i] = acc;
 }
 
+int g_wgrad_batch = 9;      // gathers in flight per lane (probe: hfl_internal_set_wgrad_batch)
+
 static int wgrad_blocks(int64_t n_rows, int rpb) {
   const int64_t need = hfl_cdiv(n_rows, (int64_t)rpb * 8);
   // 3 workgroups per CU: the gathers of a row are only hidden by other waves (one workgroup per CU ran at a quarter of
@@ -200,7 +236,7 @@ static int wgrad_blocks(int64_t n_rows, int rpb) {
   const int64_t cap = 3 * (int64_t)hfl_num_cus();
   int64_t b = need < cap ? need : cap;
   if (b < 1) b = 1;
-  return (int)b;
+  return (int)((b + 7) & ~(int64_t)7);           // every XCD's eighth of the rows needs a workgroup (the kernel's row map)
 }
 
 template <typename IdxT>
@@ -211,8 +247,15 @@ static int launch_wgrad(float* out, const float* grad, const float* data, const 
     const int blocks = wgrad_blocks(n_rows, g.rpb);
     const size_t lds = (size_t)g.rpb * K * sizeof(IdxT);
     float* partial = static_cast<float*>(workspace);
-    dwconv_wgrad_partial<IdxT><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows,
-                                                                  (int)C, K, g.tpr, g.rpb);
+    if (g_wgrad_batch == 6)
+      dwconv_wgrad_partial<IdxT, 6><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows, (int)C, K, g.tpr,
+                                                                       g.rpb);
+    else if (g_wgrad_batch == 3)
+      dwconv_wgrad_partial<IdxT, 3><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows, (int)C, K, g.tpr,
+                                                                       g.rpb);
+    else
+      dwconv_wgrad_partial<IdxT, 9><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows, (int)C, K, g.tpr,
+                                                                       g.rpb);
     const int64_t kc = (int64_t)K * C;
     dwconv_wgrad_reduce<<<(int)hfl_cdiv(kc, 64), 1024, 0, s>>>(out, partial, blocks * g.rpb, kc);
   } else {
@@ -489,4 +532,6 @@ int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table
 
 /* internal tuning hook used by hfl_set_variant("cpe_chunk_rows", n) */
 void hfl_internal_set_cpe_chunk(int rows) { g_cpe_chunk_rows = rows; }
+/* probe: gathers in flight per lane of the depth-wise weight gradient (9, 6 or 3) */
+void hfl_internal_set_wgrad_batch(int taps) { g_wgrad_batch = taps; }
 }  // extern "C"

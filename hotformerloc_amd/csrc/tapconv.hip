@@ -22,6 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 tap_wgrad_kernel(float* __restrict__ ws, const float* __restrict__ g, const float* __restrict__ dpart,
+                 const int32_t* __restrict__ g_rows, const int32_t* __restrict__ d_rows,
                  const int32_t* __restrict__ chunks, int cin, int cout) {
   __shared__ float red[3][64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,8 +45,12 @@ tap_wgrad_kernel(float* __restrict__ ws, const float* __restrict__ g, const floa
     for (int s = 0; s < 4; ++s) {
       const int p = p0 + 4 * s + q;
       const bool ok = p < end;
-      const float* gr = g + (int64_t)p * cin + ci0 + c;
-      const float* dr = dpart + (int64_t)p * cout + co0 + c;
+      // (hfl_tap_wgrad_gather: pair p reads row g_rows[p] of the layer input / d_rows[p] of the output gradient -- the
+      //  pair-major copies of both never exist)
+      const int64_t pg = g_rows != nullptr ? (int64_t)g_rows[ok ? p : begin] : (int64_t)p;
+      const int64_t pd = d_rows != nullptr ? (int64_t)d_rows[ok ? p : begin] : (int64_t)p;
+      const float* gr = g + pg * cin + ci0 + c;
+      const float* dr = dpart + pd * cout + co0 + c;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         a[s][i] = ok ? gr[16 * i] : 0.f;
@@ -107,19 +112,27 @@ tap_wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ ws, co
 
 }  // namespace
 
-extern "C" int hfl_tap_wgrad(float* dw, const float* g, const float* dpart, const int32_t* chunks, int n_chunks,
-                             const int32_t* tap_chunk_off, int taps, int cin, int cout, float* workspace,
-                             hfl_stream_t stream) {
+extern "C" int hfl_tap_wgrad_gather(float* dw, const float* g, const int32_t* g_rows, const float* dpart,
+                                    const int32_t* d_rows, const int32_t* chunks, int n_chunks,
+                                    const int32_t* tap_chunk_off, int taps, int cin, int cout, float* workspace,
+                                    hfl_stream_t stream) {
   if (taps <= 0 || cin <= 0 || cout <= 0 || cin % 64 != 0 || cout % 64 != 0 || n_chunks < 0) return HFL_EINVAL;
   if (dw == nullptr || tap_chunk_off == nullptr) return HFL_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_chunks > 0) {
     if (g == nullptr || dpart == nullptr || chunks == nullptr || workspace == nullptr) return HFL_EINVAL;
     dim3 grid((unsigned)n_chunks, (unsigned)((cin / 64) * (cout / 64)));
-    tap_wgrad_kernel<<<grid, 256, 0, s>>>(workspace, g, dpart, chunks, cin, cout);
+    tap_wgrad_kernel<<<grid, 256, 0, s>>>(workspace, g, dpart, g_rows, d_rows, chunks, cin, cout);
   }
   const int n4 = cin * cout / 4;
   dim3 rgrid((unsigned)hfl_cdiv(n4, 256), (unsigned)taps);
   tap_wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(dw, workspace, tap_chunk_off, n4);
   HFL_RETURN_LAST_ERROR();
+}
+
+extern "C" int hfl_tap_wgrad(float* dw, const float* g, const float* dpart, const int32_t* chunks, int n_chunks,
+                             const int32_t* tap_chunk_off, int taps, int cin, int cout, float* workspace,
+                             hfl_stream_t stream) {
+  return hfl_tap_wgrad_gather(dw, g, nullptr, dpart, nullptr, chunks, n_chunks, tap_chunk_off, taps, cin, cout, workspace,
+                              stream);
 }

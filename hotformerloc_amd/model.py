@@ -1756,6 +1756,16 @@ class Mixer(nn.Module):
                 g2 = ops.linear_x3(h2, _w2(fc1), bias=fc1.bias, gelu_split_out=True)
                 x2 = ops.linear_x3(g2, _w2(fc2), bias=fc2.bias, residual=x2)
             x = x2.view(b, k, c)
+        elif all(_mixer_layer_fits(m) for m in self.mix) and _x6_path(x, *[l for m in self.mix for l in (m.mix[1], m.mix[3])]):
+            # matched precision: LayerNorm, fc1 + bias + GELU, fc2 + bias + residual on hfl_linear_x6 (three launches per layer)
+            b, k, c = x.shape
+            x2 = x.reshape(b * k, c).contiguous()
+            for m in self.mix:
+                ln, fc1, _, fc2 = m.mix
+                h = ops.layer_norm(x2, ln.weight, ln.bias, ln.eps)
+                g = ops.linear_x6(h, _w6(fc1), bias=fc1.bias, gelu=True)
+                x2 = ops.linear_x6(g, _w6(fc2), bias=fc2.bias, residual=x2)
+            x = x2.view(b, k, c)
         else:
             x = self.mix(x)
         if (_MIXER_FUSED and _GEMM_MODE == 'x3' and x.is_cuda and not _grad_path() and x.dtype == torch.float32

@@ -948,19 +948,25 @@ def inverse_table(inverse: torch.Tensor, table: torch.Tensor):
     return inverse
 
 
-def tap_wgrad(g: torch.Tensor, dpart: torch.Tensor, chunks: torch.Tensor, tap_chunk_off: torch.Tensor, taps: int):
+def tap_wgrad(g: torch.Tensor, dpart: torch.Tensor, chunks: torch.Tensor, tap_chunk_off: torch.Tensor, taps: int,
+              g_rows=None, d_rows=None):
     """dW (taps, Cin, Cout) of a live-tap octree convolution: dW[k] = g_k^T dpart_k over the pairs of tap k
-    (hfl_tap_wgrad; `chunks` / `tap_chunk_off` from Octree.sparse_taps_bwd)."""
-    _dev(g, dpart, chunks, tap_chunk_off)
+    (hfl_tap_wgrad; `chunks` / `tap_chunk_off` from Octree.sparse_taps_bwd).  g_rows / d_rows (P,) int32: pair p reads row
+    g_rows[p] of g / d_rows[p] of dpart (hfl_tap_wgrad_gather) instead of row p of a pair-major copy."""
+    _dev(g, dpart, chunks, tap_chunk_off, g_rows, d_rows)
     g, dpart = _f32c(g), _f32c(dpart)
     cin, cout = g.shape[1], dpart.shape[1]
     n_chunks = chunks.shape[0]
+    for t in (g_rows, d_rows):
+        assert t is None or (t.dtype == torch.int32 and t.is_contiguous())
+    pairs = (g_rows if g_rows is not None else g).shape[0]
     dw = torch.empty((taps, cin, cout), dtype=torch.float32, device=g.device)
     ws = torch.empty((max(n_chunks, 1), cin, cout), dtype=torch.float32, device=g.device)
-    with _timed('hfl_tap_wgrad', (g.numel() + dpart.numel()) * 4, 2 * g.shape[0] * cin * cout):
-        check(_native.load().hfl_tap_wgrad(dw.data_ptr(), g.data_ptr(), dpart.data_ptr(), chunks.data_ptr(), n_chunks,
-                                           tap_chunk_off.data_ptr(), taps, cin, cout, ws.data_ptr(), _stream()),
-              'hfl_tap_wgrad')
+    with _timed('hfl_tap_wgrad', pairs * (cin + cout) * 4, 2 * pairs * cin * cout):
+        check(_native.load().hfl_tap_wgrad_gather(dw.data_ptr(), g.data_ptr(), None if g_rows is None else g_rows.data_ptr(),
+                                                  dpart.data_ptr(), None if d_rows is None else d_rows.data_ptr(),
+                                                  chunks.data_ptr(), n_chunks, tap_chunk_off.data_ptr(), taps, cin, cout,
+                                                  ws.data_ptr(), _stream()), 'hfl_tap_wgrad_gather')
     return dw
 
 

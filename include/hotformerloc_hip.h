@@ -590,6 +590,12 @@ int64_t hfl_window_attention_bwd_workspace(const hfl_window_attn_desc* desc);
 int hfl_window_attention_bwd_det(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
                                  const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* desc,
                                  void* workspace, hfl_stream_t stream);
+/* The same (workspace = NULL: the float-atomic table gradient of hfl_window_attention_bwd) with dqkv written as the split2
+ * operand (rows, 2 * 3 H 16) bf16 of the qkv layer's data- and weight-gradient GEMMs (round 6): bit for bit what hfl_split2
+ * makes of the f32 gradient, which is never in memory (the training step spent 2 ms in that pass). */
+int hfl_window_attention_bwd_split2(uint16_t* dqkv_split2, float* drpe_table, const float* qkv, const float* dout,
+                                    const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* desc,
+                                    void* workspace, hfl_stream_t stream);
 /* Gradient of hfl_relay_attention_fwd.  dqkv (rows, 3*H*16): rows listed in seq_rows are written, the
  * others left untouched (the caller zero-fills).  max_seq_len * 268 B of LDS per workgroup: returns
  * HFL_ECAPACITY beyond 611 relay tokens per cloud. */
@@ -699,6 +705,12 @@ int hfl_relay_block_forward_x3(const hfl_relay_block_weights* w, const hfl_relay
  * cin % 64 == 0, cout % 64 == 0.  fp32 MFMA, fixed summation order. */
 int hfl_tap_wgrad(float* dw, const float* g, const float* dpart, const int32_t* chunks, int n_chunks,
                   const int32_t* tap_chunk_off, int taps, int cin, int cout, float* workspace, hfl_stream_t stream);
+/* The same with the pair-major operands read through row tables (round 6): pair p contracts row g_rows[p] of g (the layer
+ * input, (n_src, cin)) with row d_rows[p] of dpart (the output gradient, (n_out, cout)); a NULL table = pair-major operand as
+ * above.  With both tables neither octree2col copy of the backward is written (ocnn materialises both). */
+int hfl_tap_wgrad_gather(float* dw, const float* g, const int32_t* g_rows, const float* dpart, const int32_t* d_rows,
+                         const int32_t* chunks, int n_chunks, const int32_t* tap_chunk_off, int taps, int cin, int cout,
+                         float* workspace, hfl_stream_t stream);
 /* Inverse of a gather table whose source and destination row counts differ (stride-2 conv:
  * table (n_dst, K) with entries in [0, n_src)): inverse (n_src, K), inverse[table[m,k], k] = m, -1 else. */
 int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table, int64_t n_dst_rows,

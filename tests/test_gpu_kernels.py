@@ -226,6 +226,43 @@ def test_live_tap_conv_gradients_match_the_dense_formulation():
             assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6, (depth, ks, stride, what)
 
 
+def test_dwconv_weight_gradient_at_small_and_ragged_row_counts():
+    """hfl_dwconv_weight_backward deals the rows to the eight XCDs in contiguous eighths: row counts below one workgroup per
+    XCD, one row, and counts that are no multiple of the rows per workgroup must still visit every row once."""
+    g = torch.Generator().manual_seed(11)
+    for n, c, k in ((1, 256, 27), (7, 256, 27), (50, 128, 27), (131, 64, 8), (1000, 256, 27), (4099, 32, 27)):
+        neigh = torch.randint(-1, n, (n, k), generator=g, dtype=torch.int32)
+        x, dy = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+        ref = torch.zeros(k, c, dtype=torch.float64)
+        for t in range(k):
+            ok = neigh[:, t] >= 0
+            ref[t] = (x[neigh[ok, t].long()].double() * dy[ok].double()).sum(0)
+        got = ops.dwconv_weight_backward(dy.to(DEV), x.to(DEV), neigh.to(DEV)).view(k, c).cpu().double()
+        assert (got - ref).abs().max().item() <= 1e-5 * max(ref.abs().max().item(), 1.0), (n, c, k)
+
+
+def test_tap_wgrad_through_row_tables_equals_the_pair_major_form():
+    """hfl_tap_wgrad_gather: the weight gradient read through the pair tables (layer input by `src`, output gradient by
+    `rowof`) is BITWISE the one computed from the two pair-major copies (same kernel, same summation order), and both match
+    the fp64 contraction."""
+    clouds = syn.make_clouds(21, 3, 3000, 'cartesian')
+    o = build_batch_octree(clouds, 7, 2, DEV, construct_neigh=True)
+    g = torch.Generator().manual_seed(5)
+    for depth, kernel, stride, cin, cout in ((6, '333', 1, 64, 64), (5, '333', 1, 128, 64), (6, '222', 2, 64, 128)):
+        src, slot, edges = o.sparse_taps(depth, kernel, stride)
+        rowof, _, chunks, tap_off = o.sparse_taps_bwd(depth, kernel, stride)
+        x = torch.randn(int(o.nnum_nempty[depth]), cin, generator=g).to(DEV)
+        dy = torch.randn(slot.shape[0], cout, generator=g).to(DEV)
+        gp, dp = ops.octree_gather(x, src), ops.octree_gather(dy, rowof)
+        taps = slot.shape[1]
+        a = ops.tap_wgrad(gp, dp, chunks, tap_off, taps)
+        b = ops.tap_wgrad(x, dy, chunks, tap_off, taps, g_rows=src, d_rows=rowof)
+        c = ops.tap_wgrad(x, dp, chunks, tap_off, taps, g_rows=src)
+        assert torch.equal(a, b) and torch.equal(a, c), (depth, kernel)
+        ref = torch.stack([gp[edges[k]:edges[k + 1]].double().t() @ dp[edges[k]:edges[k + 1]].double() for k in range(taps)])
+        assert ((a.double() - ref).norm() / ref.norm()).item() < 1e-6
+
+
 # ------------------------------------------------------------------------- dwconv
 def test_dwconv_matches_ocnn_semantics(golden_dir):
     """Port of the reference's own test (`libs/dwconv/test/test_octree_dwconv.py:13-68`):
@@ -1057,6 +1094,14 @@ def test_window_attention_backward_matches_autograd():
             rows_ok = nt + real if G else nt                     # rows of padding windows are never written
             assert torch.equal(td2.grad, td.grad), (cfg, depth, G, dil)
             assert torch.equal(qd2.grad[:rows_ok], qd.grad[:rows_ok]), (cfg, depth, G, dil)
+            # hfl_window_attention_bwd_split2: the gradient written as the split2 GEMM operand = hfl_split2 of the f32 one, bitwise
+            dsp = torch.zeros((qd.shape[0], 6 * C), dtype=torch.bfloat16, device=DEV)
+            dtab = torch.zeros_like(td)
+            desc = ag._desc(nt, W, K, dil, G, H, B, nt, depth)
+            ag._window_attention_bwd(dsp, dtab, qd.detach(), wd if G else torch.cat([wd[:nt], torch.zeros_like(wd[nt:])]),
+                                     plan.meta[depth], td.detach(), desc, split=True)
+            assert torch.equal(dsp[:rows_ok].view(torch.int16), ops.split2(qd.grad[:rows_ok].contiguous()).view(torch.int16))
+            assert torch.equal(dtab, td.grad), (cfg, depth, G, dil)
 
 
 def test_gather_and_relay_init_backward():
