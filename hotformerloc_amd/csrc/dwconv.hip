@@ -120,7 +120,7 @@ static int launch_fwd(float* out, const float* data, const float* weight, const 
 }
 
 // ---------------------------------------------------------- weight gradient
-// partial[(block*rpb+ty), k, c] = sum over the rows this lane-row visited.
+// partial[block, k, c] = sum over the rows the workgroup visited (per lane-row in visiting order, then over its lane-rows).
 // The 27 gathers of a row are issued nine at a time WITHOUT a branch around each (a missing neighbour reads row 0 and is
 // dropped by a select): with `if (ni >= 0) load; fma` every gather waited for the one before it and the launch ran at the
 // latency of 27 dependent L2 round trips per row (187 us at depth 4 against the forward's 65).  Rows are dealt like the
@@ -185,10 +185,37 @@ __global__ void __launch_bounds__(256) dwconv_wgrad_partial(float* __restrict__ 
     const float4 g = reinterpret_cast<const float4*>(grad + h * C)[tx];
     wgrad_row<IdxT, B>(acc, g, data, s_idx + ty * K, K, C, tx);
   }
-  float4* dst = reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * rpb + ty) * K * C);
+  // the workgroup's rpb lane-rows are added in a fixed order (row 0 takes 1, 2, ...), nine taps at a time through LDS: ONE
+  // partial slab per workgroup for the second kernel instead of rpb (85 -> 21 MB written and re-read per depth-4 launch)
+  float4* s_red = reinterpret_cast<float4*>(smem + (((size_t)rpb * K * sizeof(IdxT) + 15) & ~(size_t)15));
 #pragma unroll
-  for (int k = 0; k < kMaxTaps; ++k)
-    if (k < K) dst[k * (C / 4) + tx] = acc[k];
+  for (int k0 = 0; k0 < kMaxTaps; k0 += 9) {
+    if (k0 < K && rpb > 1) {
+      __syncthreads();
+      if (ty > 0) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+          if (k0 + j < K) s_red[((ty - 1) * 9 + j) * tpr + tx] = acc[k0 + j];
+      }
+      __syncthreads();
+      if (ty == 0) {
+        for (int t = 1; t < rpb; ++t) {
+#pragma unroll
+          for (int j = 0; j < 9; ++j)
+            if (k0 + j < K) {
+              const float4 v = s_red[((t - 1) * 9 + j) * tpr + tx];
+              acc[k0 + j].x += v.x; acc[k0 + j].y += v.y; acc[k0 + j].z += v.z; acc[k0 + j].w += v.w;
+            }
+        }
+      }
+    }
+  }
+  if (ty == 0) {
+    float4* dst = reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * K * C);
+#pragma unroll
+    for (int k = 0; k < kMaxTaps; ++k)
+      if (k < K) dst[k * (C / 4) + tx] = acc[k];
+  }
 }
 
 // out[i] = sum_p partial[p, i] in a fixed order (bitwise reproducible)
@@ -245,7 +272,8 @@ static int launch_wgrad(float* out, const float* grad, const float* data, const 
   if (C % 4 == 0 && C <= 1024 && K <= kMaxTaps) {
     RowGeom g = row_geom(C);
     const int blocks = wgrad_blocks(n_rows, g.rpb);
-    const size_t lds = (size_t)g.rpb * K * sizeof(IdxT);
+    const size_t lds = (((size_t)g.rpb * K * sizeof(IdxT) + 15) & ~(size_t)15) +
+                       (size_t)(g.rpb - 1) * 9 * C * sizeof(float);          // row tables | the row reduction's nine-tap block
     float* partial = static_cast<float*>(workspace);
     if (g_wgrad_batch == 6)
       dwconv_wgrad_partial<IdxT, 6><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows, (int)C, K, g.tpr,
@@ -257,7 +285,7 @@ static int launch_wgrad(float* out, const float* grad, const float* data, const 
       dwconv_wgrad_partial<IdxT, 9><<<blocks, g.tpr * g.rpb, lds, s>>>(partial, grad, data, neigh, n_rows, (int)C, K, g.tpr,
                                                                        g.rpb);
     const int64_t kc = (int64_t)K * C;
-    dwconv_wgrad_reduce<<<(int)hfl_cdiv(kc, 64), 1024, 0, s>>>(out, partial, blocks * g.rpb, kc);
+    dwconv_wgrad_reduce<<<(int)hfl_cdiv(kc, 64), 1024, 0, s>>>(out, partial, blocks, kc);
   } else {
     const int64_t kc = (int64_t)K * C;
     dwconv_wgrad_scalar<IdxT><<<(int)hfl_cdiv(kc, 256), 256, 0, s>>>(out, grad, data, neigh, n_rows, C, K);
@@ -447,7 +475,7 @@ int hfl_dwconv_forward_backward(float* out, const float* data, const float* weig
 int64_t hfl_dwconv_weight_backward_workspace(int64_t n_rows, int64_t channels, int kngh) {
   if (channels % 4 != 0 || channels > 1024 || kngh > kMaxTaps) return 16;
   RowGeom g = row_geom(channels);
-  return (int64_t)wgrad_blocks(n_rows, g.rpb) * g.rpb * kngh * channels * (int64_t)sizeof(float);
+  return (int64_t)wgrad_blocks(n_rows, g.rpb) * kngh * channels * (int64_t)sizeof(float);
 }
 
 int hfl_dwconv_weight_backward(float* out, const float* grad, const float* data,

@@ -8,7 +8,7 @@
 // column matrix that is 80-94 % zeros.  Per tap the product contracts thousands of pairs into a 64 x 64 .. 128 x 128
 // matrix -- a shape the BLAS library runs at a few TF/s -- so it is done here: fp32 MFMA (v_mfma_f32_16x16x4_f32, the
 // reference's arithmetic), operands straight from global memory in their natural row-major layout (lane (c, q) of an
-// MFMA wants element [pair q][channel c]: 16 consecutive floats of a row per 16 lanes), no LDS staging.
+// MFMA holds element [pair q][a channel of lane c]: 16 B = four channels, one per feature block, per lane), no LDS staging.
 //
 // Work split: the pair list is cut into chunks of <= 2048 pairs that never straddle a tap (host-built table, cached with
 // the tap lists); workgroup = (chunk, 64 x 64 output tile), its 4 waves take interleaved 16-pair groups and are combined in
@@ -20,11 +20,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <bool GATHER_G, bool GATHER_D>
 __global__ void __launch_bounds__(256)
 tap_wgrad_kernel(float* __restrict__ ws, const float* __restrict__ g, const float* __restrict__ dpart,
                  const int32_t* __restrict__ g_rows, const int32_t* __restrict__ d_rows,
                  const int32_t* __restrict__ chunks, int cin, int cout) {
-  __shared__ float red[3][64 * 64];
+  __shared__ __attribute__((aligned(16))) float red[3][64 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
   const int chunk = blockIdx.x;
@@ -38,43 +39,74 @@ tap_wgrad_kernel(float* __restrict__ ws, const float* __restrict__ g, const floa
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // wave w takes the 16-pair groups w, w + 4, ... of the chunk; inside a group four MFMA steps of 4 pairs
-  for (int p0 = begin + wave * 16; p0 < end; p0 += 64) {
-    float a[4][4], b[4][4];
+  // wave w takes the 16-pair groups w, w + 4, ... of the chunk; inside a group four MFMA steps of 4 pairs.
+  // Lane (c, q) of an MFMA operand holds [pair q][one channel of lane c]; WHICH channel is ours to choose, so lane c takes the
+  // four consecutive channels 4c .. 4c + 3 of the tile for the four feature blocks i (j) -- one 16-B load per pair and operand
+  // instead of four 4-B loads 64 B apart (the launch was bound by the number of vector-memory instructions).
+  // Every address below is valid (a pair index past the chunk's end is clamped to its last pair and the loaded values
+  // dropped by a select), so nothing is loaded under a branch, and the group's operands are requested one group AHEAD, its
+  // table entries two: the 64 MFMAs of a group run while the next group's sixteen 16-B reads are in flight (left to itself
+  // hipcc sinks every read to its first use and waits for each in turn).
+  auto rows_of = [&](int p0, int (&rg)[4], int (&rd)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int p = p0 + 4 * s + q;
-      const bool ok = p < end;
+      const int pc = p < end ? p : end - 1;
       // (hfl_tap_wgrad_gather: pair p reads row g_rows[p] of the layer input / d_rows[p] of the output gradient -- the
       //  pair-major copies of both never exist)
-      const int64_t pg = g_rows != nullptr ? (int64_t)g_rows[ok ? p : begin] : (int64_t)p;
-      const int64_t pd = d_rows != nullptr ? (int64_t)d_rows[ok ? p : begin] : (int64_t)p;
-      const float* gr = g + pg * cin + ci0 + c;
-      const float* dr = dpart + pd * cout + co0 + c;
+      rg[s] = GATHER_G ? g_rows[pc] : pc;
+      rd[s] = GATHER_D ? d_rows[pc] : pc;
+    }
+  };
+  auto operands_of = [&](const int (&rg)[4], const int (&rd)[4], f32x4 (&a)[4], f32x4 (&b)[4]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[s][i] = ok ? gr[16 * i] : 0.f;
-        b[s][i] = ok ? dr[16 * i] : 0.f;
+    for (int s = 0; s < 4; ++s) {
+      a[s] = *reinterpret_cast<const f32x4*>(g + (int64_t)rg[s] * cin + ci0 + 4 * c);
+      b[s] = *reinterpret_cast<const f32x4*>(dpart + (int64_t)rd[s] * cout + co0 + 4 * c);
+    }
+  };
+  if (begin < end) {
+    int p0 = begin + wave * 16;
+    f32x4 a[4], b[4], an[4], bn[4];
+    int rg[4], rd[4];
+    rows_of(p0, rg, rd);
+    operands_of(rg, rd, a, b);
+    rows_of(p0 + 64, rg, rd);
+    for (; p0 < end; p0 += 64) {
+      operands_of(rg, rd, an, bn);                  // group p0 + 64 (its rows were requested one group ago)
+      rows_of(p0 + 128, rg, rd);                    // raw table entries only: nothing below the barrier uses them
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = p0 + 4 * s + q < end;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[s][i] = ok ? a[s][i] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[s] = an[s];
+        b[s] = bn[s];
       }
     }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
   }
 
   // combine the four waves in a fixed order: waves 1..3 park their tiles in LDS, wave 0 adds them 1, 2, 3
-  // accumulator layout: lane (c, q) holds rows ci = 16 i + 4 q + e, column co = 16 j + c
+  // accumulator layout: lane (c, q), element e of acc[i][j] = input channel 4 (4 q + e) + i, output channel 4 c + j
   if (wave > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave - 1][(16 * i + 4 * q + e) * 64 + 16 * j + c] = acc[i][j][e];
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<f32x4*>(&red[wave - 1][(4 * (4 * q + e) + i) * 64 + 4 * c]) =
+            (f32x4){acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
   }
   __syncthreads();
   if (wave == 0) {
@@ -82,16 +114,14 @@ tap_wgrad_kernel(float* __restrict__ ws, const float* __restrict__ g, const floa
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 16 * i + 4 * q + e, cc = 16 * j + c;
-          float v = acc[i][j][e];
-          v += red[0][r * 64 + cc];
-          v += red[1][r * 64 + cc];
-          v += red[2][r * 64 + cc];
-          out[(int64_t)(ci0 + r) * cout + co0 + cc] = v;
-        }
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * (4 * q + e) + i;
+        f32x4 v = (f32x4){acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]};
+        v += *reinterpret_cast<const f32x4*>(&red[0][r * 64 + 4 * c]);
+        v += *reinterpret_cast<const f32x4*>(&red[1][r * 64 + 4 * c]);
+        v += *reinterpret_cast<const f32x4*>(&red[2][r * 64 + 4 * c]);
+        *reinterpret_cast<f32x4*>(out + (int64_t)(ci0 + r) * cout + co0 + 4 * c) = v;
+      }
   }
 }
 
@@ -122,7 +152,14 @@ extern "C" int hfl_tap_wgrad_gather(float* dw, const float* g, const int32_t* g_
   if (n_chunks > 0) {
     if (g == nullptr || dpart == nullptr || chunks == nullptr || workspace == nullptr) return HFL_EINVAL;
     dim3 grid((unsigned)n_chunks, (unsigned)((cin / 64) * (cout / 64)));
-    tap_wgrad_kernel<<<grid, 256, 0, s>>>(workspace, g, dpart, g_rows, d_rows, chunks, cin, cout);
+    if (g_rows != nullptr && d_rows != nullptr)
+      tap_wgrad_kernel<true, true><<<grid, 256, 0, s>>>(workspace, g, dpart, g_rows, d_rows, chunks, cin, cout);
+    else if (g_rows != nullptr)
+      tap_wgrad_kernel<true, false><<<grid, 256, 0, s>>>(workspace, g, dpart, g_rows, d_rows, chunks, cin, cout);
+    else if (d_rows != nullptr)
+      tap_wgrad_kernel<false, true><<<grid, 256, 0, s>>>(workspace, g, dpart, g_rows, d_rows, chunks, cin, cout);
+    else
+      tap_wgrad_kernel<false, false><<<grid, 256, 0, s>>>(workspace, g, dpart, g_rows, d_rows, chunks, cin, cout);
   }
   const int n4 = cin * cout / 4;
   dim3 rgrid((unsigned)hfl_cdiv(n4, 256), (unsigned)taps);

@@ -291,9 +291,12 @@ class Octree:
             neigh = self.get_neigh(depth, kernel, stride, nempty=True).contiguous()
             n_src = int(self.nnum_nempty[depth])
             rows = torch.arange(slot.shape[0], dtype=torch.int32, device=slot.device).view(-1, 1).expand_as(slot)
-            live = slot >= 0
-            rowof = torch.empty(max(edges[-1], 1), dtype=torch.int32, device=slot.device)
-            rowof[slot[live].long()] = rows[live]
+            # (scatter with the missing pairs sent to a spare entry: boolean-mask indexing is a nonzero + a host round trip in
+            #  the middle of the backward)
+            npairs = int(edges[-1])
+            rowof = torch.empty(npairs + 1, dtype=torch.int32, device=slot.device)
+            rowof.scatter_(0, torch.where(slot >= 0, slot, torch.full_like(slot, npairs)).reshape(-1).long(),
+                           rows.reshape(-1))
             inv = torch.empty((n_src, neigh.shape[1]), dtype=torch.int32, device=neigh.device)
             ops.inverse_table(inv, neigh)
             inv_slot = torch.where(inv >= 0, slot.gather(0, inv.clamp_min(0).long()), torch.full_like(inv, -1))
