@@ -1922,6 +1922,7 @@ struct WinBwdParams {
   float* dtable_part;     // second-generation kernel: per (grid column, head) partial tables (gridDim.x, H, 3*nrpe) instead of
                           // float atomics into dtable (fixed-order reduction afterwards: reproducible); null = atomics
   int out_split;          // 1: dqkv leaves as the split2 operand of the GEMMs behind it (hfl_window_attention_bwd_split2)
+  int depth;              // octree depth of the token rows (coordinates < 2^depth), 0 = unknown
 };
 
 // one lane's four consecutive channels of a dqkv row.  split != 0: the row is written in the split2 layout of csrc/gemm_x3.hip
@@ -2231,7 +2232,15 @@ __device__ __forceinline__ bwd_b8 bwd_cat(const uint2 a, const uint2 b) {
   return __builtin_bit_cast(bwd_b8, q);
 }
 
-template <int T, int G, int NREP>
+// RT > 0 (round 6): the RPE-table gradient on the matrix cores.  The token coordinates of a level of depth <= 5 are < R = 16 RT, so
+//     dtable[axis][clamp(w - v + bnd)] = sum_{q, k} dS[q][k] [x_q = w] [x_k = v]  =  diagonal sums of  F = OHQ^T dS OHK
+// with the one-hot matrices OHQ (L x R), OHK (L x R) of the window's query / key coordinates: E = dS OHK (the dS fragments that
+// feed dQ, against a one-hot B operand built from the packed coordinates), F += OHQ^T E (E's accumulators of a query-tile pair,
+// split to bf16 (hi, lo), ARE the B operand: no transposition).  F (3 axes x R x R, 12 or 48 accumulator registers) is summed over
+// every window the wave visits; the 2R - 1 diagonals are added once, at the end, in a fixed order.  No LDS atomics: the
+// fixed-point scatter-add below ran at the rate of its equal-address conflicts (64 lanes onto <= 31 offsets per axis at depth 4)
+// and was 56-61 % of the launch (profiles/r06_o_attn_bwd_bench_before.log).  RT = 0: that path (deeper levels).
+template <int T, int G, int NREP, int RT>
 __global__ void __launch_bounds__(128)
 window_attn_bwd2_kernel(const WinBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2249,7 +2258,11 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
   int4* s_key = reinterpret_cast<int4*>(smem);                          // [LP]
   int4* s_qry = s_key + LP;                                             // [LP]
   int* s_row = reinterpret_cast<int*>(s_qry + LP);                      // [LP]
-  unsigned char* wave_base = reinterpret_cast<unsigned char*>(s_row + LP);
+  // one-hot image of the window's coordinates (RT > 0): [axis][LR token rows][R = 16 RT columns] bf16, 1.0 at the token's
+  // coordinate, all-zero rows for slots without RPE (padding, the relay token); both waves of the workgroup read it
+  constexpr int OHB = 32 * RT;                                           // bytes per image row
+  unsigned char* s_oh = reinterpret_cast<unsigned char*>(s_row + LP);    // [3][LR][OHB]
+  unsigned char* wave_base = s_oh + 3 * LR * OHB;
   const int scr_bytes = NREP * tabf * 8 > 4096 ? NREP * tabf * 8 : 4096;   // transposition block / fixed-point table: never live together
   const int wave_bytes = 3 * LR * 64 + scr_bytes + 2 * tabf * 4;
 
@@ -2284,6 +2297,11 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
       const int a = i / ((LR - LP) * 4), r = i % ((LR - LP) * 4);
       reinterpret_cast<uint4*>(img_k + a * LR * 64 + LP * 64)[r] = make_uint4(0u, 0u, 0u, 0u);
     }
+  if (RT > 0 && LR > LP)
+    for (int i = tid; i < 3 * (LR - LP) * OHB / 16; i += NHW * 64) {
+      const int a = i / ((LR - LP) * OHB / 16), r = i % ((LR - LP) * OHB / 16);
+      reinterpret_cast<uint4*>(s_oh + (a * LR + LP) * OHB)[r] = make_uint4(0u, 0u, 0u, 0u);
+    }
   const int hi4 = 8 * p.bnd;
   const float scale2 = p.scale * kLog2e;
   const float mask2 = kMaskValue * kLog2e;
@@ -2311,6 +2329,14 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
     const bwd_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(base + stride16));
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   };
+  constexpr int RTA = RT > 0 ? RT : 1;
+  f32x4 ftab[3][RTA][RTA];                         // F[axis][w tile][v tile]: lane (c, g) holds rows w = 4g + r, column v = c
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < RTA; ++i)
+#pragma unroll
+      for (int j = 0; j < RTA; ++j) ftab[a][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int w = blockIdx.x; w < p.n_windows; w += gridDim.x) {
     // Rows are index arithmetic (token of window slot j = tok0 + j * D, relay row = rt_row0 + w), so NOTHING below waits for
@@ -2381,6 +2407,19 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
       s_key[tid] = make_int4(4 * (p.bnd - x), 4 * (p.bnd - y), 4 * (p.bnd - z), m_bid);
       s_qry[tid] = make_int4(4 * x, 4 * y, 4 * z, m_row >= 0 ? m_bid : -2);
       s_row[tid] = m_row;
+      if constexpr (RT > 0) {
+        if (rpe) {
+          const bool live = tid < K && m_row >= 0;
+          const int xyz[3] = {x, y, z};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            unsigned char* row = s_oh + (a * LR + tid) * OHB;
+#pragma unroll
+            for (int i = 0; i < OHB / 16; ++i) reinterpret_cast<uint4*>(row)[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (live && xyz[a] < 16 * RT) reinterpret_cast<uint16_t*>(row)[xyz[a]] = 0x3F80;   // (same thread, LDS in order)
+          }
+        }
+      }
     }
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0);   // this wave's LDS writes are complete before it reads them
@@ -2391,6 +2430,21 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
     for (int kt = 0; kt < T; ++kt) {
       dk[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dv[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // one-hot operands of the window (RT > 0), straight from the image by transposing reads: lane (c, g) gets column c of a
+    // 16-column block for the token slots 4g .. 4g + 3 of the two 16-row tiles of pair tp -- the contraction order of the dS / E
+    // fragments.  Queries and keys are the same tokens: oh[tp] is OHK of key pair tp and OHQ^T of query pair tp.
+    bwd_b8 oh[NP][3][RTA];
+    if constexpr (RT > 0) {
+      if (rpe) {
+        const int tr_oh = (4 * g + (c >> 2)) * OHB + (c & 3) * 8;
+#pragma unroll
+        for (int tp = 0; tp < NP; ++tp)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) oh[tp][a][t] = tr_pair(s_oh + (a * LR + 2 * tp * 16) * OHB + t * 32 + tr_oh, 16 * OHB);
+      }
     }
 
 #pragma unroll
@@ -2466,7 +2520,7 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
           bwd_split4(s[kt][0], s[kt][1], s[kt][2], s[kt][3], ph[u][kt], pl[u][kt]);
           bwd_split4(dsv[kt][0], dsv[kt][1], dsv[kt][2], dsv[kt][3], sh[u][kt], sl[u][kt]);
         }
-        if (q_rpe) {
+        if (RT == 0 && q_rpe) {
 #pragma unroll
           for (int o = 1; o < 16; o <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
           dmax = att_rows_max(dmax);
@@ -2521,6 +2575,43 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
                      dq[3] * p.scale, p.out_split);
       }
 
+      // ---- table gradient of the pair's 32 queries on the matrix cores (see the kernel's header) ----------------------
+      if constexpr (RT > 0) {
+        if (rpe) {
+          const uint2 z2 = make_uint2(0u, 0u);
+#pragma unroll
+          for (int axis = 0; axis < 3; ++axis) {
+#pragma unroll
+            for (int vt = 0; vt < RT; ++vt) {
+              f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};     // E[query 4g + r of tile u][v = 16 vt + c]
+#pragma unroll
+              for (int kp = 0; kp < NP; ++kp) {
+                const bwd_b8 ohk = oh[kp][axis][vt];
+                const bool two = 2 * kp + 1 < T;
+                const bwd_b8 a0h = bwd_cat(sh[0][2 * kp], two ? sh[0][two ? 2 * kp + 1 : 0] : z2);
+                const bwd_b8 a0l = bwd_cat(sl[0][2 * kp], two ? sl[0][two ? 2 * kp + 1 : 0] : z2);
+                const bwd_b8 a1h = bwd_cat(sh[1][2 * kp], two ? sh[1][two ? 2 * kp + 1 : 0] : z2);
+                const bwd_b8 a1l = bwd_cat(sl[1][2 * kp], two ? sl[1][two ? 2 * kp + 1 : 0] : z2);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, ohk, e0, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, ohk, e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, ohk, e1, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, ohk, e1, 0, 0, 0);
+              }
+              uint2 h0, l0, h1, l1;
+              bwd_split4(e0[0], e0[1], e0[2], e0[3], h0, l0);
+              bwd_split4(e1[0], e1[1], e1[2], e1[3], h1, l1);
+              const bwd_b8 eb_h = bwd_cat(h0, h1), eb_l = bwd_cat(l0, l1);
+#pragma unroll
+              for (int wt = 0; wt < RT; ++wt) {
+                const bwd_b8 ohq = oh[qp][axis][wt];
+                ftab[axis][wt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ohq, eb_l, ftab[axis][wt][vt], 0, 0, 0);
+                ftab[axis][wt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ohq, eb_h, ftab[axis][wt][vt], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+
       // ---- dK^T, dV^T: contraction over the 32 queries of the pair ---------------------------------------------------
       const bwd_b8 qT_h = tr_pair(img_q + (2 * qp) * 16 * 64 + tr_img, 16 * 64);
       const bwd_b8 qT_l = tr_pair(img_q + (2 * qp) * 16 * 64 + 32 + tr_img, 16 * 64);
@@ -2562,6 +2653,41 @@ window_attn_bwd2_kernel(const WinBwdParams p) {
       }
     }
   }
+  if constexpr (RT > 0) {
+    if (rpe) {
+      // F leaves the accumulators through this wave's (now idle) image block; entry t of an axis = the diagonals w - v that
+      // clamp to it, added in ascending (diagonal, w) order by the lane that owns the entry
+      constexpr int R = 16 * RT;
+      static_assert(3 * R * R * 4 <= 3 * LR * 64, "F must fit the wave's image block");
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      float* fl = reinterpret_cast<float*>(img_k);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int wt = 0; wt < RT; ++wt)
+#pragma unroll
+          for (int vt = 0; vt < RT; ++vt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fl[(a * R + 16 * wt + 4 * g + r) * R + 16 * vt + c] = ftab[a][wt][vt][r];
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < 3 * nrpe; i += 64) {
+        const int a = i / nrpe, t = i - a * nrpe;
+        int dlo = t - p.bnd, dhi = t - p.bnd;
+        if (t == 0) dlo = -(R - 1);
+        if (t == nrpe - 1) dhi = R - 1;
+        if (dlo < -(R - 1)) dlo = -(R - 1);
+        if (dhi > R - 1) dhi = R - 1;
+        float sum = 0.f;
+        for (int d = dlo; d <= dhi; ++d) {
+          const int w0 = d > 0 ? d : 0, w1 = d < 0 ? R - 1 + d : R - 1;
+          for (int w = w0; w <= w1; ++w) sum += fl[(a * R + w) * R + (w - d)];
+        }
+        dtabx[i] = sum;
+      }
+    }
+  }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   if (rpe && p.dtable_part != nullptr) {          // this wave's whole partial table, zeros included: summed in a fixed order
@@ -2587,47 +2713,97 @@ __global__ void __launch_bounds__(256) window_dtable_reduce_kernel(float* __rest
 
 static int g_window_bwd_variant = 2;
 
-// grid columns of the second-generation backward (must equal what launch_window_bwd2 computes)
-template <int T, int G, int NREP>
-static int window_bwd2_columns(int n_windows, int H, int bnd) {
+// table gradient on the matrix cores when the level's coordinates fit 16 or 32 (desc.depth is the octree depth of the token rows;
+// 0 = not given) and F fits the wave's image block; the fixed-point LDS scatter-add otherwise
+int g_window_bwd_rt = -1;                          // probe: hfl_internal_set_window_bwd_rt(0) forces the scatter-add path
+template <int T>
+static int window_bwd2_rt(int depth, bool has_table) {
+  constexpr int LR = ((T + 1) / 2) * 32;
+  int rt = 0;
+  if (has_table && depth >= 1 && depth <= 4) rt = 1;
+  else if (has_table && depth == 5 && 3 * 32 * 32 * 4 <= 3 * LR * 64) rt = 2;
+  if (g_window_bwd_rt >= 0 && g_window_bwd_rt < rt) rt = g_window_bwd_rt;
+  return rt;
+}
+
+template <int T, int NREP>
+static size_t window_bwd2_lds(int bnd, int rt) {
   constexpr int LP = T * 16, NP = (T + 1) / 2, LR = NP * 32, NHW = 2;
   const int nrpe = 2 * bnd + 1;
   const int tabf = (3 * nrpe + 3) & ~3;
   const size_t scr_bytes = (size_t)NREP * tabf * 8 > 4096 ? (size_t)NREP * tabf * 8 : 4096;
-  const size_t lds = (size_t)LP * 36 + (size_t)NHW * (3 * LR * 64 + scr_bytes + 2 * tabf * 4);
+  return (size_t)LP * 36 + (size_t)3 * LR * 32 * rt + (size_t)NHW * (3 * LR * 64 + scr_bytes + 2 * tabf * 4);
+}
+
+// Workgroups of one instantiation that a CU holds at once -- registers AND LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor).
+// Rounds 2-5 sized the grid from the LDS alone and added one column: the K = 64 + relay kernel holds 2 workgroups per CU by its
+// registers where its LDS admits 3, so a third of the grid ran as a second round (and the "+ 1" column made a second round of a
+// few workgroups even where the count was right).  Every workgroup loops over windows / columns of them: the grid must not
+// exceed what is resident.
+template <int T, int G, int NREP, int RT>
+static int window_bwd2_resident(size_t lds) {
+  static size_t cached_lds = 0;
+  static int cached = 0;
+  if (cached_lds == lds) return cached;
+  const void* fn = reinterpret_cast<const void*>(window_attn_bwd2_kernel<T, G, NREP, RT>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 128, lds) != hipSuccess) nb = 0;
+  cached_lds = lds;
+  cached = nb;
+  return nb;
+}
+
+// grid columns of the second-generation backward (the launch and the workspace size both come here)
+template <int T, int G, int NREP, int RT>
+static int window_bwd2_columns_rt(int n_windows, int H, int bnd) {
+  constexpr int NHW = 2;
   if (H % NHW != 0) return 0;
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu < 1) return 0;
-  if (per_cu > 8) per_cu = 8;
-  int bx = n_windows;
-  const int capx = hfl_num_cus() * per_cu / (H / NHW) + 1;
-  return bx > capx ? capx : bx;
+  int nb = window_bwd2_resident<T, G, NREP, RT>(window_bwd2_lds<T, NREP>(bnd, RT));
+  if (nb < 1) return 0;
+  if (nb > 8) nb = 8;
+  int capx = hfl_num_cus() * nb / (H / NHW);
+  if (capx < 1) capx = 1;
+  return n_windows > capx ? capx : n_windows;
 }
 
 template <int T, int G, int NREP>
-static int launch_window_bwd2(const WinBwdParams& p, hipStream_t s) {
-  constexpr int LP = T * 16, NP = (T + 1) / 2, LR = NP * 32, NHW = 2;
+static int window_bwd2_columns(int n_windows, int H, int bnd, int depth) {
+  constexpr int LR = ((T + 1) / 2) * 32;
+  const int rt = window_bwd2_rt<T>(depth, true);
+  if constexpr (3 * 32 * 32 * 4 <= 3 * LR * 64) {
+    if (rt == 2) return window_bwd2_columns_rt<T, G, NREP, 2>(n_windows, H, bnd);
+  }
+  if (rt >= 1) return window_bwd2_columns_rt<T, G, NREP, 1>(n_windows, H, bnd);
+  return window_bwd2_columns_rt<T, G, NREP, 0>(n_windows, H, bnd);
+}
+
+template <int T, int G, int NREP, int RT>
+static int launch_window_bwd2_rt(const WinBwdParams& p, hipStream_t s) {
+  constexpr int NHW = 2;
   const int nrpe = 2 * p.bnd + 1;
-  const int tabf = (3 * nrpe + 3) & ~3;
-  const size_t scr_bytes = (size_t)NREP * tabf * 8 > 4096 ? (size_t)NREP * tabf * 8 : 4096;
-  const size_t lds = (size_t)LP * 36 + (size_t)NHW * (3 * LR * 64 + scr_bytes + 2 * tabf * 4);
+  const size_t lds = window_bwd2_lds<T, NREP>(p.bnd, RT);
   if (p.H % NHW != 0) return HFL_EINVAL;
-  int per_cu = (int)((160 * 1024) / lds);
-  if (per_cu < 1) return HFL_ECAPACITY;
-  if (per_cu > 8) per_cu = 8;
-  int bx = p.n_windows;
-  const int capx = hfl_num_cus() * per_cu / (p.H / NHW) + 1;
-  if (bx > capx) bx = capx;
+  const int bx = window_bwd2_columns_rt<T, G, NREP, RT>(p.n_windows, p.H, p.bnd);     // (sets the kernel's LDS attribute)
+  if (bx < 1) return HFL_ECAPACITY;
   dim3 grid((unsigned)bx, (unsigned)(p.H / NHW));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd2_kernel<T, G, NREP>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return (int)e;
-  window_attn_bwd2_kernel<T, G, NREP><<<grid, NHW * 64, lds, s>>>(p);
+  window_attn_bwd2_kernel<T, G, NREP, RT><<<grid, NHW * 64, lds, s>>>(p);
   if (p.dtable_part != nullptr && p.dtable != nullptr && p.table != nullptr) {
     const int n3 = 3 * nrpe;
     window_dtable_reduce_kernel<<<(n3 * p.H + 255) / 256, 256, 0, s>>>(p.dtable, p.dtable_part, bx, p.H, n3);
   }
   HFL_RETURN_LAST_ERROR();
+}
+
+template <int T, int G, int NREP>
+static int launch_window_bwd2(const WinBwdParams& p, hipStream_t s) {
+  constexpr int LR = ((T + 1) / 2) * 32;
+  const int rt = window_bwd2_rt<T>(p.depth, p.table != nullptr);
+  if constexpr (3 * 32 * 32 * 4 <= 3 * LR * 64) {
+    if (rt == 2) return launch_window_bwd2_rt<T, G, NREP, 2>(p, s);
+  }
+  if (rt >= 1) return launch_window_bwd2_rt<T, G, NREP, 1>(p, s);
+  return launch_window_bwd2_rt<T, G, NREP, 0>(p, s);
 }
 
 template <int T, int G>
@@ -2658,6 +2834,7 @@ static int launch_window_bwd(const WinBwdParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" void hfl_internal_set_window_bwd(int v) { g_window_bwd_variant = v; }
+extern "C" void hfl_internal_set_window_bwd_rt(int v) { g_window_bwd_rt = v; }
 
 static int window_bwd_columns(const hfl_window_attn_desc* d) {
   if (d == nullptr || d->n_heads <= 0 || d->patch_size % 16 != 0 || d->n_relay < 0 || d->n_relay > 1) return 0;
@@ -2666,18 +2843,18 @@ static int window_bwd_columns(const hfl_window_attn_desc* d) {
   const int W = d->n_windows, H = d->n_heads, b = d->pos_bnd;
   if (d->n_relay == 0) {
     switch (T) {
-      case 1: return window_bwd2_columns<1, 0, 1>(W, H, b);
-      case 2: return window_bwd2_columns<2, 0, 1>(W, H, b);
-      case 3: return window_bwd2_columns<3, 0, 1>(W, H, b);
-      case 4: return window_bwd2_columns<4, 0, 1>(W, H, b);
+      case 1: return window_bwd2_columns<1, 0, 1>(W, H, b, d->depth);
+      case 2: return window_bwd2_columns<2, 0, 1>(W, H, b, d->depth);
+      case 3: return window_bwd2_columns<3, 0, 1>(W, H, b, d->depth);
+      case 4: return window_bwd2_columns<4, 0, 1>(W, H, b, d->depth);
       default: return 0;
     }
   }
   switch (T) {
-    case 2: return window_bwd2_columns<2, 1, 1>(W, H, b);
-    case 3: return window_bwd2_columns<3, 1, 1>(W, H, b);
-    case 4: return window_bwd2_columns<4, 1, 1>(W, H, b);
-    case 5: return window_bwd2_columns<5, 1, 1>(W, H, b);
+    case 2: return window_bwd2_columns<2, 1, 1>(W, H, b, d->depth);
+    case 3: return window_bwd2_columns<3, 1, 1>(W, H, b, d->depth);
+    case 4: return window_bwd2_columns<4, 1, 1>(W, H, b, d->depth);
+    case 5: return window_bwd2_columns<5, 1, 1>(W, H, b, d->depth);
     default: return 0;
   }
 }
@@ -2729,6 +2906,7 @@ static int window_attention_bwd_impl(float* dqkv, float* drpe_table, const float
   p.scale = d->scale;
   p.dtable_part = static_cast<float*>(workspace);
   p.out_split = out_split;
+  p.depth = d->depth;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int T = d->patch_size / 16 + d->n_relay;
   if (d->n_relay == 0) {

@@ -13,6 +13,7 @@ md = depth - 2
 plan = WindowPlan(octree, params.patch_size, params.dilation, md, md - 3, 3, 1, params.ADaPE_mode)
 K = params.patch_size
 lib = _native.load()
+lib.hfl_internal_set_window_bwd_rt.argtypes = [ctypes.c_int]
 def timeit(fn, rounds=5, inner=5):
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -42,6 +43,22 @@ for d, H, G, dil in ((md, 8, 0, 1), (md, 8, 0, params.dilation), (md - 1, 16, 1,
                       plan.meta[d].data_ptr(), table.data_ptr(), ctypes.byref(desc), ops._stream()), 'bwd')
         t = timeit(run)
         res[variant] = (t, dqkv.clone(), dtab.clone())
+    # round 6: the table gradient on the matrix cores (default where the level's coordinates fit) against the LDS scatter-add
+    lib.hfl_set_variant(b'window_bwd', 2)
+    rt = {}
+    for name, v in (('scatter-add', 0), ('matrix cores', -1)):
+        lib.hfl_internal_set_window_bwd_rt(v)
+        dqkv = torch.zeros_like(qkv); dtab = torch.zeros_like(table)
+        def run2():
+            dtab.zero_()
+            ops.check(lib.hfl_window_attention_bwd(dqkv.data_ptr(), dtab.data_ptr(), qkv.data_ptr(), dout.data_ptr(),
+                      plan.meta[d].data_ptr(), table.data_ptr(), ctypes.byref(desc), ops._stream()), 'bwd')
+        rt[name] = (timeit(run2), dqkv.clone(), dtab.clone())
+    lib.hfl_internal_set_window_bwd_rt(-1)
+    print('   table gradient: scatter-add %.1f us, matrix cores %.1f us | dtable difference %.1e of its max, dqkv difference %.1e of its max'
+          % (rt['scatter-add'][0], rt['matrix cores'][0],
+             (rt['scatter-add'][2] - rt['matrix cores'][2]).abs().max().item() / rt['scatter-add'][2].abs().max().item(),
+             (rt['scatter-add'][1] - rt['matrix cores'][1]).abs().max().item() / rt['scatter-add'][1].abs().max().item()))
     t_norpe = {}
     for variant in (1, 2):
         lib.hfl_set_variant(b'window_bwd', variant)
