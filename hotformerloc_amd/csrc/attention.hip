@@ -1226,6 +1226,8 @@ static int g_window_v4_wgs_per_cu = 1;   // multiples of the resident workgroup 
 static int g_window_dbg = 0;
 static int g_window_v2_wgs_per_cu = 16;
 static int g_window_heads_per_wg = 4;
+static int g_relay_fast = 1;            // probe (hfl_set_variant "relay_fast")
+static int g_window_bwd_rt = -1;        // probe ("window_bwd_rt"): 0 forces the scatter-add table gradient of the backward
 
 // fp16 (hi, lo) operand layout: only the v5 kernel reads it (callers ask hfl_window_attention_f16_ok first).  `n` problems of
 // one shape in ONE launch (see WinMultiParams); HFL_EINVAL when they cannot share a launch (the caller then launches them
@@ -1500,7 +1502,7 @@ relay_attn_kernel(float* __restrict__ out, const float* __restrict__ qkv,
 __global__ void __launch_bounds__(256)
 relay_attn_f16_kernel(unsigned char* __restrict__ out2, const unsigned char* __restrict__ qkv,
                       const int32_t* __restrict__ seq_rows, const int32_t* __restrict__ seq_off,
-                      const int32_t* __restrict__ orphan_rows, int n_orphans, int batch, int H) {
+                      const int32_t* __restrict__ orphan_rows, int n_orphans, int batch, int H, int relay_fast) {
   const int b = blockIdx.x;
   const int C = H * 16;
   if (b >= batch) {
@@ -1524,6 +1526,81 @@ relay_attn_f16_kernel(unsigned char* __restrict__ out2, const unsigned char* __r
     };
     return make_float4(h(hi.x, 0) + h(lo.x, 0), h(hi.x, 1) + h(lo.x, 1), h(hi.y, 0) + h(lo.y, 0), h(hi.y, 1) + h(lo.y, 1));
   };
+  if (R <= 0) return;
+  if (ntile <= 4 && relay_fast) {
+    // Short sequences (every shipped configuration: <= 64 relay tokens per cloud): a (head, query tile) item is ONE memory
+    // round trip.  The lane's own row index first (one coalesced read; the others by cross-lane reads), then the query, the
+    // four key fragments and the sixteen V elements of the lane are requested together from always-valid addresses (slots past
+    // the sequence are clamped to its last row and masked below), scores and probabilities stay in registers (no second pass).
+    // The general loop below re-reads the row table per key tile and per V element under a branch: ~40 dependent L2 round
+    // trips per item, 23 us for 0.1 MFLOP, ten times per forward on the relay tokens' chain.
+    const int myrow = seq_rows[r0 + (lane < R ? lane : R - 1)];
+    for (int item = blockIdx.y * nwave + wave; item < H * ntile; item += gridDim.y * nwave) {
+      const int h = item / ntile, qt = item % ntile;
+      const float4 qf = ld4(qkv + (size_t)__shfl(myrow, qt * 16 + c, 64) * row_b + h * 64);
+      float4 kf[4];
+      unsigned short vh[4][4], vl[4][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        kf[kt] = ld4(qkv + (size_t)__shfl(myrow, kt * 16 + c, 64) * row_b + (size_t)C * 4 + h * 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned char* vp = qkv + (size_t)__shfl(myrow, kt * 16 + 4 * g + r, 64) * row_b + (size_t)C * 8 + h * 64 + c * 2;
+          vh[kt][r] = *reinterpret_cast<const unsigned short*>(vp);
+          vl[kt][r] = *reinterpret_cast<const unsigned short*>(vp + 32);
+        }
+      }
+      f32x4 sc[4];
+      float m = kDeadValue;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].x, qf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].y, qf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].z, qf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt].w, qf.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[kt][r] = kt * 16 + 4 * g + r < R ? acc[r] : kDeadValue;
+          m = fmaxf(m, sc[kt][r]);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[kt][r] = __builtin_amdgcn_exp2f(sc[kt][r] - m);
+          l += sc[kt][r];
+        }
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float vv = (float)__builtin_bit_cast(_Float16, vh[kt][r]) + (float)__builtin_bit_cast(_Float16, vl[kt][r]);
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][r] * inv, vv, o, 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oq = qt * 16 + 4 * g + r;
+        const int orow = __shfl(myrow, oq < 64 ? oq : 63, 64);       // (outside the branch: a cross-lane read needs its source lane active)
+        if (oq < R) {
+          const uint32_t hb = x3_bf16_rne(o[r]);
+          const uint32_t lb = x3_bf16_rne(o[r] - __uint_as_float(hb << 16));
+          unsigned char* op = out2 + (size_t)orow * (size_t)(C * 4) + (h >> 1) * 128 + (h & 1) * 32 + c * 2;
+          *reinterpret_cast<unsigned short*>(op) = (unsigned short)hb;
+          *reinterpret_cast<unsigned short*>(op + 64) = (unsigned short)lb;
+        }
+      }
+    }
+    return;
+  }
   for (int item = blockIdx.y * nwave + wave; item < H * ntile; item += gridDim.y * nwave) {
     const int h = item / ntile, qt = item % ntile;
     const int qi = qt * 16 + c;
@@ -1655,6 +1732,8 @@ int hfl_set_variant(const char* key, int value) {
     g_rpe_form1_max_depth = 4;
     g_window_v2_wgs_per_cu = 16;
     g_window_heads_per_wg = 4;
+    g_relay_fast = 1;
+    g_window_bwd_rt = -1;
     hfl_internal_set_window_bwd(2);
     hfl_internal_set_x3_dbg(0);
     hfl_internal_set_x3_dbg(0x100);
@@ -1703,6 +1782,10 @@ int hfl_set_variant(const char* key, int value) {
     g_window_v2_wgs_per_cu = value;
   } else if (is("window_heads_per_wg")) {
     g_window_heads_per_wg = value;
+  } else if (is("relay_fast")) {                      // probe: 0 = the general loop of relay_attn_f16_kernel for every length
+    g_relay_fast = value;
+  } else if (is("window_bwd_rt")) {                   // probe: 0 = scatter-add table gradient in the attention backward
+    g_window_bwd_rt = value;
   } else {
     return HFL_EINVAL;
   }
@@ -1889,7 +1972,7 @@ int hfl_relay_attention_f16_fwd(void* out_split2, const void* qkv_f16, const int
   dim3 grid((unsigned)batch + (n_orphans > 0 ? 1u : 0u), (unsigned)(items > 4 ? (items + 3) / 4 : 1));
   relay_attn_f16_kernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<unsigned char*>(out_split2), static_cast<const unsigned char*>(qkv_f16), seq_rows, seq_off, orphan_rows,
-      n_orphans, batch, n_heads);
+      n_orphans, batch, n_heads, g_relay_fast);
   HFL_RETURN_LAST_ERROR();
 }
 
@@ -2715,7 +2798,6 @@ static int g_window_bwd_variant = 2;
 
 // table gradient on the matrix cores when the level's coordinates fit 16 or 32 (desc.depth is the octree depth of the token rows;
 // 0 = not given) and F fits the wave's image block; the fixed-point LDS scatter-add otherwise
-int g_window_bwd_rt = -1;                          // probe: hfl_internal_set_window_bwd_rt(0) forces the scatter-add path
 template <int T>
 static int window_bwd2_rt(int depth, bool has_table) {
   constexpr int LR = ((T + 1) / 2) * 32;

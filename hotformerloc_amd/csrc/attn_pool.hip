@@ -387,7 +387,9 @@ namespace {
 
 constexpr int kTailMaxD = 8;
 
-__global__ void __launch_bounds__(256)
+// One workgroup per cloud, 16 waves (round 6; 4 waves walked 65 tokens each with the row_proj rows re-read per token and one
+// lane per output looped over all tokens: 122 us at the very end of the forward, where nothing overlaps it).
+__global__ void __launch_bounds__(1024)
 mixer_tail_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ wc,
                   const float* __restrict__ bc, const float* __restrict__ wr, const float* __restrict__ br, int K, int C, int KO,
                   int D) {
@@ -395,33 +397,63 @@ mixer_tail_kernel(float* __restrict__ out, const float* __restrict__ x, const fl
   float* U = tail_lds;
   float* sw = tail_lds + K * D;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = 16;
   const float* xb = x + (int64_t)b * K * C;
-  // ---- U: wave w takes tokens w, w + 4, ...; a lane holds 4 channels of every 256-channel slab
-  for (int t = wave; t < K; t += 4) {
-    float acc[kTailMaxD];
+  // ---- U: wave w takes tokens w, w + 16, ...; a lane holds 4 channels of every 256-channel slab.  C == 256 (every shipped
+  // configuration): the lane's row_proj weights stay in registers and four tokens are in flight.
+  if (C == 256) {
+    float4 w[kTailMaxD];
 #pragma unroll
-    for (int j = 0; j < kTailMaxD; ++j) acc[j] = 0.f;
-    for (int c0 = lane * 4; c0 < C; c0 += 256) {
-      const float4 xv = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + c0);
+    for (int j = 0; j < kTailMaxD; ++j)
+      w[j] = j < D ? *reinterpret_cast<const float4*>(wr + (int64_t)j * C + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t0 = wave; t0 < K; t0 += 4 * NW) {
+      float4 xv[4];
 #pragma unroll
-      for (int j = 0; j < kTailMaxD; ++j) {
-        if (j < D) {
-          const float4 w = *reinterpret_cast<const float4*>(wr + (int64_t)j * C + c0);
-          acc[j] += (xv.x * w.x + xv.y * w.y) + (xv.z * w.z + xv.w * w.w);
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * NW;
+        xv[u] = *reinterpret_cast<const float4*>(xb + (int64_t)(t < K ? t : t0) * C + lane * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * NW;
+#pragma unroll
+        for (int j = 0; j < kTailMaxD; ++j) {
+          if (j < D) {
+            float v = (xv[u].x * w[j].x + xv[u].y * w[j].y) + (xv[u].z * w[j].z + xv[u].w * w[j].w);
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0 && t < K) U[t * D + j] = v;
+          }
         }
       }
     }
+  } else {
+    for (int t = wave; t < K; t += NW) {
+      float acc[kTailMaxD];
 #pragma unroll
-    for (int j = 0; j < kTailMaxD; ++j) {
-      if (j < D) {
-        float v = acc[j];
+      for (int j = 0; j < kTailMaxD; ++j) acc[j] = 0.f;
+      for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + c0);
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-        if (lane == 0) U[t * D + j] = v;
+        for (int j = 0; j < kTailMaxD; ++j) {
+          if (j < D) {
+            const float4 w = *reinterpret_cast<const float4*>(wr + (int64_t)j * C + c0);
+            acc[j] += (xv.x * w.x + xv.y * w.y) + (xv.z * w.z + xv.w * w.w);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kTailMaxD; ++j) {
+        if (j < D) {
+          float v = acc[j];
+#pragma unroll
+          for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+          if (lane == 0) U[t * D + j] = v;
+        }
       }
     }
   }
-  if (wave == 0) {                                   // sw[j] = sum_c Wr[j, c]
+  if (wave == NW - 1) {                              // sw[j] = sum_c Wr[j, c]
     for (int j = 0; j < D; ++j) {
       float v = 0.f;
       for (int c = lane; c < C; c += 64) v += wr[(int64_t)j * C + c];
@@ -431,13 +463,27 @@ mixer_tail_kernel(float* __restrict__ out, const float* __restrict__ x, const fl
     }
   }
   __syncthreads();
-  // ---- out: one (o, j) per lane
-  for (int idx = tid; idx < KO * D; idx += 256) {
-    const int o = idx / D, j = idx % D;
-    const float* wrow = wc + (int64_t)o * K;
-    float v = 0.f;
-    for (int t = 0; t < K; ++t) v = fmaf(wrow[t], U[t * D + j], v);
-    out[(int64_t)b * KO * D + idx] = v + bc[o] * sw[j] + br[j];
+  // ---- out: wave w takes output tokens o = w, w + 16, ...; lanes run over the input tokens (one coalesced read of the
+  // channel_proj row), the D sums by butterfly
+  for (int o = wave; o < KO; o += NW) {
+    float acc[kTailMaxD];
+#pragma unroll
+    for (int j = 0; j < kTailMaxD; ++j) acc[j] = 0.f;
+    for (int t = lane; t < K; t += 64) {
+      const float wv = wc[(int64_t)o * K + t];
+#pragma unroll
+      for (int j = 0; j < kTailMaxD; ++j)
+        if (j < D) acc[j] = fmaf(wv, U[t * D + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kTailMaxD; ++j) {
+      if (j < D) {
+        float v = acc[j];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+        if (lane == 0) out[(int64_t)b * KO * D + o * D + j] = v + bc[o] * sw[j] + br[j];
+      }
+    }
   }
 }
 
@@ -453,7 +499,7 @@ extern "C" int hfl_mixer_tail(float* out, const float* x, const float* channel_w
   const size_t lds = (size_t)(k_tokens * out_d + out_d) * sizeof(float);
   if (lds > 64 * 1024) return HFL_ECAPACITY;
   if (batch == 0) return HFL_OK;
-  mixer_tail_kernel<<<(unsigned)batch, 256, lds, static_cast<hipStream_t>(stream)>>>(out, x, channel_w, channel_b, row_w, row_b,
+  mixer_tail_kernel<<<(unsigned)batch, 1024, lds, static_cast<hipStream_t>(stream)>>>(out, x, channel_w, channel_b, row_w, row_b,
                                                                                    k_tokens, channels, k_out, out_d);
   HFL_RETURN_LAST_ERROR();
 }
