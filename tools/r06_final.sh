@@ -35,6 +35,14 @@ PY
 # ---- counter survey of hfl_linear_x6 at the depth-4 fc1 shape (MFMA busy, waits, LDS)
 bash tools/pmc_survey2.sh ${tag}_x6_fc1 gemm_x6_kernel tools/x6_one.py 68167 256 1024 0 > $out/${tag}_x6_counters.txt 2>&1
 bash tools/cpe_counters.sh ${tag}
+# ---- training step (config 3): kernel trace, attention-backward bench, plain and checkpointed step
+bash tools/prof_train.sh ${tag}_final_train > $out/${tag}_final_train_prof.log 2>&1
+rm -rf $out/${tag}_final_train_stats
+timeout 600 python tools/attn_bwd_bench.py cs-wild-places 64 8192 > $out/${tag}_attn_bwd_bench_cs_wild_places.log 2>&1
+for i in 1 2; do
+  timeout 600 python bench.py --train --config cs-wild-places --steps 5 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_train_cs_$i.json 2>/dev/null
+  HFL_CHECKPOINT=always timeout 600 python bench.py --train --config cs-wild-places --steps 5 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_train_cs_checkpointed_$i.json 2>/dev/null
+done
 rm -rf $out/${tag}_stats $out/${tag}_serial_stats $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE $out/${tag}_x6_stats $out/${tag}_x6_pmc_FETCH_SIZE $out/${tag}_x6_pmc_WRITE_SIZE $out/survey_${tag}_x6_fc1_g*
 head -16 $out/${tag}_matched_serial_summary_table.md
 tail -c 800 $out/${tag}_bench_default.json
