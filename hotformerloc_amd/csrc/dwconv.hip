@@ -30,6 +30,22 @@ static RowGeom row_geom(int64_t channels) {
   return g;
 }
 
+// Workgroups of a persistent kernel per CU: a whole multiple of what is RESIDENT (registers and LDS, by the occupancy query), at
+// most `want`.  With a grid that is not such a multiple the last, partial round costs a whole one: every workgroup owns an equal
+// share of the rows (round 6: 8 per CU were launched where 5 fit -- 1.6 rounds).
+static int persistent_per_cu(const void* kernel, int threads, size_t lds, int want, int* cache_nb, size_t* cache_lds) {
+  if (*cache_lds != lds + 1) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds) != hipSuccess || nb < 1) nb = 0;
+    *cache_nb = nb;
+    *cache_lds = lds + 1;
+  }
+  const int nb = *cache_nb;
+  if (nb < 1) return want;                         // (query failed: keep the old figure)
+  if (nb >= want) return want;
+  return (want / nb) * nb >= nb ? ((want / nb) * nb) : nb;
+}
+
 // ---------------------------------------------------------------- forward
 // LDS: [K*C] weights | [rpb*K] row indices
 template <typename IdxT, int KFIX>
@@ -103,7 +119,14 @@ static int launch_fwd(float* out, const float* data, const float* weight, const 
     RowGeom g = row_geom(C);
     const size_t lds = (size_t)K * C * sizeof(float) + (size_t)g.rpb * K * sizeof(IdxT);
     const int64_t need = hfl_cdiv(n_out, g.rpb);
-    const int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
+    static int nb27 = 0, nb0 = 0;
+    static size_t l27 = 0, l0 = 0;
+    const int per_cu = K == 27 ? persistent_per_cu(reinterpret_cast<const void*>(dwconv_fwd_vec4<IdxT, 27>), g.tpr * g.rpb, lds, 8,
+                                                   &nb27, &l27)
+                               : persistent_per_cu(reinterpret_cast<const void*>(dwconv_fwd_vec4<IdxT, 0>), g.tpr * g.rpb, lds, 8,
+                                                   &nb0, &l0);
+    const int64_t cap = (int64_t)hfl_stream_cus(s) * per_cu;
+    const int blocks = (int)(need < cap ? need : cap);
     if (K == 27)
       dwconv_fwd_vec4<IdxT, 27><<<blocks, g.tpr * g.rpb, lds, s>>>(out, data, weight, neigh, n_out,
                                                                    (int)C, K, g.tpr, g.rpb);
@@ -449,7 +472,11 @@ static int launch_cpe(float* out, float* conv_out, const float* x, const float* 
   constexpr int RPB = 256 / TPR;
   const size_t lds = (size_t)K * TPR * 16 + (size_t)RPB * K * (sizeof(int32_t) + 1) + 16;
   const int64_t need = hfl_cdiv(n, RPB);
-  int blocks = (int)(need < (int64_t)hfl_stream_cus(s) * 8 ? need : (int64_t)hfl_stream_cus(s) * 8);
+  static int nb = 0;
+  static size_t nb_lds = 0;
+  const int per_cu = persistent_per_cu(reinterpret_cast<const void*>(cpe_fwd_kernel<TPR, NORM>), 256, lds, 8, &nb, &nb_lds);
+  const int64_t cap = (int64_t)hfl_stream_cus(s) * per_cu;
+  int blocks = (int)(need < cap ? need : cap);
   if (g_cpe_chunk_rows < 0) blocks = (blocks + 7) & ~7;          // the XCD map deals whole groups of eight workgroups
   cpe_fwd_kernel<TPR, NORM><<<blocks, 256, lds, s>>>(out, conv_out, x, add, w, gamma, beta, neigh, n, K, eps, residual,
                                                      g_cpe_chunk_rows);

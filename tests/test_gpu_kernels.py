@@ -586,6 +586,16 @@ def test_relay_attention_init_and_stats(cfg, sizes, depth):
     val = (v[:, :, 0] + v[:, :, 1]).reshape(o2.shape[0], C).cpu()
     assert (val - got).abs().max().item() < 3e-5 * max(got.abs().max().item(), 1.0)
     assert torch.all(val[~torch.from_numpy(listed)] == 0)
+    # sequences of <= 64 relay tokens take the one-round-trip path of the kernel; the general loop (longer sequences) must agree
+    lib = _native.load()
+    try:
+        assert lib.hfl_set_variant(b'relay_fast', 0) == 0
+        o3 = ops.relay_attention_f16(packed, plan.seq_rows, plan.seq_off, B, H, plan.max_seq_len, plan.orphan_rows)
+    finally:
+        lib.hfl_set_variant(b'relay_fast', 1)
+    v3 = o3.float().view(o3.shape[0], C // 32, 2, 32)
+    val3 = (v3[:, :, 0] + v3[:, :, 1]).reshape(o3.shape[0], C).cpu()
+    assert (val3 - val).abs().max().item() < 2e-6 * max(got.abs().max().item(), 1.0)
 
 
 def test_segment_softmax():
@@ -1102,6 +1112,18 @@ def test_window_attention_backward_matches_autograd():
                                      plan.meta[depth], td.detach(), desc, split=True)
             assert torch.equal(dsp[:rows_ok].view(torch.int16), ops.split2(qd.grad[:rows_ok].contiguous()).view(torch.int16))
             assert torch.equal(dtab, td.grad), (cfg, depth, G, dil)
+            # the table gradient on the matrix cores (depth <= 5: what ran above) against the LDS scatter-add of deeper levels
+            lib = _native.load()
+            try:
+                assert lib.hfl_set_variant(b'window_bwd_rt', 0) == 0
+                dq0 = torch.zeros((qd.shape[0], 3 * C), device=DEV)
+                dt0 = torch.zeros_like(td)
+                ag._window_attention_bwd(dq0, dt0, qd.detach(), wd if G else torch.cat([wd[:nt], torch.zeros_like(wd[nt:])]),
+                                         plan.meta[depth], td.detach(), desc)
+            finally:
+                lib.hfl_set_variant(b'window_bwd_rt', -1)
+            assert (dt0 - td.grad).abs().max().item() < 2e-5 * max(tscale, 1), (cfg, depth, G, dil)
+            assert (dq0[:rows_ok] - qd.grad[:rows_ok]).abs().max().item() < 2e-5 * max(scale, 1)
 
 
 def test_gather_and_relay_init_backward():
