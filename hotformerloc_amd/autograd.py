@@ -689,6 +689,50 @@ def cpe(x, weights, gamma, beta, neigh, residual: bool, eps: float):
     return CpeFn.apply(x, weights, gamma, beta, neigh, residual, eps)
 
 
+class CpeBufferFn(torch.autograd.Function):
+    """new = [ tokens + LayerNorm(dwconv(tokens)) | relay rows ] of a pyramid level's [tokens | relay rows] buffer: what
+    `torch.cat([cpe(buf[:nt]), relay], 0)` computes at the head of every HOTFormer block (models/hotformerloc_backbone.py:
+    197-205), with the CPE launch writing the token rows of the new buffer itself.  The backward writes the token rows' gradient
+    straight into the buffer's gradient: autograd over the slices and the concatenation made two zero-filled full-size
+    gradients, two copies and an add per block (1.5 ms of the config-3 step) besides the concatenation's copy."""
+
+    @staticmethod
+    def forward(ctx, buf, relay, weights, gamma, beta, neigh, nt, eps):
+        buf = buf.contiguous()
+        new = torch.empty_like(buf)
+        conv = torch.empty((nt, buf.shape[1]), dtype=torch.float32, device=buf.device)
+        ops.cpe_forward(buf[:nt], weights, gamma, beta, neigh, True, eps, out=new[:nt], conv_out=conv)
+        new[nt:].copy_(buf[nt:] if relay is None else relay)
+        ctx.save_for_backward(buf, conv, weights, gamma, neigh)
+        ctx.nt, ctx.eps, ctx.has_relay = nt, eps, relay is not None
+        return new
+
+    @staticmethod
+    def backward(ctx, dnew):
+        from .dwconv import _inverse_of
+        buf, conv, weights, gamma, neigh = ctx.saved_tensors
+        need = ctx.needs_input_grad                    # (buf, relay, weights, gamma, beta, neigh, nt, eps)
+        nt = ctx.nt
+        dnew = dnew.contiguous()
+        dtok = dnew[:nt]
+        dconv, dg, dbeta = ops.layer_norm_bwd(dtok, conv, gamma, ctx.eps)
+        dbuf = None
+        if need[0]:
+            dbuf = torch.empty_like(buf)
+            ops.dwconv_add(dconv, weights, _inverse_of(neigh), dtok, out=dbuf[:nt])
+            if ctx.has_relay:
+                dbuf[nt:].zero_()                       # the buffer's old relay rows were replaced
+            else:
+                dbuf[nt:].copy_(dnew[nt:])
+        drelay = dnew[nt:] if (ctx.has_relay and need[1]) else None
+        dw = ops.dwconv_weight_backward(dconv, buf[:nt], neigh) if need[2] else None
+        return dbuf, drelay, dw, (dg if need[3] else None), (dbeta if need[4] else None), None, None, None
+
+
+def cpe_buffer(buf, relay, weights, gamma, beta, neigh, nt: int, eps: float):
+    return CpeBufferFn.apply(buf, relay, weights, gamma, beta, neigh, nt, eps)
+
+
 # ------------------------------------------------ LayerNorm with HIP forward and backward
 class LayerNormFn(torch.autograd.Function):
     """LayerNorm over the channel axis: `hfl_layer_norm` forward (keeps only its input), `hfl_layer_norm_bwd` backward.

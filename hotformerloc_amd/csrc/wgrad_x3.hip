@@ -206,11 +206,21 @@ wgrad_x3_kernel(const WgParams p) {
 }
 
 // out[i] = sum over slabs (fixed order): 64 float4 columns x 4 slab groups per workgroup, LDS combine
+// (the bias gradient's slabs ride in the same launch: workgroups past `blocks_a` reduce the second array -- 179 launches per
+//  config-3 step fewer)
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(float* __restrict__ out, const float* __restrict__ ws, int64_t n4, int S) {
+wgrad_reduce_kernel(float* out, const float* ws, int64_t n4, int S, int blocks_a, float* out_b, const float* ws_b,
+                    int64_t n4_b) {
   __shared__ float4 part[4][64];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + col;
+  int64_t blk = blockIdx.x;
+  if ((int)blockIdx.x >= blocks_a) {               // (workgroup-uniform)
+    blk -= blocks_a;
+    out = out_b;
+    ws = ws_b;
+    n4 = n4_b;
+  }
+  const int64_t i = blk * 64 + col;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n4) {
     const float4* src = reinterpret_cast<const float4*>(ws) + i;
@@ -276,9 +286,8 @@ int hfl_wgrad_x3(float* dw, float* db, const uint16_t* dy2, const uint16_t* x2, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   wgrad_x3_kernel<<<(unsigned)p.n_wg, 256, 2 * WG_TILE_B, s>>>(p);
   const int64_t n4 = out_features * in_features / 4;
-  wgrad_reduce_kernel<<<(unsigned)hfl_cdiv(n4, 64), 256, 0, s>>>(dw, p.ws, n4, sp.S);
-  if (db != nullptr)
-    wgrad_reduce_kernel<<<(unsigned)hfl_cdiv(out_features / 4, 64), 256, 0, s>>>(db, p.wsb, out_features / 4, sp.S);
+  const int blocks_a = (int)hfl_cdiv(n4, 64), blocks_b = db != nullptr ? (int)hfl_cdiv(out_features / 4, 64) : 0;
+  wgrad_reduce_kernel<<<(unsigned)(blocks_a + blocks_b), 256, 0, s>>>(dw, p.ws, n4, sp.S, blocks_a, db, p.wsb, out_features / 4);
   HFL_RETURN_LAST_ERROR();
 }
 

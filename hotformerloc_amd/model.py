@@ -119,6 +119,7 @@ _DROP_POOL = _knob('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draw
 # LN1 -> qkv -> window attention of a relay-token block's token rows as one launch (csrc/attn_ws.hip) from this many token rows
 _RTSA_SEGMENTS = _knob('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
 _TRAIN_CPE_FUSED = _knob('HFL_TRAIN_CPE_FUSED', '1') != '0'  # training CPE forward as the fused launch (autograd.CpeFn)
+_TRAIN_CPE_BUFFER = _knob('HFL_TRAIN_CPE_BUFFER', '1') != '0'     # probe: 0 = slices + torch.cat around the CPE of a block
 _RELAY_IN_PLACE = _knob('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
 _ATTN_WS = _knob('HFL_ATTN_WS', '1') != '0'
 _ATTN_WS_MIN_ROWS = int(_knob('HFL_ATTN_WS_MIN_ROWS', '40000'))
@@ -1120,7 +1121,13 @@ class HOTFormerBlock(nn.Module):
     def _forward(self, buf, plan: WindowPlan, depth: int, relay=None):
         nt = plan.n_tokens[depth]
         if _grad_path(buf):
-            buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:] if relay is None else relay], 0)
+            c = self.cpe
+            if (not c.xcpe and _TRAIN_CPE_FUSED and _TRAIN_CPE_BUFFER and buf.shape[1] in (32, 64, 128, 256) and buf.is_cuda
+                    and buf.dtype == torch.float32 and nt > 0):
+                # the CPE launch writes the token rows of the new [tokens | relay rows] buffer (no slices, no concatenation)
+                buf = ag.cpe_buffer(buf, relay, c.conv.weights, c.norm.weight, c.norm.bias, plan.neigh(depth), nt, c.norm.eps)
+            else:
+                buf = torch.cat([self.cpe(buf[:nt], plan, depth, residual=True), buf[nt:] if relay is None else relay], 0)
         else:                                   # CPE writes straight into the new buffer's token rows
             y = _native_block(self, buf, relay, plan, depth)
             if y is not None:

@@ -139,15 +139,20 @@ def dwconv_forward_backward(data: torch.Tensor, weight: torch.Tensor, neigh: tor
     return out
 
 
-def dwconv_add(data: torch.Tensor, weight: torch.Tensor, neigh: torch.Tensor, add=None):
+def dwconv_add(data: torch.Tensor, weight: torch.Tensor, neigh: torch.Tensor, add=None, out=None):
     """dwconv(data, weight, neigh) [+ add] through the CPE kernel's gather (hfl_dwconv_add): int32 table, C in {32, 64, 128,
-    256}; the data gradient of CPE (neigh = the inverse table, add = the skip connection's gradient)."""
-    _dev(data, weight, neigh, add)
+    256}; the data gradient of CPE (neigh = the inverse table, add = the skip connection's gradient).  `out`: a preallocated
+    contiguous (m, C) f32 view to write to (not `data`: the kernel gathers)."""
+    _dev(data, weight, neigh, add, out)
     data, weight = _f32c(data), _f32c(weight)
     assert neigh.dtype == torch.int32 and neigh.is_contiguous()
     m, k = neigh.shape
     c = data.shape[1]
-    out = torch.empty((m, c), dtype=torch.float32, device=data.device)
+    if out is None:
+        out = torch.empty((m, c), dtype=torch.float32, device=data.device)
+    else:
+        assert tuple(out.shape) == (m, c) and out.is_contiguous() and out.dtype == torch.float32
+        assert out.data_ptr() != data.data_ptr()
     if add is not None:
         add = _f32c(add)
         assert tuple(add.shape) == (m, c)

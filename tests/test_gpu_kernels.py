@@ -595,7 +595,7 @@ def test_relay_attention_init_and_stats(cfg, sizes, depth):
         lib.hfl_set_variant(b'relay_fast', 1)
     v3 = o3.float().view(o3.shape[0], C // 32, 2, 32)
     val3 = (v3[:, :, 0] + v3[:, :, 1]).reshape(o3.shape[0], C).cpu()
-    assert (val3 - val).abs().max().item() < 2e-6 * max(got.abs().max().item(), 1.0)
+    assert (val3 - val).abs().max().item() < 2e-5 * max(got.abs().max().item(), 1.0)       # (the output's (hi, lo) pair: 16 bits)
 
 
 def test_segment_softmax():
