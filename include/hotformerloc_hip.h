@@ -590,7 +590,11 @@ int64_t hfl_window_attention_bwd_workspace(const hfl_window_attn_desc* desc);
 int hfl_window_attention_bwd_det(float* dqkv, float* drpe_table, const float* qkv, const float* dout,
                                  const uint32_t* tok_meta, const float* rpe_table, const hfl_window_attn_desc* desc,
                                  void* workspace, hfl_stream_t stream);
-/* The same (workspace = NULL: the float-atomic table gradient of hfl_window_attention_bwd) with dqkv written as the split2
+/* (All three backward entry points, round 6: with desc->depth in 1..5 -- token coordinates < 32 -- the RPE-table gradient
+ * of models/layers/octformer_layers.py:144-174 is computed on the matrix cores as the diagonal sums of OHQ^T dS OHK, one-hot
+ * coordinate matrices of the window, summed over every window of a wave and reduced once in a fixed order; deeper levels or
+ * depth 0 = unknown keep the fixed-point LDS scatter-add.  The grid is the resident workgroup count of the instantiation.)
+ * The same (workspace = NULL: the float-atomic table gradient of hfl_window_attention_bwd) with dqkv written as the split2
  * operand (rows, 2 * 3 H 16) bf16 of the qkv layer's data- and weight-gradient GEMMs (round 6): bit for bit what hfl_split2
  * makes of the f32 gradient, which is never in memory (the training step spent 2 ms in that pass). */
 int hfl_window_attention_bwd_split2(uint16_t* dqkv_split2, float* drpe_table, const float* qkv, const float* dout,
