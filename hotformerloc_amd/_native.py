@@ -155,6 +155,7 @@ SIGNATURES = {
     'hfl_linear_x3_gelu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'hfl_tap_wgrad': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                              c_void_p]),
+    'hfl_slot_sum': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     'hfl_tap_wgrad_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                     c_int, c_void_p, c_void_p]),
     'hfl_wgrad_x3_workspace': (c_int64, [c_int64, c_int64, c_int64]),

@@ -185,7 +185,7 @@ class LiveTapConvFn(torch.autograd.Function):
                         torch.mm(g[edges[k]:edges[k + 1]], weights[k], out=part[edges[k]:edges[k + 1]])
             ctx.save_for_backward(g, weights)
         ctx.octree, ctx.key, ctx.n_src, ctx.grouped, ctx.x6 = octree, (depth, kernel, stride), data.shape[0], grouped, x6
-        return ops.dwconv_forward_backward(part, _unit_taps(kdim, cout, data.device), slot)
+        return ops.slot_sum(part, slot) if _slot_sum_ok(part, slot) else ops.dwconv_forward_backward(part, _unit_taps(kdim, cout, data.device), slot)
 
     @staticmethod
     def backward(ctx, dout):
@@ -228,8 +228,13 @@ class LiveTapConvFn(torch.autograd.Function):
                     a, b = edges[k], edges[k + 1]
                     if b > a:
                         torch.mm(dpart[a:b], weights[k].t(), out=dg[a:b])
-            ddata = ops.dwconv_forward_backward(dg, _unit_taps(kdim, cin, dg.device), inv_slot)
+            ddata = (ops.slot_sum(dg, inv_slot) if _slot_sum_ok(dg, inv_slot)
+                     else ops.dwconv_forward_backward(dg, _unit_taps(kdim, cin, dg.device), inv_slot))
         return ddata, dw, None, None, None, None
+
+
+def _slot_sum_ok(part, slot) -> bool:
+    return part.shape[1] % 4 == 0 and part.shape[1] <= 1024 and slot.shape[1] <= 27 and slot.dtype == torch.int32
 
 
 def _grouped_ok(cin, cout) -> bool:

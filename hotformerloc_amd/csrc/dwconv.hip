@@ -93,6 +93,48 @@ __global__ void __launch_bounds__(256) dwconv_fwd_vec4(float* __restrict__ out, 
   }
 }
 
+// out[h] = sum over the row's live slots of part[slot[h, k]] [+ bias]: the second half of an octree convolution over its live
+// (row, tap) pairs (model.OctreeConv._forward_live_taps: every output row adds its own partial products, in tap order, no
+// atomics).  Rounds 1-5 ran it as the depth-wise convolution above with unit weights -- 27 x C ones staged in LDS and a
+// multiply per element -- and added the convolution's bias in a separate pass; the sums are bitwise the same.
+template <int B>
+__global__ void __launch_bounds__(256) slot_sum_kernel(float* __restrict__ out, const float* __restrict__ part,
+                                                        const int32_t* __restrict__ slot, const float* __restrict__ bias,
+                                                        int64_t n_out, int C, int K, int tpr, int rpb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* s_idx = reinterpret_cast<int32_t*>(smem);
+  const int tx = threadIdx.x % tpr, ty = threadIdx.x / tpr;
+  const float4 bv = bias != nullptr ? reinterpret_cast<const float4*>(bias)[tx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t base = (int64_t)blockIdx.x * rpb; base < n_out; base += (int64_t)gridDim.x * rpb) {
+    const int64_t h = base + ty;
+    const bool live = h < n_out;
+    __syncthreads();
+    if (live)
+      for (int k = tx; k < K; k += tpr) s_idx[ty * K + k] = slot[h * K + k];
+    __syncthreads();
+    if (!live) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += B) {
+      float4 v[B];
+      bool ok[B];
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        const int k = k0 + j;
+        int64_t ni = (k < K) ? (int64_t)s_idx[ty * K + k] : -1;
+        ok[j] = ni >= 0;
+        if (!ok[j]) ni = 0;
+        v[j] = reinterpret_cast<const float4*>(part + ni * C)[tx];
+      }
+#pragma unroll
+      for (int j = 0; j < B; ++j)
+        if (ok[j]) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+    }
+    if (bias != nullptr) { acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w; }
+    reinterpret_cast<float4*>(out + h * C)[tx] = acc;
+  }
+}
+
 // any channel count (scalar lanes), used when C % 4 != 0 or C > 1024
 template <typename IdxT>
 __global__ void dwconv_fwd_scalar(float* __restrict__ out, const float* __restrict__ data,
@@ -582,6 +624,24 @@ int hfl_inverse_table(int32_t* inverse, int64_t n_src_rows, const int32_t* table
   const int64_t need = hfl_cdiv(n_dst_rows * kngh, 256);
   const int blocks = (int)(need < 4096 ? need : 4096);
   inverse_neigh_kernel<int32_t><<<blocks, 256, 0, s>>>(inverse, table, n_dst_rows, kngh);
+  HFL_RETURN_LAST_ERROR();
+}
+
+/* see include/hotformerloc_hip.h */
+int hfl_slot_sum(float* out, const float* part, const int32_t* slot, const float* bias, int64_t n_out, int64_t channels, int kngh,
+                 hfl_stream_t stream) {
+  if (n_out < 0 || channels <= 0 || channels % 4 != 0 || channels > 1024 || kngh <= 0 || kngh > kMaxTaps) return HFL_EINVAL;
+  if (n_out == 0) return HFL_OK;
+  if (out == nullptr || part == nullptr || slot == nullptr) return HFL_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const RowGeom g = row_geom(channels);
+  const size_t lds = (size_t)g.rpb * kngh * sizeof(int32_t);
+  static int nb = 0;
+  static size_t nb_lds = 0;
+  const int per_cu = persistent_per_cu(reinterpret_cast<const void*>(slot_sum_kernel<9>), g.tpr * g.rpb, lds, 8, &nb, &nb_lds);
+  const int64_t need = hfl_cdiv(n_out, g.rpb), cap = (int64_t)hfl_stream_cus(s) * per_cu;
+  slot_sum_kernel<9><<<(int)(need < cap ? need : cap), g.tpr * g.rpb, lds, s>>>(out, part, slot, bias, n_out, (int)channels, kngh,
+                                                                               g.tpr, g.rpb);
   HFL_RETURN_LAST_ERROR();
 }
 

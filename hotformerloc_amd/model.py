@@ -592,8 +592,7 @@ class OctreeConv(nn.Module):
                 gs = ops.octree_gather(d2.view(torch.float32), src).view(torch.bfloat16)
                 part = ops.linear_x3_grouped(gs, self._tap_weights_split2(npad),
                                              octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
-            out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
-            return out if self.bias is None else out + self.bias
+            return self._slot_sum(part, slot)
         if (_GEMM_MODE == 'x6' and _GROUPED_TAPS and not _grad_path() and data.dtype == torch.float32 and edges[-1] > 0
                 and self.in_channels % 32 == 0 and (self.out_channels % 128 == 0 or self.out_channels == 64)):
             # matched precision: the same grouped launch on hfl_linear_x6 (fp32-grade products; the tile loader gathers the pairs'
@@ -601,8 +600,7 @@ class OctreeConv(nn.Module):
             npad = max(self.out_channels, 128)
             part = ops.linear_x6_grouped_gather(data, src, self._tap_weights_x6(npad),
                                                 octree.tap_tiles(depth, self.kernel, self.stride, npad), self.out_channels)
-            out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
-            return out if self.bias is None else out + self.bias
+            return self._slot_sum(part, slot)
         g = ops.octree_gather(data, src)                                  # (P, Cin)
         part = torch.empty((g.shape[0], self.out_channels), dtype=torch.float32, device=data.device)
         w = self.weights
@@ -622,7 +620,13 @@ class OctreeConv(nn.Module):
         else:
             for k in live:
                 torch.mm(g[edges[k]:edges[k + 1]], w[k], out=part[edges[k]:edges[k + 1]])
-        out = ops.dwconv_forward_backward(part, self._unit(data.device), slot)
+        return self._slot_sum(part, slot)
+
+    def _slot_sum(self, part, slot):
+        """every output row adds the partial products of its own live taps (+ the bias) in one pass (hfl_slot_sum)"""
+        if part.shape[1] % 4 == 0 and part.shape[1] <= 1024 and slot.shape[1] <= 27 and slot.dtype == torch.int32:
+            return ops.slot_sum(part, slot, self.bias)
+        out = ops.dwconv_forward_backward(part, self._unit(part.device), slot)
         return out if self.bias is None else out + self.bias
 
     def _unit(self, device):

@@ -161,6 +161,20 @@ def dwconv_add(data: torch.Tensor, weight: torch.Tensor, neigh: torch.Tensor, ad
     return out
 
 
+def slot_sum(part: torch.Tensor, slot: torch.Tensor, bias=None):
+    """out[h] = sum of part[slot[h, k]] over the row's live slots [+ bias] (hfl_slot_sum): the per-row sum of the partial
+    products of a live-tap octree convolution.  part (P, C) f32, slot (n_out, K) int32 (-1 = none)."""
+    _dev(part, slot, bias)
+    part = _f32c(part)
+    assert slot.dtype == torch.int32 and slot.is_contiguous() and slot.dim() == 2
+    n, k = slot.shape
+    c = part.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=part.device)
+    check(_native.load().hfl_slot_sum(out.data_ptr(), part.data_ptr(), slot.data_ptr(),
+                                      None if bias is None else _f32c(bias).data_ptr(), n, c, k, _stream()), 'hfl_slot_sum')
+    return out
+
+
 def dwconv_weight_backward(grad: torch.Tensor, data: torch.Tensor, neigh: torch.Tensor):
     """libs/dwconv/csrc/dwconv.h:14 -- -> (K,1,C)."""
     _dev(grad, data, neigh)

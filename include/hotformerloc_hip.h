@@ -51,6 +51,14 @@ int hfl_dwconv_forward_backward(float* out, const float* data, const float* weig
                                 const void* neigh, int idx64, int64_t n_out,
                                 int64_t channels, int kngh, hfl_stream_t stream);
 
+/* out[h,c] = sum_k [slot[h,k] >= 0] part[slot[h,k], c] [+ bias[c]]  (round 6): the per-row sum of the partial products of an
+ * octree convolution over its live (row, tap) pairs -- ocnn's octree2col + mm scatters nothing, it multiplies the zero-padded
+ * column matrix (models/layers/octformer_layers.py:89-95); here every output row adds the products of its own live taps in tap
+ * order -- and the convolution's bias.  part (P, C) f32, slot (n_out, K) int32, -1 = no such neighbour, bias (C) or NULL.
+ * Equals hfl_dwconv_forward_backward with unit weights (what rounds 1-5 launched) bit for bit. */
+int hfl_slot_sum(float* out, const float* part, const int32_t* slot, const float* bias, int64_t n_out, int64_t channels, int kngh,
+                 hfl_stream_t stream);
+
 /* gW[k,c] = sum_h [neigh[h,k] >= 0] data[neigh[h,k], c] * grad[h,c]
  *   replaces  Tensor dwconv_weight_backward(Tensor grad, Tensor data, Tensor neigh)
  *             libs/dwconv/csrc/dwconv.h:14, dwconv.cu:44-72,115-131, pybind.cpp:12

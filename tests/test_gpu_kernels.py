@@ -226,6 +226,19 @@ def test_live_tap_conv_gradients_match_the_dense_formulation():
             assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6, (depth, ks, stride, what)
 
 
+def test_slot_sum_equals_the_unit_weight_convolution():
+    """hfl_slot_sum (the per-row sum of a live-tap convolution's partial products, bias included) is bitwise the depth-wise
+    convolution with unit weights it replaced, plus the bias."""
+    g = torch.Generator().manual_seed(12)
+    for n, p, c, k in ((1, 5, 256, 27), (1000, 7000, 64, 27), (4099, 9000, 128, 8), (300, 900, 32, 27)):
+        slot = torch.randint(-1, p, (n, k), generator=g, dtype=torch.int32).to(DEV)
+        part = torch.randn(p, c, generator=g).to(DEV)
+        bias = torch.randn(c, generator=g).to(DEV)
+        want = ops.dwconv_forward_backward(part, torch.ones(k, 1, c, device=DEV), slot)
+        assert torch.equal(ops.slot_sum(part, slot), want), (n, c, k)
+        assert torch.equal(ops.slot_sum(part, slot, bias), want + bias), (n, c, k)
+
+
 def test_dwconv_weight_gradient_at_small_and_ragged_row_counts():
     """hfl_dwconv_weight_backward deals the rows to the eight XCDs in contiguous eighths: row counts below one workgroup per
     XCD, one row, and counts that are no multiple of the rows per workgroup must still visit every row once."""
