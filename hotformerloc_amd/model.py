@@ -119,6 +119,7 @@ _DROP_POOL = _knob('HFL_DROP_POOL', '1') != '0'          # stochastic-depth draw
 # LN1 -> qkv -> window attention of a relay-token block's token rows as one launch (csrc/attn_ws.hip) from this many token rows
 _RTSA_SEGMENTS = _knob('HFL_RTSA_SEGMENTS', '1') != '0'  # RTSA reads the levels' relay rows in place (no torch.cat)
 _TRAIN_CPE_FUSED = _knob('HFL_TRAIN_CPE_FUSED', '1') != '0'  # training CPE forward as the fused launch (autograd.CpeFn)
+_CPE_FIRST = _knob('HFL_CPE_FIRST', '0') != '0'       # plain schedule: the finest level's CPE before the relay-token block (same stream)
 _TRAIN_CPE_BUFFER = _knob('HFL_TRAIN_CPE_BUFFER', '1') != '0'     # probe: 0 = slices + torch.cat around the CPE of a block
 _RELAY_IN_PLACE = _knob('HFL_RELAY_IN_PLACE', '1') != '0'  # blocks read RTSA's relay rows in place (no copy launch)
 _ATTN_WS = _knob('HFL_ATTN_WS', '1') != '0'
@@ -1535,6 +1536,17 @@ class HOTFormerStage(nn.Module):
                     done = [st.record_event() for st in dict.fromkeys(sts)]
                 del calls, old, fresh, rt_all
                 continue
+            call0 = None
+            if (_CPE_FIRST and _PYRAMID_STREAMS and not _SERIAL_STREAMS and not ckpt and not _grad_path(data) and data.is_cuda
+                    and not proj):
+                # Probe (off): the finest level's CPE, which reads token rows only, issued BEFORE the relay-token block on the same
+                # stream (no event hop), so that it runs alone instead of behind the coarse levels' forked launches (kernel
+                # timeline profiles/r06_x_phases_iteration_5.log: 131 us there, 44 us alone).  Measured -1.9 % on the headline,
+                # Oxford -0.4 % (profiles/r06_aa_ab_cpe_first.log): the relay-token block then starts 44 us later and everything
+                # that waits for it with it.
+                call0 = _native_block_call(self.hosa_blocks[0][i], bufs[depths[0]], plan, depths[0])
+                if call0 is not None:
+                    call0.run(1)
             if ckpt:                                                    # 596-601
                 rt_all = _checkpoint_block(self.rtsa_blocks[i], torch.cat([rts[d] for d in depths], 0), plan)
             else:
@@ -1561,11 +1573,14 @@ class HOTFormerStage(nn.Module):
                         bufs[d], rts[d] = hosa(j, d, i, bufs[d], fresh[d])
                     used.append(j)
                 for j, d in enumerate(depths):
-                    if j not in used:
+                    if j == 0 and call0 is not None:            # the rest of the block whose CPE went out before RTSA
+                        out = self.hosa_blocks[0][i]._tail(call0.run(2, fresh[d]), plan, d)
+                        bufs[d], rts[d] = out, out[nts[0]:]
+                    elif j not in used:
                         bufs[d], rts[d] = hosa(j, d, i, bufs[d], fresh[d])
                 for j in used:
                     main.wait_stream(side[j - 1])
-                del keep
+                del keep, call0
             else:
                 for j, d in enumerate(depths):
                     bufs[d], rts[d] = hosa(j, d, i, bufs[d], fresh[d])
